@@ -1,0 +1,615 @@
+/*
+ * or_assembly.c -- constraint-row assembly of the four filter variants.
+ * TEST INFRASTRUCTURE (see or_oracle.h).  Each function names the reference lines it restates.
+ */
+#include "or_internal.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static __thread int g_last_crit[16];
+static __thread int g_last_ncrit;
+
+int or_last_crit_idx(int *idx, int cap)
+{
+	int n = g_last_ncrit < cap ? g_last_ncrit : cap;
+	for (int i = 0; i < n; i++) idx[i] = g_last_crit[i];
+	return n;
+}
+
+/* Option values exactly as the example main()s set them before initialize():
+ *  C2 examples/DoubleIntegrator.cpp:15-16,69-70 (initialize(lb,ub) -> struct defaults, include/asif.h:13-16)
+ *  C3 examples/InvertedPendulum_Implicit.cpp:19-20,93-97
+ *  C4 examples/segway_implicit_tb.cpp:18-19,223-230
+ *  C5 examples/InvertedPendulum_Robust.cpp:23-24,35-38,120-121 (ROBUST build flavour) + SURVEY 8(d) half-planes */
+void or_default_options(int model, int variant, or_options *o)
+{
+	memset(o, 0, sizeof(*o));
+	o->relaxCost = 50.0;
+	o->relaxLb = 5.0;
+	o->relaxReachLb = 5.0;
+	o->relaxTTS = 5.0;
+	o->relaxMinOrtho = 5.0;
+	o->backTrajHorizon = 1.0;
+	o->backTrajExtend = 0.05;
+	o->backTrajDt = 0.01;
+	o->backTrajMinOrtho = 0.01;
+	o->satSharpness = (variant == OR_VARIANT_EXPLICIT) ? 5.0 : 0.1;
+	o->inf = 1e20;
+	o->pMin = o->pMax = 1.0;
+	switch (model) {
+	case OR_MODEL_DOUBLE_INTEGRATOR:
+		o->lb[0] = -1.0;
+		o->ub[0] = 1.0;
+		break;
+	case OR_MODEL_INVERTED_PENDULUM:
+		o->lb[0] = -1.5;
+		o->ub[0] = 1.5;
+		o->backTrajHorizon = 5.0;
+		o->backTrajDt = 0.001;
+		o->relaxReachLb = 5.0;
+		o->relaxLb = 10.0;
+		break;
+	case OR_MODEL_SEGWAY:
+		o->lb[0] = -20.0;
+		o->ub[0] = 20.0;
+		o->backTrajHorizon = 3.0;
+		o->backTrajDt = 0.01;
+		o->relaxCost = 10;
+		o->relaxLb = 2.0;
+		o->relaxTTS = 30.0;
+		o->relaxMinOrtho = 60.0;
+		o->backTrajMinOrtho = 0.001;
+		break;
+	case OR_MODEL_INVERTED_PENDULUM_ROBUST: {
+		o->lb[0] = -1.5;
+		o->ub[0] = 1.5;
+		o->pMin = 0.8;
+		o->pMax = 1.2;
+		o->nHalfPlanes = 4;
+		const double a = 1.0 / M_PI;
+		const double hp[8] = {a, 0, -a, 0, 0, a, 0, -a};
+		memcpy(o->halfPlanes, hp, sizeof(hp));
+		break;
+	}
+	default:
+		break;
+	}
+}
+
+static int traj_len(int variant, const or_options *o, int npBTSS, double *dt_out)
+{
+	/* src/asif_implicit.cpp:211-216; src/asif_implicit_tb.cpp:177-182 (with the (1+extend) factor) */
+	double T = o->backTrajHorizon;
+	if (variant == OR_VARIANT_IMPLICIT_TB) T = o->backTrajHorizon * (1.0 + o->backTrajExtend);
+	double dt = o->backTrajDt;
+	int npBT = (int)(round(T / dt) + 1);
+	if (npBT < npBTSS) {
+		npBT = npBTSS;
+		dt = T / (double)(npBT - 1);
+	}
+	if (dt_out) *dt_out = dt;
+	return npBT;
+}
+
+int or_get_dims(int model, int variant, const or_options *o, or_dims *d)
+{
+	const or_model *m = or_model_get(model);
+	if (!m) return -1;
+	memset(d, 0, sizeof(*d));
+	d->nx = m->nx;
+	d->nu = m->nu;
+	d->npSS = m->npSS;
+	d->npBS = m->npBS;
+	switch (variant) {
+	case OR_VARIANT_EXPLICIT: /* src/asif.cpp:17-22 */
+		if (!m->dynamics || model == OR_MODEL_INVERTED_PENDULUM_ROBUST) return -1;
+		d->nv = m->nu + 1;
+		d->nc = m->npSS;
+		d->nrelax = 1;
+		break;
+	case OR_VARIANT_IMPLICIT: /* src/asif_implicit.cpp:121-129 */
+		if (!m->controller) return -1;
+		d->npBTSS = 10; /* examples/InvertedPendulum_Implicit.cpp:17 */
+		d->nv = m->nu + 2;
+		d->nc = d->npBTSS * m->npSS + m->npBS;
+		d->nrelax = 2;
+		d->npBT = traj_len(variant, o, d->npBTSS, 0);
+		break;
+	case OR_VARIANT_IMPLICIT_TB: /* src/asif_implicit_tb.cpp:118-125 */
+		if (!m->controller) return -1;
+		d->npBTSS = 4; /* examples/segway_implicit_tb.cpp:16 */
+		d->nv = m->nu + 1;
+		d->nc = d->npBTSS * m->npSS + 2;
+		d->nrelax = 1;
+		d->npBT = traj_len(variant, o, d->npBTSS, 0);
+		break;
+	case OR_VARIANT_ROBUST: /* src/asif_robust.cpp:17-22, npSSmax = npSS */
+		if (!m->dynamics_af) return -1;
+		d->npSS = o->nHalfPlanes;
+		d->nv = m->nu + 1 + d->npSS * 2 * (m->nu + 1);
+		d->nc = d->npSS * (1 + (m->nu + 1));
+		d->nrelax = 1;
+		break;
+	default:
+		return -1;
+	}
+	return 0;
+}
+
+/* ---------------------------------------------------------------- explicit */
+/* src/asif.cpp:233-312 with npSSmax == npSS (no row subset) */
+static int assemble_explicit(const or_model *m, const or_options *o, const double *x, double *A, double *b)
+{
+	const int nx = m->nx, nu = m->nu, np = m->npSS, nc = np;
+	double h[OR_MAX_NPSS], Dh[OR_MAX_NPSS * OR_MAX_NX], f[OR_MAX_NX], g[OR_MAX_NX * OR_MAX_NU];
+	double Lfh[OR_MAX_NPSS], Lgh[OR_MAX_NPSS * OR_MAX_NU];
+	m->safety(o, x, h, Dh);
+	m->dynamics(o, x, f, g);
+	or_matvec(Dh, np, nx, f, Lfh);
+	or_matmul(Dh, np, nx, g, nu, Lgh);
+	for (int i = 0; i < np; i++) {
+		for (int j = 0; j < nu; j++) A[i + j * nc] = Lgh[i + j * np];
+		A[i + nu * nc] = h[i];
+		b[i] = -Lfh[i];
+	}
+	return 1;
+}
+
+/* ------------------------------------------------- backup closed loop (shared) */
+/* src/asif_implicit.cpp:682-737 == src/asif_implicit_tb.cpp:764-819 */
+static void saturate_soft(const or_model *m, const or_options *o, const double *u, double *uSat, double *DuSat)
+{
+	const double r = o->satSharpness;
+	const double alpha = M_PI / 8;
+	const double beta = M_PI / 4;
+	for (int i = 0; i < m->nu; i++) {
+		const double mi = o->lb[i], ma = o->ub[i];
+		const double range = ma - mi;
+		const double middle = (ma + mi) / 2;
+		const double uc = 2 * (u[i] - middle) / range;
+		const double bevelL = r * tan(alpha);
+		const double bevelStart = 1 - cos(beta) * bevelL;
+		const double bevelStop = 1 + bevelL;
+		const double bevelXc = bevelStop;
+		const double bevelYc = 1 - r;
+		if (uc >= bevelStop) {
+			uSat[i] = ma;
+			DuSat[i] = 0;
+		} else if (uc <= -bevelStop) {
+			uSat[i] = mi;
+			DuSat[i] = 0;
+		} else if (uc <= bevelStart && uc >= -bevelStart) {
+			uSat[i] = u[i];
+			DuSat[i] = 1;
+		} else if (uc > bevelStart) {
+			uSat[i] = sqrt(r * r - (uc - bevelXc) * (uc - bevelXc)) + bevelYc;
+			DuSat[i] = (bevelXc - uc) / sqrt(r * r - (uc - bevelXc) * (uc - bevelXc));
+			uSat[i] = 0.5 * uSat[i] * range + middle;
+		} else if (uc < -bevelStart) {
+			uSat[i] = -sqrt(r * r - (uc + bevelXc) * (uc + bevelXc)) - bevelYc;
+			DuSat[i] = (bevelXc + uc) / sqrt(r * r - (uc + bevelXc) * (uc + bevelXc));
+			uSat[i] = 0.5 * uSat[i] * range + middle;
+		} else { /* NaN input */
+			DuSat[i] = 1;
+			uSat[i] = u[i];
+		}
+	}
+}
+
+/* src/asif_implicit.cpp:751-815 (separate dynamics + dynamicsGradients branch, :789-807) */
+static void backup_cl(const or_model *m, const or_options *o, const double *x, double *fCL, double *DfCL)
+{
+	const int nx = m->nx, nu = m->nu;
+	double f[OR_MAX_NX], g[OR_MAX_NX * OR_MAX_NU], u[OR_MAX_NU], Du[OR_MAX_NU * OR_MAX_NX];
+	double uSat[OR_MAX_NU], DuSat[OR_MAX_NU];
+	double Df[OR_MAX_NX * OR_MAX_NX], Dg[OR_MAX_NX * OR_MAX_NU * OR_MAX_NX];
+	m->controller(o, x, u, Du);
+	saturate_soft(m, o, u, uSat, DuSat);
+	m->dynamics(o, x, f, g);
+	m->gradients(o, x, Df, Dg);
+	for (int i = 0; i < nx; i++)
+		for (int j = 0; j < nx; j++) {
+			const int id = i + j * nx;
+			DfCL[id] = Df[id];
+			for (int k = 0; k < nu; k++)
+				DfCL[id] += Dg[i + k * nx + j * nx * nu] * uSat[k] + g[i + k * nx] * DuSat[k] * Du[k + j * nu];
+		}
+	or_matvec(g, nx, nu, uSat, fCL);
+	for (int i = 0; i < nx; i++) fCL[i] += f[i];
+}
+
+/* src/asif_implicit.cpp:817-827: z = [x; vec Q], zdot = [fCL; DfCL*Q] */
+static void ode_rhs(const or_model *m, const or_options *o, const double *z, double *zdot)
+{
+	double DfCL[OR_MAX_NX * OR_MAX_NX];
+	backup_cl(m, o, z, zdot, DfCL);
+	or_matmul(DfCL, m->nx, m->nx, z + m->nx, m->nx, zdot + m->nx);
+}
+
+typedef struct {
+	int npBT, nz;
+	double dt;
+	double *t;     /* [npBT] accumulated sample times */
+	double *z;     /* [npBT][nz] */
+	double *hFull; /* [npBT][npSS] */
+	double *DhFull;/* [npBT][npSS*nx] */
+	double *hMin;  /* [npBT] */
+	int *order;    /* [npBT] */
+} traj_t;
+
+static void traj_free(traj_t *T)
+{
+	free(T->t); free(T->z); free(T->hFull); free(T->DhFull); free(T->hMin); free(T->order);
+}
+
+/* src/asif_implicit.cpp:417-425,461-484 == src/asif_implicit_tb.cpp:421-430,464-488:
+ * forward Euler on [x; vec Q], Q(0)=I, time ignored by the rhs; safety set sampled at every point */
+static void integrate(const or_model *m, const or_options *o, int variant, int npBTSS, const double *x, traj_t *T)
+{
+	const int nx = m->nx, np = m->npSS, nz = nx + nx * nx;
+	T->npBT = traj_len(variant, o, npBTSS, &T->dt);
+	T->nz = nz;
+	const int n = T->npBT;
+	T->t = (double *)calloc(n, sizeof(double));
+	T->z = (double *)calloc((size_t)n * nz, sizeof(double));
+	T->hFull = (double *)calloc((size_t)n * np, sizeof(double));
+	T->DhFull = (double *)calloc((size_t)n * np * nx, sizeof(double));
+	T->hMin = (double *)calloc(n, sizeof(double));
+	T->order = (int *)calloc(n, sizeof(int));
+	double *z0 = T->z;
+	for (int i = 0; i < nx; i++) z0[i] = x[i];
+	for (int i = nx; i < nz; i += nx + 1) z0[i] = 1.0;
+	double zdot[OR_MAX_NX + OR_MAX_NX * OR_MAX_NX];
+	for (int i = 0; i < n; i++) {
+		double *zi = T->z + (size_t)i * nz;
+		if (i > 0) {
+			const double *zp = zi - nz;
+			T->t[i] = T->t[i - 1] + T->dt;
+			ode_rhs(m, o, zp, zdot);
+			for (int k = 0; k < nz; k++) zi[k] = zdot[k] * T->dt;
+			for (int k = 0; k < nz; k++) zi[k] = zi[k] + zp[k];
+		}
+		double *hi = T->hFull + (size_t)i * np;
+		m->safety(o, zi, hi, T->DhFull + (size_t)i * np * nx);
+		double mn = hi[0];
+		for (int k = 1; k < np; k++)
+			if (hi[k] < mn) mn = hi[k];
+		T->hMin[i] = mn;
+		T->order[i] = i;
+	}
+}
+
+/* Indexes of the smallest hMin first; ties -> lowest index first.  The reference uses std::sort
+ * (src/asif_implicit.cpp:487), whose order among equal keys is implementation-defined
+ * (SURVEY App. B 3); "lowest index wins" is this build's fixed rule, on device too.
+ * Only the leading npBTSS (<=10) entries are ever consumed, so a partial selection suffices. */
+static void sort_by_hmin(traj_t *T, int count)
+{
+	const int want = count < 16 ? count : 16;
+	for (int k = 0; k < want; k++) {
+		int best = k;
+		for (int i = k + 1; i < count; i++) {
+			const int a = T->order[i], c = T->order[best];
+			if (T->hMin[a] < T->hMin[c] || (T->hMin[a] == T->hMin[c] && a < c)) best = i;
+		}
+		const int tmp = T->order[k];
+		T->order[k] = T->order[best];
+		T->order[best] = tmp;
+	}
+}
+
+/* ---------------------------------------------------------------- implicit */
+/* src/asif_implicit.cpp:403-651 */
+static int assemble_implicit(const or_model *m, const or_options *o, const double *x, double *A, double *b)
+{
+	const int nx = m->nx, nu = m->nu, np = m->npSS, nb = m->npBS, npBTSS = 10;
+	const int nTC = npBTSS * np + nb, nv = nu + 2;
+	double f[OR_MAX_NX], g[OR_MAX_NX * OR_MAX_NU];
+	m->dynamics(o, x, f, g);
+	traj_t T;
+	integrate(m, o, OR_VARIANT_IMPLICIT, npBTSS, x, &T);
+	sort_by_hmin(&T, T.npBT);
+
+	double h[64] = {0.0}, Dh[64 * OR_MAX_NX] = {0.0};
+	double DhSSDx[OR_MAX_NPSS * OR_MAX_NX], DhBS[OR_MAX_NX], DhBSDx[OR_MAX_NX];
+	g_last_ncrit = npBTSS;
+	for (int idx = 0; idx < npBTSS; idx++) {
+		const int cur = T.order[idx];
+		g_last_crit[idx] = cur;
+		memcpy(&h[idx * np], &T.hFull[(size_t)cur * np], np * sizeof(double));
+		const double *DhSS = &T.DhFull[(size_t)cur * np * nx];
+		const double *Q = T.z + (size_t)cur * T.nz + nx;
+		or_matmul(DhSS, np, nx, Q, nx, DhSSDx);
+		for (int i = 0; i < np; i++)
+			for (int j = 0; j < nx; j++) Dh[(idx * np + i) + j * nTC] = DhSSDx[i + j * np];
+	}
+	const double *zend = T.z + (size_t)(T.npBT - 1) * T.nz;
+	m->backup(o, zend, &h[npBTSS * np], DhBS, 0);
+	or_matmul(DhBS, nb, nx, zend + nx, nx, DhBSDx);
+	for (int i = 0; i < nb; i++)
+		for (int j = 0; j < nx; j++) Dh[(npBTSS * np + i) + j * nTC] = DhBSDx[i + j * nb];
+
+	double Lfh[64], Lgh[64 * OR_MAX_NU];
+	or_matvec(Dh, nTC, nx, f, Lfh);
+	or_matmul(Dh, nTC, nx, g, nu, Lgh);
+	/* :591-611 */
+	for (int i = 0; i < nTC * nv; i++) A[i] = 0.0;
+	for (int i = 0; i < nTC; i++)
+		for (int j = 0; j < nu; j++) A[i + j * nTC] = Lgh[i + j * nTC];
+	for (int i = 0; i < npBTSS * np; i++) A[i + nu * nTC] = h[i];
+	for (int i = npBTSS * np; i < nTC; i++) A[i + (nu + 1) * nTC] = h[i];
+	for (int i = 0; i < nTC; i++) b[i] = -Lfh[i];
+	traj_free(&T);
+	return 1;
+}
+
+/* ---------------------------------------------------------------------- TB */
+/* src/asif_implicit_tb.cpp:716-733 */
+static void assemble_tb_trivial(const or_options *o, int nTC, int nv, double *A, double *b, double *diag)
+{
+	for (int i = 0; i < nTC * nv; i++) A[i] = 0.0;
+	for (int i = 0; i < nTC; i++) b[i] = -o->inf;
+	if (diag) {
+		diag[0] = 0.0; /* TTS_ */
+		diag[1] = 1.0; /* BTorthoBS_ */
+		diag[2] = 0.0;
+	}
+}
+
+/* src/asif_implicit_tb.cpp:407-714; returns 1, or -1 when the backup set is never hit (:529-536) */
+static int assemble_tb(const or_model *m, const or_options *o, const double *x, double *A, double *b, double *diag)
+{
+	const int nx = m->nx, nu = m->nu, np = m->npSS, npBTSS = 4;
+	const int nTC = npBTSS * np + 2;
+	double f[OR_MAX_NX], g[OR_MAX_NX * OR_MAX_NU];
+	m->dynamics(o, x, f, g);
+	traj_t T;
+	integrate(m, o, OR_VARIANT_IMPLICIT_TB, npBTSS, x, &T);
+
+	/* time-to-safety scan, :490-536 -- effectively "first hit wins" */
+	double hBSnm1 = -1.0, hBS[1] = {0}, DhBS[OR_MAX_NX], DDhBS[OR_MAX_NX * OR_MAX_NX];
+	int BSHit = 0, idxHit = 0;
+	double cosTilde[1] = {0}, fClBS[OR_MAX_NX], DfClBS[OR_MAX_NX * OR_MAX_NX];
+	double den1 = 0, den2 = 0, den = 0, ortho = 0;
+	const double *btX = 0;
+	for (int i = 1; i < T.npBT; i++) {
+		if (hBSnm1 < 0.0) {
+			m->backup(o, T.z + (size_t)i * T.nz, hBS, DhBS, DDhBS);
+			if (hBS[0] >= 0.0) {
+				idxHit = i;
+				BSHit = 1;
+				btX = T.z + (size_t)i * T.nz;
+				backup_cl(m, o, btX, fClBS, DfClBS);
+				or_matmul(DhBS, 1, nx, fClBS, 1, cosTilde);
+				den1 = or_vecnorm(DhBS, nx);
+				den2 = or_vecnorm(fClBS, nx);
+				den = den1 * den2;
+				ortho = cosTilde[0] / den;
+				if (ortho > 2.0 * o->backTrajMinOrtho) break;
+			}
+		}
+		hBSnm1 = hBS[0];
+	}
+	if (!BSHit) {
+		if (diag) {
+			diag[1] = 0;
+		}
+		traj_free(&T);
+		return -1;
+	}
+	sort_by_hmin(&T, idxHit + 1);
+
+	double h[32] = {0.0}, Dh[32 * OR_MAX_NX] = {0.0};
+	double DhSSDx[OR_MAX_NPSS * OR_MAX_NX], DhBSDx[OR_MAX_NX];
+	g_last_ncrit = 0;
+	for (int idx = 0; idx < npBTSS; idx++) {
+		if (idx > idxHit) { /* fewer trajectory points than rows: inert padding, :556-566 */
+			for (int i = 0; i < np; i++) {
+				h[idx * np + i] = 1.0;
+				for (int j = 0; j < nx; j++) Dh[(idx * np + i) + j * nTC] = 0.0;
+			}
+		} else {
+			const int cur = T.order[idx];
+			g_last_crit[g_last_ncrit++] = cur;
+			memcpy(&h[idx * np], &T.hFull[(size_t)cur * np], np * sizeof(double));
+			const double *DhSS = &T.DhFull[(size_t)cur * np * nx];
+			or_matmul(DhSS, np, nx, T.z + (size_t)cur * T.nz + nx, nx, DhSSDx);
+			for (int i = 0; i < np; i++)
+				for (int j = 0; j < nx; j++) Dh[(idx * np + i) + j * nTC] = DhSSDx[i + j * np];
+		}
+	}
+	/* time-to-safety row, :588-599 */
+	const double TTS = T.t[idxHit];
+	const double hReach = o->backTrajHorizon - T.t[idxHit];
+	const double *btDX = btX + nx;
+	or_matmul(DhBS, 1, nx, btDX, nx, DhBSDx);
+	h[npBTSS * np] = hReach;
+	for (int i = 0; i < nx; i++) Dh[(npBTSS * np) + i * nTC] = DhBSDx[i] / cosTilde[0];
+	/* orthogonality row and its gradient, :601-641 */
+	const double denSquared = den * den;
+	h[npBTSS * np + 1] = ortho - o->backTrajMinOrtho;
+	double DxHit[OR_MAX_NX * OR_MAX_NX];
+	or_matmul(fClBS, nx, 1, DhBSDx, nx, DxHit);
+	for (int i = 0; i < nx * nx; i++) DxHit[i] = btDX[i] - DxHit[i];
+	double Dnum[OR_MAX_NX] = {0.0}, Dden1[OR_MAX_NX] = {0.0}, Dden2[OR_MAX_NX] = {0.0}, Dden[OR_MAX_NX];
+	for (int i = 0; i < nx; i++)
+		for (int k = 0; k < nx; k++) {
+			double temp1 = 0.0, temp2 = 0.0;
+			for (int l = 0; l < nx; l++) {
+				temp1 += DDhBS[k + l * nx] * DxHit[l + i * nx];
+				temp2 += DfClBS[k + l * nx] * DxHit[l + i * nx];
+			}
+			const double temp3 = DhBS[k] * temp2;
+			const double temp4 = temp1 * fClBS[k];
+			Dden1[i] += temp3;
+			Dden2[i] += temp4;
+			Dnum[i] += temp3 + temp4;
+		}
+	for (int i = 0; i < nx; i++) Dden[i] = den2 * Dden1[i] / den1 + den1 * Dden2[i] / den2;
+	for (int i = 0; i < nx; i++) {
+		DhBSDx[i] = (Dnum[i] * den - cosTilde[0] * Dden[i]) / denSquared;
+		Dh[(npBTSS * np + 1) + i * nTC] = DhBSDx[i];
+	}
+	double Lfh[32], Lgh[32 * OR_MAX_NU];
+	or_matvec(Dh, nTC, nx, f, Lfh);
+	or_matmul(Dh, nTC, nx, g, nu, Lgh);
+	/* :655-674.  Column nu of the two extra rows is never written by the reference after the
+	 * constructor / trivial fill zeroed it, so it is 0. */
+	for (int i = 0; i < nTC * (nu + 1); i++) A[i] = 0.0;
+	for (int i = 0; i < nTC; i++)
+		for (int j = 0; j < nu; j++) A[i + j * nTC] = Lgh[i + j * nTC];
+	for (int i = 0; i < npBTSS * np; i++) A[i + nu * nTC] = h[i];
+	for (int i = 0; i < nTC; i++) b[i] = -Lfh[i];
+	b[npBTSS * np] -= o->relaxTTS * h[npBTSS * np];
+	b[npBTSS * np + 1] -= o->relaxMinOrtho * (h[npBTSS * np + 1]);
+	if (diag) {
+		diag[0] = TTS;
+		diag[1] = ortho;
+		diag[2] = (double)idxHit;
+	}
+	traj_free(&T);
+	return 1;
+}
+
+/* ------------------------------------------------------------------ robust */
+/* src/asif_robust.cpp:103-133 (fixed structure) + :275-367 (interval rows), npSSmax == npSS */
+static int assemble_robust(const or_model *m, const or_options *o, const double *x, double *A, double *b)
+{
+	const int nx = m->nx, nu = m->nu, N = o->nHalfPlanes;
+	const int nv = nu + 1 + N * 2 * (nu + 1), nc = N * (nu + 2);
+	for (int i = 0; i < nc * nv; i++) A[i] = 0.0;
+	for (int i = 0; i < nc; i++) b[i] = 0.0;
+	int iCol = nu + 1;
+	for (int iRow = 0; iRow < nc; iRow += nu + 2) {
+		for (int i = 0; i < nu; i++)
+			for (int j = 0; j < nu; j++) A[(iRow + 1 + i) + j * nc] = -1.0; /* full -1 block, exact for nu==1 only (App. B 8) */
+		for (int i = 0; i < nu + 1; i++) {
+			A[(iRow + 1 + i) + (iCol + i) * nc] = 1.0;
+			A[(iRow + 1 + i) + (iCol + nu + 1 + i) * nc] = -1.0;
+		}
+		b[iRow + nu + 1] = 1.0;
+		iCol += 2 * (nu + 1);
+	}
+	or_af_ctx cx = {0, 0};
+	or_af xI[OR_MAX_NX], f[OR_MAX_NX], g[OR_MAX_NX * OR_MAX_NU];
+	for (int i = 0; i < nx; i++) or_af_interval(&cx, &xI[i], x[i], x[i]);
+	double h[OR_MAX_NPSS], Dh[OR_MAX_NPSS * OR_MAX_NX];
+	m->safety(o, x, h, Dh);
+	for (int i = 0; i < nx; i++) or_af_const(&f[i], 0);
+	for (int i = 0; i < nx * nu; i++) or_af_const(&g[i], 0);
+	m->dynamics_af(o, &cx, xI, f, g);
+	or_af DhI[OR_MAX_NPSS * OR_MAX_NX], Lfh[OR_MAX_NPSS], Lgh[OR_MAX_NPSS * OR_MAX_NU], t;
+	for (int i = 0; i < N * nx; i++) or_af_interval(&cx, &DhI[i], Dh[i], Dh[i]);
+	/* include/asif_utils.h:46-62 instantiated on AAF: Ab[i] = 0.0; Ab[i] = Ab[i] + A*b */
+	for (int i = 0; i < N; i++) {
+		or_af_const(&Lfh[i], 0.0);
+		for (int k = 0; k < nx; k++) {
+			or_af_mul(&cx, &DhI[i + k * N], &f[k], &t);
+			or_af_add(&Lfh[i], &t, &Lfh[i]);
+		}
+	}
+	for (int i = 0; i < N; i++)
+		for (int j = 0; j < nu; j++) {
+			or_af *r = &Lgh[i + j * N];
+			or_af_const(r, 0.0);
+			for (int k = 0; k < nx; k++) {
+				or_af_mul(&cx, &DhI[i + k * N], &g[k + j * nx], &t);
+				or_af_add(r, &t, r);
+			}
+		}
+	iCol = nu + 1;
+	int s = 0;
+	for (int iRow = 0; iRow < nc; iRow += nu + 2) {
+		double lo, hi;
+		A[iRow + nu * nc] = h[s];
+		for (int j = 0; j < nu; j++) {
+			or_af_convert(&Lgh[s + j * N], &lo, &hi);
+			A[iRow + (iCol + j) * nc] = lo;
+			A[iRow + (iCol + (nu + 1) + j) * nc] = -hi;
+		}
+		or_af_convert(&Lfh[s], &lo, &hi);
+		A[iRow + (iCol + nu) * nc] = lo;
+		A[iRow + (iCol + (nu + 1) + nu) * nc] = -hi;
+		iCol += 2 * (nu + 1);
+		s++;
+	}
+	return cx.overflow ? -100 : 1;
+}
+
+/* ---------------------------------------------------------------- dispatch */
+int or_assemble(int model, int variant, const or_options *o, const double *x, double *A, double *b, double *diag)
+{
+	const or_model *m = or_model_get(model);
+	or_dims d;
+	if (!m || or_get_dims(model, variant, o, &d)) return -100;
+	switch (variant) {
+	case OR_VARIANT_EXPLICIT:
+		return assemble_explicit(m, o, x, A, b);
+	case OR_VARIANT_IMPLICIT:
+		return assemble_implicit(m, o, x, A, b);
+	case OR_VARIANT_IMPLICIT_TB: {
+		/* src/asif_implicit_tb.cpp:278-290: inside the backup set -> trivial rows, filter() returns 2 */
+		double hb[1], Dhb[OR_MAX_NX], DDhb[OR_MAX_NX * OR_MAX_NX];
+		m->backup(o, x, hb, Dhb, DDhb);
+		if (hb[0] >= 0) {
+			assemble_tb_trivial(o, d.nc, d.nv, A, b, diag);
+			return 2;
+		}
+		int r = assemble_tb(m, o, x, A, b, diag);
+		return r == 1 ? 1 : -3;
+	}
+	case OR_VARIANT_ROBUST:
+		return assemble_robust(m, o, x, A, b);
+	}
+	return -100;
+}
+
+/* Cost / bounds / equality flags each variant hands to QPWrapperAbstract::initialize + updateCost:
+ *  explicit src/asif.cpp:84-98,314-325; implicit src/asif_implicit.cpp:237-254,653-664;
+ *  TB src/asif_implicit_tb.cpp:198-210; robust src/asif_robust.cpp:89-101,140-148 */
+void or_qp_static(int model, int variant, const or_options *o, const double *uDes,
+                  double *Hd, double *c, double *lb, double *ub, uint8_t *be)
+{
+	or_dims d;
+	if (or_get_dims(model, variant, o, &d)) return;
+	const int nu = d.nu;
+	for (int i = 0; i < d.nv; i++) { Hd[i] = 0; c[i] = 0; lb[i] = 0; ub[i] = 0; }
+	for (int i = 0; i < d.nc; i++) be[i] = 0;
+	for (int i = 0; i < nu; i++) {
+		Hd[i] = 1.0;
+		c[i] = -2.0 * uDes[i];
+		lb[i] = o->lb[i];
+		ub[i] = o->ub[i];
+	}
+	switch (variant) {
+	case OR_VARIANT_EXPLICIT:
+		Hd[nu] = o->relaxCost;
+		c[nu] = -2.0 * o->relaxCost * o->relaxLb;
+		lb[nu] = o->relaxLb;
+		ub[nu] = o->relaxLb; /* src/asif.cpp:91: the relax variable is pinned */
+		break;
+	case OR_VARIANT_IMPLICIT:
+		Hd[nu] = Hd[nu + 1] = o->relaxCost;
+		c[nu] = -2.0 * o->relaxCost * o->relaxLb;
+		c[nu + 1] = -2.0 * o->relaxCost * o->relaxReachLb;
+		lb[nu] = o->relaxLb;
+		lb[nu + 1] = o->relaxReachLb;
+		ub[nu] = ub[nu + 1] = o->inf;
+		break;
+	case OR_VARIANT_IMPLICIT_TB:
+		Hd[nu] = o->relaxCost;
+		c[nu] = -2.0 * o->relaxCost * o->relaxLb;
+		lb[nu] = o->relaxLb;
+		ub[nu] = o->inf;
+		break;
+	case OR_VARIANT_ROBUST:
+		Hd[nu] = o->relaxCost;
+		c[nu] = -2.0 * o->relaxCost * o->relaxLb;
+		lb[nu] = o->relaxLb;
+		ub[nu] = o->inf;
+		for (int i = nu + 1; i < d.nv; i++) { lb[i] = 0.0; ub[i] = o->inf; }
+		for (int i = 0; i < d.nc; i++) be[i] = (i % (nu + 2)) != 0;
+		break;
+	}
+}

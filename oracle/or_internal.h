@@ -1,0 +1,30 @@
+/* or_internal.h -- shared declarations inside oracle/.  TEST INFRASTRUCTURE (see or_oracle.h). */
+#ifndef OR_INTERNAL_H
+#define OR_INTERNAL_H
+
+#include "or_oracle.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* Model callbacks with the reference's std::function signatures (include/asif.h:22-27,
+ * include/asif_implicit.h:48-62, include/asif_implicit_tb.h:46-60, include/asif_robust.h:24-29);
+ * ud carries or_options for models that need data. */
+typedef struct {
+	int nx, nu, npSS, npBS;
+	void (*safety)(const void *ud, const double *x, double *h, double *Dh);
+	void (*backup)(const void *ud, const double *x, double *h, double *Dh, double *DDh);
+	void (*dynamics)(const void *ud, const double *x, double *f, double *g);
+	void (*gradients)(const void *ud, const double *x, double *Df, double *Dg);
+	void (*controller)(const void *ud, const double *x, double *u, double *Du);
+	void (*dynamics_af)(const void *ud, or_af_ctx *cx, const or_af *x, or_af *f, or_af *g);
+} or_model;
+
+const or_model *or_model_get(int id);
+
+void or_matvec(const double *A, int nl, int ncol, const double *b, double *Ab);
+void or_matmul(const double *A, int nlA, int ncA, const double *B, int ncB, double *AB);
+double or_vecnorm(const double *v, int len);
+
+#endif

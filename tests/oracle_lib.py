@@ -1,0 +1,198 @@
+"""ctypes view of oracle/liboracle.so (and oracle/_ref when it exists).
+
+TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+import this module; the product (asif_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_LIB_PATH = os.path.join(ORACLE_DIR, "_ref", "libaffa_ref.so")
+
+MODEL_DI, MODEL_IP, MODEL_SEGWAY, MODEL_IP_ROBUST = 0, 1, 2, 3
+VAR_EXPLICIT, VAR_IMPLICIT, VAR_TB, VAR_ROBUST = 0, 1, 2, 3
+SOLVER_EXACT, SOLVER_ADMM = 0, 1
+
+# config id (BASELINE.json configs[]) -> (model, variant)
+CONFIGS = {2: (MODEL_DI, VAR_EXPLICIT), 3: (MODEL_IP, VAR_IMPLICIT), 4: (MODEL_SEGWAY, VAR_TB),
+           5: (MODEL_IP_ROBUST, VAR_ROBUST)}
+
+
+class Options(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "relaxCost", "relaxLb", "relaxReachLb", "relaxTTS", "relaxMinOrtho", "backTrajHorizon",
+        "backTrajExtend", "backTrajDt", "backTrajMinOrtho", "satSharpness", "inf")] + [
+        ("lb", C.c_double * 1), ("ub", C.c_double * 1), ("pMin", C.c_double), ("pMax", C.c_double),
+        ("nHalfPlanes", C.c_int32), ("halfPlanes", C.c_double * 16)]
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("nx", "nu", "npSS", "npBS", "npBTSS", "nv", "nc", "nrelax", "npBT")]
+
+
+class AdmmSettings(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("rho", "sigma", "alpha", "eps_abs", "eps_rel", "eps_prim_inf",
+                                          "eps_dual_inf")] + [
+        (n, C.c_int) for n in ("scaling", "adaptive_rho", "adaptive_rho_interval", "check_termination",
+                               "max_iter")] + [("adaptive_rho_tolerance", C.c_double), ("reduced_kkt", C.c_int),
+                                               ("polish", C.c_int)]
+
+
+class AfInstr(C.Structure):
+    _fields_ = [("op", C.c_int), ("dst", C.c_int), ("a", C.c_int), ("b", C.c_int), ("imm0", C.c_double),
+                ("imm1", C.c_double)]
+
+
+OPS = dict(CONST=0, INTERVAL=1, ADD=2, SUB=3, MUL=4, DIV=5, INV=6, NEG=7, SCALE=8, SIN=9, COPY=10)
+
+
+def build(force=False):
+    """Compile liboracle.so (gcc) and, when /root/reference is present, oracle/_ref."""
+    if force or not os.path.exists(LIB_PATH) or any(
+            os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(LIB_PATH)
+            for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "liboracle.so"])
+    if os.path.isdir("/root/reference/lib/libaffa/src") and (force or not os.path.exists(REF_LIB_PATH)):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "ref"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.or_rng_uniform.restype = C.c_double
+        _lib.or_rng_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        for f in ("or_filter_batch", "or_assemble_batch", "or_qp_solve_batch"):
+            getattr(_lib, f).restype = C.c_int64
+    return _lib
+
+
+def ref_lib():
+    """The reference's libaffa behind oracle/ref_affa_shim.cpp, or None when not built."""
+    if not os.path.exists(REF_LIB_PATH):
+        return None
+    return C.CDLL(REF_LIB_PATH)
+
+
+def _p(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def default_options(model, variant):
+    o = Options()
+    lib().or_default_options(model, variant, C.byref(o))
+    return o
+
+
+def dims(model, variant, o):
+    d = Dims()
+    r = lib().or_get_dims(model, variant, C.byref(o), C.byref(d))
+    assert r == 0
+    return d
+
+
+def admm_settings(**kw):
+    s = AdmmSettings()
+    lib().or_admm_default_settings(C.byref(s))
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+def make_batch(cfg, B, first=0):
+    model, variant = CONFIGS[cfg]
+    d = dims(model, variant, default_options(model, variant))
+    x = np.zeros((B, d.nx))
+    u = np.zeros((B, d.nu))
+    lib().or_make_batch(cfg, C.c_int64(B), C.c_int64(first), _p(x), _p(u))
+    return x, u
+
+
+def filter_batch(model, variant, o, x, udes, solver=SOLVER_EXACT, settings=None, nthreads=1, uact_init=None):
+    d = dims(model, variant, o)
+    B = x.shape[0]
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    udes = np.ascontiguousarray(udes, dtype=np.float64).reshape(B, d.nu)
+    uact = np.full((B, d.nu), np.nan) if uact_init is None else np.array(uact_init, dtype=np.float64).reshape(B, d.nu)
+    relax = np.full((B, d.nrelax), np.nan)
+    rc = np.zeros(B, dtype=np.int32)
+    sp = C.byref(settings) if settings is not None else None
+    n = lib().or_filter_batch(model, variant, C.byref(o), solver, sp, C.c_int64(B), _p(x), _p(udes), _p(uact),
+                              _p(relax), _p(rc, C.c_int32), nthreads)
+    assert n == B
+    return uact, relax, rc
+
+
+def assemble_batch(model, variant, o, x):
+    d = dims(model, variant, o)
+    B = x.shape[0]
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    A = np.zeros((B, d.nc * d.nv))
+    b = np.zeros((B, d.nc))
+    code = np.zeros(B, dtype=np.int32)
+    diag = np.zeros((B, 8))
+    n = lib().or_assemble_batch(model, variant, C.byref(o), C.c_int64(B), _p(x), _p(A), _p(b), _p(code, C.c_int32),
+                                _p(diag))
+    assert n == B
+    return A, b, code, diag
+
+
+def qp_static(model, variant, o, udes):
+    d = dims(model, variant, o)
+    Hd, c, lb, ub = (np.zeros(d.nv) for _ in range(4))
+    be = np.zeros(d.nc, dtype=np.uint8)
+    ud = np.ascontiguousarray(np.atleast_1d(udes), dtype=np.float64)
+    lib().or_qp_static(model, variant, C.byref(o), _p(ud), _p(Hd), _p(c), _p(lb), _p(ub), _p(be, C.c_uint8))
+    return Hd, c, lb, ub, be
+
+
+def qp_solve_batch(nv, nc, Hd, c, A, b, lb, ub, be=None, solver=SOLVER_ADMM, settings=None):
+    """AoS inputs: Hd,c,lb,ub [B,nv]; A [B,nc*nv] col-major per instance; b [B,nc]."""
+    B = c.shape[0]
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (Hd, c, A, b, lb, ub)]
+    sol = np.full((B, nv), np.nan)
+    status = np.zeros(B, dtype=np.int32)
+    iters = np.zeros(B, dtype=np.int32)
+    bep = _p(np.ascontiguousarray(be, dtype=np.uint8), C.c_uint8) if be is not None else None
+    sp = C.byref(settings) if settings is not None else None
+    n = lib().or_qp_solve_batch(nv, nc, solver, sp, C.c_int64(B), *[_p(a) for a in arrs], bep, _p(sol),
+                                _p(status, C.c_int32), _p(iters, C.c_int32))
+    assert n == B
+    return sol, status, iters
+
+
+def last_crit_idx(cap=16):
+    idx = np.zeros(cap, dtype=np.int32)
+    n = lib().or_last_crit_idx(_p(idx, C.c_int32), cap)
+    return idx[:n].copy()
+
+
+def _run_program(fn, prog, nreg, cap=48):
+    arr = (AfInstr * len(prog))(*[AfInstr(*p) for p in prog])
+    center = np.zeros(nreg)
+    n = np.zeros(nreg, dtype=np.int32)
+    lo = np.zeros(nreg)
+    hi = np.zeros(nreg)
+    idx = np.zeros(nreg * cap, dtype=np.uint32)
+    coef = np.zeros(nreg * cap)
+    r = fn(arr, len(prog), nreg, cap, _p(center), _p(n, C.c_int32), _p(lo), _p(hi), _p(idx, C.c_uint32), _p(coef))
+    return r, dict(center=center, n=n, lo=lo, hi=hi, idx=idx.reshape(nreg, cap), coef=coef.reshape(nreg, cap))
+
+
+def af_run_oracle(prog, nreg, cap=48):
+    return _run_program(lib().or_af_run, prog, nreg, cap)
+
+
+def af_run_reference(prog, nreg, cap=48):
+    rl = ref_lib()
+    assert rl is not None
+    return _run_program(rl.ref_affa_run, prog, nreg, cap)
