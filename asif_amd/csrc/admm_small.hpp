@@ -1,0 +1,597 @@
+// admm_small.hpp -- in-register ADMM for the tiny dense QPs of the safety filter (nv <= 4).
+//
+// Replaces the reference's OSQP call chain (src/qpwrapper_osqp.cpp:55-261 -> osqp_setup/osqp_solve)
+// for one QP per lane group.  Nothing is ported from OSQP: the splitting is the published ADMM of
+// Stellato et al. (OSQP, Math. Prog. Comp. 2020) laid out for CDNA4:
+//   * G lanes cooperate on one QP (G = 1, 2, 4, ... 64, compile time).  The NC general rows are dealt
+//     round-robin to the G lanes (RPL rows per lane, in VGPRs); the nv variables, the nv bound rows and
+//     the nv x nv reduced KKT factor are replicated in every lane of the group, so the only cross-lane
+//     traffic per iteration is one nv-vector sum (A'(rho z - y)).
+//   * The quasi-definite (nv+m) KKT system of the paper is eliminated to its nv x nv Schur complement
+//     P + sigma I + A' diag(rho) A, factored LDL' in registers (nv <= 4: a handful of FMAs).  The
+//     row-outer-product sum is formed once; a rho change refactors without any cross-lane traffic.
+//   * Ruiz equilibration uses power-of-two factors (exponent arithmetic, exact to apply and undo).
+//   * Every `check_interval` iterations: a KKT-validated active-set polish, the unscaled residual
+//     test (OSQP's criteria), primal/dual infeasibility certificates, and rho adaptation.
+// Form translation follows the wrapper the reference puts in front of OSQP (src/qpwrapper_osqp.cpp:263-376):
+//   P = 2H, q = c, rows [A; I], l = [b; lb], u = [+inf | b where be; ub].
+// General rows are one-sided (A x >= b) or equalities; `b` is data and always finite (the reference's
+// own "infinity" is 1e20, include/asif.h:16, far below OSQP's 1e30), so they are never "loose" rows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "asif_hip.h"
+
+namespace asif {
+
+constexpr double kInfty = 1e30;
+constexpr double kMinScaling = 1e-4;
+constexpr double kMaxScaling = 1e4;
+constexpr double kRhoMin = 1e-6;
+constexpr double kRhoMax = 1e6;
+constexpr double kRhoEqOverIneq = 1e3;
+constexpr double kRhoTol = 1e-4;
+constexpr double kPolishDelta = 1e-6;
+constexpr double kPolishKktTol = 1e-9;
+constexpr double kPolishStatTol = 1e-7;
+
+constexpr int kStatusSolved = 1;
+constexpr int kStatusSolvedInaccurate = 2;
+constexpr int kStatusPrimalInfInaccurate = 3;
+constexpr int kStatusDualInfInaccurate = 4;
+constexpr int kStatusMaxIter = -2;
+constexpr int kStatusPrimalInf = -3;
+constexpr int kStatusDualInf = -4;
+
+template <int G>
+__device__ __forceinline__ double gsum(double v)
+{
+#pragma unroll
+	for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
+	return v;
+}
+template <int G>
+__device__ __forceinline__ double gmax(double v)
+{
+#pragma unroll
+	for (int m = 1; m < G; m <<= 1) v = fmax(v, __shfl_xor(v, m, 64));
+	return v;
+}
+template <int G>
+__device__ __forceinline__ int gand(int p)
+{
+#pragma unroll
+	for (int m = 1; m < G; m <<= 1) p &= __shfl_xor(p, m, 64);
+	return p;
+}
+
+__device__ __forceinline__ double limit_scaling(double v)
+{
+	v = v < kMinScaling ? 1.0 : v;
+	v = v > kMaxScaling ? kMaxScaling : v;
+	return v;
+}
+// power-of-two stand-in for 1/sqrt(v): v = f*2^e, f in [0.5,1) -> 2^-(e>>1)
+__device__ __forceinline__ double pow2_rsqrt(double v)
+{
+	int e;
+	(void)frexp(v, &e);
+	return ldexp(1.0, -(e >> 1));
+}
+__device__ __forceinline__ double pow2_floor(double v)
+{
+	int e;
+	(void)frexp(v, &e);
+	return ldexp(1.0, e - 1);
+}
+// exact reciprocal of a power of two
+__device__ __forceinline__ double pow2_inv(double p)
+{
+	int e;
+	(void)frexp(p, &e);
+	return ldexp(1.0, 1 - e);
+}
+
+// One QP as the filter classes hand it to QPWrapperAbstract (include/qpwrapper_abstract.h:30-43),
+// this lane's share of the rows only.
+template <int NV, int RPL>
+struct QpLaneData {
+	double Hd[NV], c[NV], lb[NV], ub[NV];
+	double A[RPL][NV], b[RPL];
+	bool eq[RPL];
+};
+
+// LDL' of a symmetric NV x NV matrix given by its lower triangle M[a][b], a >= b, in place:
+// on return M holds L (strictly lower) and Dinv = 1/d.  False if a pivot is not positive.
+template <int NV>
+__device__ __forceinline__ bool ldl_factor(double (&M)[NV][NV], double (&Dinv)[NV])
+{
+	bool ok = true;
+	double d[NV];
+#pragma unroll
+	for (int j = 0; j < NV; j++) {
+		double dj = M[j][j];
+#pragma unroll
+		for (int k = 0; k < j; k++) dj -= M[j][k] * M[j][k] * d[k];
+		ok = ok && (dj > 0.0);
+		d[j] = dj;
+		const double di = 1.0 / dj;
+		Dinv[j] = di;
+#pragma unroll
+		for (int i = j + 1; i < NV; i++) {
+			double s = M[i][j];
+#pragma unroll
+			for (int k = 0; k < j; k++) s -= M[i][k] * M[j][k] * d[k];
+			M[i][j] = s * di;
+		}
+	}
+	return ok;
+}
+template <int NV>
+__device__ __forceinline__ void ldl_solve(const double (&L)[NV][NV], const double (&Dinv)[NV], double (&v)[NV])
+{
+#pragma unroll
+	for (int i = 1; i < NV; i++)
+#pragma unroll
+		for (int k = 0; k < i; k++) v[i] -= L[i][k] * v[k];
+#pragma unroll
+	for (int i = 0; i < NV; i++) v[i] *= Dinv[i];
+#pragma unroll
+	for (int i = NV - 2; i >= 0; i--)
+#pragma unroll
+		for (int k = i + 1; k < NV; k++) v[i] -= L[k][i] * v[k];
+}
+
+template <int NV, int RPL, int G>
+struct AdmmSmall {
+	// scaled problem
+	double P[NV], q[NV], D[NV], cs;
+	double A[RPL][NV], l[RPL], E[RPL];
+	bool eqr[RPL];
+	double Ab[NV], lbs[NV], ubs[NV], Eb[NV]; // bound rows: Ab = scaled identity entry
+	int clsb[NV];                            // bound-row class: -1 loose, 0 inequality, 1 equality
+	double S[NV][NV];                        // sum_r w_r a_r a_r' over the general rows (w = 1 | 1e3)
+	// iterates
+	double x[NV], z[RPL], y[RPL], zb[NV], yb[NV];
+	double dy[RPL], dyb[NV], dx[NV];
+	// rho + factor
+	double rho, rinv, rinv_eq, rb[NV], rbinv[NV];
+	double L[NV][NV], Dinv[NV];
+
+	__device__ __forceinline__ void load_and_scale(const QpLaneData<NV, RPL> &in, int iters)
+	{
+#pragma unroll
+		for (int j = 0; j < NV; j++) {
+			P[j] = 2.0 * in.Hd[j];
+			q[j] = in.c[j];
+			D[j] = 1.0;
+			Ab[j] = 1.0;
+			Eb[j] = 1.0;
+		}
+#pragma unroll
+		for (int r = 0; r < RPL; r++) {
+			E[r] = 1.0;
+#pragma unroll
+			for (int j = 0; j < NV; j++) A[r][j] = in.A[r][j];
+		}
+		cs = 1.0;
+#pragma unroll 1
+		for (int it = 0; it < iters; it++) {
+			double Dt[NV];
+#pragma unroll
+			for (int j = 0; j < NV; j++) {
+				double v = 0.0;
+#pragma unroll
+				for (int r = 0; r < RPL; r++) v = fmax(v, fabs(A[r][j]));
+				v = gmax<G>(v);
+				v = fmax(v, fmax(fabs(P[j]), fabs(Ab[j])));
+				Dt[j] = pow2_rsqrt(limit_scaling(v));
+			}
+#pragma unroll
+			for (int r = 0; r < RPL; r++) {
+				double v = 0.0;
+#pragma unroll
+				for (int j = 0; j < NV; j++) v = fmax(v, fabs(A[r][j]));
+				const double Et = pow2_rsqrt(limit_scaling(v));
+				E[r] *= Et;
+#pragma unroll
+				for (int j = 0; j < NV; j++) A[r][j] *= Et * Dt[j];
+			}
+			double cm = 0.0, qn = 0.0;
+#pragma unroll
+			for (int j = 0; j < NV; j++) {
+				const double Etb = pow2_rsqrt(limit_scaling(fabs(Ab[j])));
+				Eb[j] *= Etb;
+				Ab[j] *= Etb * Dt[j];
+				P[j] *= Dt[j] * Dt[j];
+				q[j] *= Dt[j];
+				D[j] *= Dt[j];
+				cm += fabs(P[j]);
+				qn = fmax(qn, fabs(q[j]));
+			}
+			cm *= (1.0 / NV);
+			qn = limit_scaling(qn);
+			const double ct = pow2_floor(1.0 / limit_scaling(fmax(cm, qn)));
+#pragma unroll
+			for (int j = 0; j < NV; j++) {
+				P[j] *= ct;
+				q[j] *= ct;
+			}
+			cs *= ct;
+		}
+#pragma unroll
+		for (int r = 0; r < RPL; r++) {
+			l[r] = in.b[r] * E[r];
+			eqr[r] = in.eq[r];
+		}
+#pragma unroll
+		for (int j = 0; j < NV; j++) {
+			lbs[j] = in.lb[j] * Eb[j];
+			ubs[j] = in.ub[j] * Eb[j];
+			if (lbs[j] < -kInfty * kMinScaling && ubs[j] > kInfty * kMinScaling) clsb[j] = -1;
+			else if (ubs[j] - lbs[j] < kRhoTol) clsb[j] = 1;
+			else clsb[j] = 0;
+		}
+		// the rho-independent part of the reduced KKT matrix
+#pragma unroll
+		for (int a = 0; a < NV; a++)
+#pragma unroll
+			for (int b = 0; b <= a; b++) {
+				double s = 0.0;
+#pragma unroll
+				for (int r = 0; r < RPL; r++) s += (eqr[r] ? kRhoEqOverIneq : 1.0) * A[r][a] * A[r][b];
+				S[a][b] = gsum<G>(s);
+			}
+	}
+
+	// per-row rho (OSQP's rho_vec) and the LDL' of  P + sigma I + A' diag(rho) A ; lane-local.
+	__device__ __forceinline__ bool set_rho_and_factor(double rho0, double sigma)
+	{
+		rho = rho0;
+		rinv = 1.0 / rho0;
+		rinv_eq = rinv * (1.0 / kRhoEqOverIneq);
+#pragma unroll
+		for (int j = 0; j < NV; j++) {
+			rb[j] = clsb[j] < 0 ? kRhoMin : (clsb[j] > 0 ? kRhoEqOverIneq * rho0 : rho0);
+			rbinv[j] = clsb[j] < 0 ? 1.0 / kRhoMin : (clsb[j] > 0 ? rinv_eq : rinv);
+		}
+#pragma unroll
+		for (int a = 0; a < NV; a++)
+#pragma unroll
+			for (int b = 0; b <= a; b++) {
+				double s = rho0 * S[a][b];
+				if (a == b) s += P[a] + sigma + rb[a] * Ab[a] * Ab[a];
+				L[a][b] = s;
+			}
+		return ldl_factor<NV>(L, Dinv);
+	}
+
+	// one ADMM iteration (x~/z~ solve, relaxation, projection, dual update)
+	__device__ __forceinline__ void iterate(double sigma, double alpha)
+	{
+		double rhs[NV];
+		const double rho_eq = kRhoEqOverIneq * rho;
+#pragma unroll
+		for (int j = 0; j < NV; j++) rhs[j] = 0.0;
+#pragma unroll
+		for (int r = 0; r < RPL; r++) {
+			const double t = (eqr[r] ? rho_eq : rho) * z[r] - y[r];
+#pragma unroll
+			for (int j = 0; j < NV; j++) rhs[j] += A[r][j] * t;
+		}
+#pragma unroll
+		for (int j = 0; j < NV; j++) {
+			rhs[j] = gsum<G>(rhs[j]);
+			rhs[j] += sigma * x[j] - q[j] + Ab[j] * (rb[j] * zb[j] - yb[j]);
+		}
+		ldl_solve<NV>(L, Dinv, rhs); // rhs = x~
+		const double oma = 1.0 - alpha;
+#pragma unroll
+		for (int r = 0; r < RPL; r++) {
+			double zt = 0.0;
+#pragma unroll
+			for (int j = 0; j < NV; j++) zt += A[r][j] * rhs[j];
+			const double zr = alpha * zt + oma * z[r];
+			const double zn = eqr[r] ? l[r] : fmax(zr + y[r] * rinv, l[r]);
+			dy[r] = (eqr[r] ? rho_eq : rho) * (zr - zn);
+			y[r] += dy[r];
+			z[r] = zn;
+		}
+#pragma unroll
+		for (int j = 0; j < NV; j++) {
+			const double zt = Ab[j] * rhs[j];
+			const double zr = alpha * zt + oma * zb[j];
+			const double zn = fmin(fmax(zr + yb[j] * rbinv[j], lbs[j]), ubs[j]);
+			dyb[j] = rb[j] * (zr - zn);
+			yb[j] += dyb[j];
+			zb[j] = zn;
+			const double xn = alpha * rhs[j] + oma * x[j];
+			dx[j] = xn - x[j];
+			x[j] = xn;
+		}
+	}
+
+	// KKT-validated active-set polish; on success xp holds the polished (scaled) x.
+	// act: 0 inactive, -1 at lower, +1 at upper, 2 equality (always active, multiplier free).
+	__device__ __forceinline__ bool polish(double (&xp)[NV])
+	{
+		const double idelta = 1.0 / kPolishDelta;
+		int act[RPL], actb[NV];
+		double nu[RPL], nub[NV], rtb[NV];
+#pragma unroll
+		for (int r = 0; r < RPL; r++) {
+			act[r] = eqr[r] ? 2 : ((z[r] - l[r] < -y[r]) ? -1 : 0);
+			nu[r] = 0.0;
+		}
+#pragma unroll
+		for (int j = 0; j < NV; j++) {
+			actb[j] = 0;
+			rtb[j] = 0.0;
+			if (clsb[j] > 0) { actb[j] = 2; rtb[j] = lbs[j]; }
+			else if (zb[j] - lbs[j] < -yb[j]) { actb[j] = -1; rtb[j] = lbs[j]; }
+			else if (ubs[j] - zb[j] < yb[j]) { actb[j] = 1; rtb[j] = ubs[j]; }
+			nub[j] = 0.0;
+		}
+		double Mp[NV][NV], Mi[NV];
+#pragma unroll
+		for (int a = 0; a < NV; a++)
+#pragma unroll
+			for (int b = 0; b <= a; b++) {
+				double s = 0.0;
+#pragma unroll
+				for (int r = 0; r < RPL; r++) s += act[r] ? A[r][a] * A[r][b] : 0.0;
+				s = gsum<G>(s) * idelta;
+				if (a == b) s += P[a] + kPolishDelta + (actb[a] ? Ab[a] * Ab[a] * idelta : 0.0);
+				Mp[a][b] = s;
+			}
+		bool ok = ldl_factor<NV>(Mp, Mi);
+#pragma unroll
+		for (int j = 0; j < NV; j++) xp[j] = 0.0;
+#pragma unroll 1
+		for (int it = 0; it < 4; it++) {
+			double rhs[NV], e2[RPL], e2b[NV];
+#pragma unroll
+			for (int j = 0; j < NV; j++) rhs[j] = 0.0;
+#pragma unroll
+			for (int r = 0; r < RPL; r++) {
+				double ax = 0.0;
+#pragma unroll
+				for (int j = 0; j < NV; j++) ax += A[r][j] * xp[j];
+				e2[r] = l[r] - ax;
+				const double w = act[r] ? (e2[r] * idelta - nu[r]) : 0.0;
+#pragma unroll
+				for (int j = 0; j < NV; j++) rhs[j] += A[r][j] * w;
+			}
+#pragma unroll
+			for (int j = 0; j < NV; j++) {
+				rhs[j] = gsum<G>(rhs[j]);
+				e2b[j] = rtb[j] - Ab[j] * xp[j];
+				rhs[j] += -q[j] - P[j] * xp[j] + (actb[j] ? Ab[j] * (e2b[j] * idelta - nub[j]) : 0.0);
+			}
+			ldl_solve<NV>(Mp, Mi, rhs); // rhs = dx
+#pragma unroll
+			for (int r = 0; r < RPL; r++) {
+				double adx = 0.0;
+#pragma unroll
+				for (int j = 0; j < NV; j++) adx += A[r][j] * rhs[j];
+				nu[r] += act[r] ? (adx - e2[r]) * idelta : 0.0;
+			}
+#pragma unroll
+			for (int j = 0; j < NV; j++) {
+				nub[j] += actb[j] ? (Ab[j] * rhs[j] - e2b[j]) * idelta : 0.0;
+				xp[j] += rhs[j];
+			}
+		}
+		// validate against the KKT conditions of the FULL problem
+		double g[NV];
+#pragma unroll
+		for (int j = 0; j < NV; j++) g[j] = 0.0;
+#pragma unroll
+		for (int r = 0; r < RPL; r++) {
+			double ax = 0.0;
+#pragma unroll
+			for (int j = 0; j < NV; j++) ax += A[r][j] * xp[j];
+			const double tol = kPolishKktTol * (1.0 + fabs(ax));
+			ok = ok && !(ax < l[r] - tol) && !(eqr[r] && ax > l[r] + tol);
+			const double nt = kPolishKktTol * (1.0 + fabs(nu[r]));
+			ok = ok && !(act[r] == -1 && nu[r] > nt);
+#pragma unroll
+			for (int j = 0; j < NV; j++) g[j] += act[r] ? A[r][j] * nu[r] : 0.0;
+		}
+		double sres = 0.0;
+#pragma unroll
+		for (int j = 0; j < NV; j++) {
+			const double ax = Ab[j] * xp[j];
+			const double tol = kPolishKktTol * (1.0 + fabs(ax));
+			ok = ok && !(ax < lbs[j] - tol || ax > ubs[j] + tol);
+			const double nt = kPolishKktTol * (1.0 + fabs(nub[j]));
+			ok = ok && !(actb[j] == -1 && nub[j] > nt) && !(actb[j] == 1 && nub[j] < -nt);
+			const double gj = gsum<G>(g[j]) + P[j] * xp[j] + q[j] + (actb[j] ? Ab[j] * nub[j] : 0.0);
+			sres = fmax(sres, fabs(gj));
+		}
+		ok = ok && (sres <= kPolishStatTol);
+		return gand<G>(ok ? 1 : 0) != 0;
+	}
+
+	// Cold-start solve.  `status` follows QPWrapperOsqp::solve() (src/qpwrapper_osqp.cpp:225-238):
+	// 1 when solved, the raw OSQP-style code otherwise.  xout is unscaled.  Must be called by every
+	// lane of the wave (group reductions and the wave-uniform exit test).
+	__device__ __forceinline__ void solve(const QpLaneData<NV, RPL> &in, const asif_hip_solver &S_, double (&xout)[NV],
+	                                      int &status, int &iters)
+	{
+		load_and_scale(in, S_.scaling_iters);
+#pragma unroll
+		for (int j = 0; j < NV; j++) { x[j] = 0.0; zb[j] = 0.0; yb[j] = 0.0; dyb[j] = 0.0; dx[j] = 0.0; xout[j] = 0.0; }
+#pragma unroll
+		for (int r = 0; r < RPL; r++) { z[r] = 0.0; y[r] = 0.0; dy[r] = 0.0; }
+		status = 0;
+		iters = 0;
+		bool fact_ok = set_rho_and_factor(S_.rho, S_.sigma);
+		const double cinv = pow2_inv(cs);
+		int it = 0;
+		const int K = S_.check_interval > 0 ? S_.check_interval : 10;
+		while (it < S_.max_iter) {
+			if (__all(status != 0)) break; // wave-uniform: every lane has latched its result
+#pragma unroll 1
+			for (int k = 0; k < K; k++) iterate(S_.sigma, S_.alpha);
+			it += K;
+			const bool last = it >= S_.max_iter;
+
+			// ---- residual norms, unscaled (termination) and scaled (rho estimate)
+			double aty[NV], pri = 0.0, nz = 0.0, nax = 0.0, pri_s = 0.0, nz_s = 0.0, nax_s = 0.0;
+#pragma unroll
+			for (int j = 0; j < NV; j++) aty[j] = 0.0;
+#pragma unroll
+			for (int r = 0; r < RPL; r++) {
+				double ax = 0.0;
+#pragma unroll
+				for (int j = 0; j < NV; j++) {
+					ax += A[r][j] * x[j];
+					aty[j] += A[r][j] * y[r];
+				}
+				const double ei = pow2_inv(E[r]);
+				pri = fmax(pri, fabs(ei * (ax - z[r])));
+				nz = fmax(nz, fabs(ei * z[r]));
+				nax = fmax(nax, fabs(ei * ax));
+				pri_s = fmax(pri_s, fabs(ax - z[r]));
+				nz_s = fmax(nz_s, fabs(z[r]));
+				nax_s = fmax(nax_s, fabs(ax));
+			}
+			double dua = 0.0, nq = 0.0, naty = 0.0, npx = 0.0, dua_s = 0.0, nq_s = 0.0, naty_s = 0.0, npx_s = 0.0;
+#pragma unroll
+			for (int j = 0; j < NV; j++) {
+				const double ax = Ab[j] * x[j];
+				const double ei = pow2_inv(Eb[j]);
+				pri = fmax(pri, fabs(ei * (ax - zb[j])));
+				nz = fmax(nz, fabs(ei * zb[j]));
+				nax = fmax(nax, fabs(ei * ax));
+				pri_s = fmax(pri_s, fabs(ax - zb[j]));
+				nz_s = fmax(nz_s, fabs(zb[j]));
+				nax_s = fmax(nax_s, fabs(ax));
+				const double at = gsum<G>(aty[j]) + Ab[j] * yb[j];
+				const double px = P[j] * x[j];
+				const double di = pow2_inv(D[j]);
+				const double rd = px + q[j] + at;
+				dua = fmax(dua, fabs(di * rd));
+				nq = fmax(nq, fabs(di * q[j]));
+				naty = fmax(naty, fabs(di * at));
+				npx = fmax(npx, fabs(di * px));
+				dua_s = fmax(dua_s, fabs(rd));
+				nq_s = fmax(nq_s, fabs(q[j]));
+				naty_s = fmax(naty_s, fabs(at));
+				npx_s = fmax(npx_s, fabs(px));
+			}
+			pri = gmax<G>(pri); nz = gmax<G>(nz); nax = gmax<G>(nax);
+			pri_s = gmax<G>(pri_s); nz_s = gmax<G>(nz_s); nax_s = gmax<G>(nax_s);
+			dua *= cinv;
+
+			int st = 0;
+			double xs[NV]; // candidate solution, scaled
+#pragma unroll
+			for (int j = 0; j < NV; j++) xs[j] = x[j];
+			if (S_.polish) {
+				double xp[NV];
+				if (polish(xp)) {
+					st = kStatusSolved;
+#pragma unroll
+					for (int j = 0; j < NV; j++) xs[j] = xp[j];
+				}
+			}
+			// ---- primal-infeasibility certificate from the last delta_y (projected on the polar cone)
+			double ndy = 0.0, lhs = 0.0, atdy[NV];
+#pragma unroll
+			for (int j = 0; j < NV; j++) atdy[j] = 0.0;
+#pragma unroll
+			for (int r = 0; r < RPL; r++) {
+				const double v = eqr[r] ? dy[r] : fmin(dy[r], 0.0);
+				ndy = fmax(ndy, fabs(E[r] * v));
+				lhs += l[r] * v;
+#pragma unroll
+				for (int j = 0; j < NV; j++) atdy[j] += A[r][j] * v;
+			}
+			ndy = gmax<G>(ndy);
+			lhs = gsum<G>(lhs);
+			double natdy = 0.0;
+			{
+				double vb[NV];
+#pragma unroll
+				for (int j = 0; j < NV; j++) {
+					double v = dyb[j];
+					if (ubs[j] > kInfty * kMinScaling) v = (lbs[j] < -kInfty * kMinScaling) ? 0.0 : fmin(v, 0.0);
+					else if (lbs[j] < -kInfty * kMinScaling) v = fmax(v, 0.0);
+					vb[j] = v;
+					ndy = fmax(ndy, fabs(Eb[j] * v));
+					lhs += ubs[j] * fmax(v, 0.0) + lbs[j] * fmin(v, 0.0);
+				}
+#pragma unroll
+				for (int j = 0; j < NV; j++) {
+					const double t = (gsum<G>(atdy[j]) + Ab[j] * vb[j]) * pow2_inv(D[j]);
+					natdy = fmax(natdy, fabs(t));
+				}
+			}
+			// ---- dual-infeasibility certificate pieces (delta_x)
+			double ndx = 0.0, qdx = 0.0, npdx = 0.0;
+#pragma unroll
+			for (int j = 0; j < NV; j++) {
+				ndx = fmax(ndx, fabs(D[j] * dx[j]));
+				qdx += q[j] * dx[j];
+				npdx = fmax(npdx, fabs(P[j] * dx[j] * pow2_inv(D[j])));
+			}
+#pragma unroll 1
+			for (int approx = 0; approx <= (last ? 1 : 0); approx++) {
+				if (st) break;
+				const double k = approx ? 10.0 : 1.0;
+				const double ea = k * S_.eps_abs, er = k * S_.eps_rel;
+				const double epi = k * S_.eps_prim_inf, edi = k * S_.eps_dual_inf;
+				const double eps_pri = ea + er * fmax(nz, nax);
+				const double eps_dua = ea + er * cinv * fmax(nq, fmax(naty, npx));
+				const bool prim_ok = pri < eps_pri, dual_ok = dua < eps_dua;
+				if (prim_ok && dual_ok) st = approx ? kStatusSolvedInaccurate : kStatusSolved;
+				else if (!prim_ok && ndy > epi && lhs < -epi * ndy && natdy < epi * ndy)
+					st = approx ? kStatusPrimalInfInaccurate : kStatusPrimalInf;
+				else if (!dual_ok && ndx > edi && qdx < -cs * edi * ndx && npdx < cs * edi * ndx) {
+					bool cone = true;
+#pragma unroll
+					for (int r = 0; r < RPL; r++) {
+						double a = 0.0;
+#pragma unroll
+						for (int j = 0; j < NV; j++) a += A[r][j] * dx[j];
+						a *= pow2_inv(E[r]);
+						cone = cone && !((eqr[r] && a > edi * ndx) || a < -edi * ndx);
+					}
+#pragma unroll
+					for (int j = 0; j < NV; j++) {
+						const double a = Ab[j] * dx[j] * pow2_inv(Eb[j]);
+						cone = cone && !((ubs[j] < kInfty * kMinScaling && a > edi * ndx) ||
+						                 (lbs[j] > -kInfty * kMinScaling && a < -edi * ndx));
+					}
+					if (gand<G>(cone ? 1 : 0)) st = approx ? kStatusDualInfInaccurate : kStatusDualInf;
+				}
+			}
+			if (!st && (last || !fact_ok)) st = kStatusMaxIter;
+			if (status == 0 && st != 0) { // latch the first verdict
+				status = st;
+				iters = it;
+#pragma unroll
+				for (int j = 0; j < NV; j++) xout[j] = D[j] * xs[j];
+			}
+			// ---- rho adaptation (OSQP's estimate on the scaled residuals); lane-local refactor
+			if (S_.adaptive_rho && !last) {
+				const double pr = pri_s / (fmax(nz_s, nax_s) + 1e-10);
+				const double dr = dua_s / (fmax(nq_s, fmax(naty_s, npx_s)) + 1e-10);
+				double rn = rho * sqrt(pr / (dr + 1e-10));
+				rn = fmin(fmax(rn, kRhoMin), kRhoMax);
+				if (rn > rho * S_.adaptive_rho_tolerance || rn < rho / S_.adaptive_rho_tolerance)
+					fact_ok = set_rho_and_factor(rn, S_.sigma) && fact_ok;
+			}
+		}
+		if (status == 0) { // max_iter == 0
+			status = kStatusMaxIter;
+			iters = it;
+#pragma unroll
+			for (int j = 0; j < NV; j++) xout[j] = D[j] * x[j];
+		}
+		if (status == kStatusSolvedInaccurate) status = kStatusSolved; // src/qpwrapper_osqp.cpp:225
+	}
+};
+
+} // namespace asif

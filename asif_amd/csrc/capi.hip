@@ -1,0 +1,330 @@
+// capi.hip -- the extern "C" surface declared in include/asif_hip.h.
+// Host-side logic only: option defaults, dimension bookkeeping (the constructors and initialize()
+// of the reference classes), kernel dispatch.  There is no CPU compute path behind any entry point.
+#include "asif_hip.h"
+#include "launchers.hpp"
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+using namespace asif;
+
+struct asif_hip_ctx {
+	int model, variant, device;
+	asif_hip_options opts;
+	asif_hip_solver solver;
+	asif_hip_dims dims;
+	DevOptions dev;
+	// staging for the host-buffer convenience entry
+	double *d_in, *d_out;
+	int32_t *d_rc;
+	int64_t cap;
+};
+
+extern "C" int asif_hip_version(void) { return ASIF_HIP_VERSION; }
+
+extern "C" const char *asif_hip_error_string(int code)
+{
+	switch (code) {
+	case ASIF_HIP_OK: return "ok";
+	case ASIF_HIP_EINVAL: return "invalid argument or unsupported model/variant pair";
+	case ASIF_HIP_ENODEVICE: return "no usable HIP device (gfx950 required)";
+	case ASIF_HIP_EUNSUPPORTED: return "no compiled kernel for this QP shape";
+	default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+	}
+}
+
+extern "C" int asif_hip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+// What each example's main() passes to initialize():
+//   C2 examples/DoubleIntegrator.cpp:15-16,69-70 (struct defaults of include/asif.h:13-16)
+//   C3 examples/InvertedPendulum_Implicit.cpp:19-20,93-97
+//   C4 examples/segway_implicit_tb.cpp:18-19,223-230
+//   C5 examples/InvertedPendulum_Robust.cpp:23-24,35-38,120-121 + box half-planes
+extern "C" int asif_hip_default_options(int model, int variant, asif_hip_options *o)
+{
+	if (!o) return ASIF_HIP_EINVAL;
+	std::memset(o, 0, sizeof(*o));
+	o->relaxCost = 50.0;
+	o->relaxLb = 5.0;
+	o->relaxReachLb = 5.0;
+	o->relaxTTS = 5.0;
+	o->relaxMinOrtho = 5.0;
+	o->backTrajHorizon = 1.0;
+	o->backTrajExtend = 0.05;
+	o->backTrajDt = 0.01;
+	o->backTrajMinOrtho = 0.01;
+	o->satSharpness = (variant == ASIF_HIP_EXPLICIT) ? 5.0 : 0.1;
+	o->inf = 1e20;
+	o->pMin = o->pMax = 1.0;
+	switch (model) {
+	case ASIF_HIP_MODEL_DOUBLE_INTEGRATOR:
+		o->lb[0] = -1.0;
+		o->ub[0] = 1.0;
+		break;
+	case ASIF_HIP_MODEL_INVERTED_PENDULUM:
+		o->lb[0] = -1.5;
+		o->ub[0] = 1.5;
+		o->backTrajHorizon = 5.0;
+		o->backTrajDt = 0.001;
+		o->relaxReachLb = 5.0;
+		o->relaxLb = 10.0;
+		break;
+	case ASIF_HIP_MODEL_SEGWAY:
+		o->lb[0] = -20.0;
+		o->ub[0] = 20.0;
+		o->backTrajHorizon = 3.0;
+		o->backTrajDt = 0.01;
+		o->relaxCost = 10;
+		o->relaxLb = 2.0;
+		o->relaxTTS = 30.0;
+		o->relaxMinOrtho = 60.0;
+		o->backTrajMinOrtho = 0.001;
+		break;
+	case ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST: {
+		o->lb[0] = -1.5;
+		o->ub[0] = 1.5;
+		o->pMin = 0.8;
+		o->pMax = 1.2;
+		o->nHalfPlanes = 4;
+		const double a = 1.0 / M_PI;
+		const double hp[8] = {a, 0, -a, 0, 0, a, 0, -a};
+		std::memcpy(o->halfPlanes, hp, sizeof(hp));
+		break;
+	}
+	default:
+		return ASIF_HIP_EINVAL;
+	}
+	return ASIF_HIP_OK;
+}
+
+extern "C" int asif_hip_default_solver(asif_hip_solver *s)
+{
+	if (!s) return ASIF_HIP_EINVAL;
+	s->rho = 0.1;
+	s->sigma = 1e-6;
+	s->alpha = 1.6;
+	s->eps_abs = 1e-8;
+	s->eps_rel = 1e-8;
+	s->eps_prim_inf = 1e-4;
+	s->eps_dual_inf = 1e-4;
+	s->adaptive_rho_tolerance = 5.0;
+	s->max_iter = 4000;
+	s->check_interval = 10;
+	s->scaling_iters = 4;
+	s->polish = 1;
+	s->adaptive_rho = 1;
+	s->lanes_per_qp = 0;
+	return ASIF_HIP_OK;
+}
+
+static int model_dims(int model, int variant, const asif_hip_options &o, asif_hip_dims &d, DevOptions &dev)
+{
+	std::memset(&d, 0, sizeof(d));
+	std::memset(&dev, 0, sizeof(dev));
+	dev.relaxCost = o.relaxCost;
+	dev.relaxLb = o.relaxLb;
+	dev.relaxReachLb = o.relaxReachLb;
+	dev.relaxTTS = o.relaxTTS;
+	dev.relaxMinOrtho = o.relaxMinOrtho;
+	dev.backTrajHorizon = o.backTrajHorizon;
+	dev.backTrajDt = o.backTrajDt;
+	dev.backTrajMinOrtho = o.backTrajMinOrtho;
+	dev.satSharpness = o.satSharpness;
+	dev.inf = o.inf;
+	for (int i = 0; i < ASIF_HIP_MAX_NU; i++) {
+		dev.lb[i] = o.lb[i];
+		dev.ub[i] = o.ub[i];
+	}
+	dev.pMin = o.pMin;
+	dev.pMax = o.pMax;
+	dev.nHalfPlanes = o.nHalfPlanes;
+	std::memcpy(dev.halfPlanes, o.halfPlanes, sizeof(dev.halfPlanes));
+	// src/asif_implicit.cpp:689-703: evaluated with the host libm, once
+	dev.bevelL = o.satSharpness * std::tan(M_PI / 8);
+	dev.bevelStart = 1 - std::cos(M_PI / 4) * dev.bevelL;
+	dev.bevelStop = 1 + dev.bevelL;
+
+	if (model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR && variant == ASIF_HIP_EXPLICIT) {
+		d.nx = 2; d.nu = 1; d.npSS = 4;
+		d.nv = d.nu + 1;  // src/asif.cpp:19
+		d.nc = d.npSS;    // src/asif.cpp:21-22 (npSSmax = -1 clamps to npSS)
+		d.nrelax = 1;
+		d.ndiag = 1;
+		return ASIF_HIP_OK;
+	}
+	return ASIF_HIP_EINVAL;
+}
+
+static int check_device(int device)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return ASIF_HIP_ENODEVICE;
+	hipDeviceProp_t p;
+	if (hipGetDeviceProperties(&p, device) != hipSuccess) return ASIF_HIP_ENODEVICE;
+	if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0) return ASIF_HIP_ENODEVICE; // code objects are gfx950 only
+	return ASIF_HIP_OK;
+}
+
+extern "C" int asif_hip_create(asif_hip_ctx **out, int model, int variant, const asif_hip_options *opts,
+                               const asif_hip_solver *solver, int device)
+{
+	if (!out) return ASIF_HIP_EINVAL;
+	*out = nullptr;
+	asif_hip_options o;
+	if (opts) o = *opts;
+	else {
+		int r = asif_hip_default_options(model, variant, &o);
+		if (r) return r;
+	}
+	asif_hip_ctx *c = new (std::nothrow) asif_hip_ctx();
+	if (!c) return ASIF_HIP_EINVAL;
+	c->model = model;
+	c->variant = variant;
+	c->device = device;
+	c->opts = o;
+	if (solver) c->solver = *solver;
+	else asif_hip_default_solver(&c->solver);
+	int r = model_dims(model, variant, o, c->dims, c->dev);
+	if (r == ASIF_HIP_OK) r = check_device(device);
+	if (r != ASIF_HIP_OK) {
+		delete c;
+		return r;
+	}
+	c->d_in = c->d_out = nullptr;
+	c->d_rc = nullptr;
+	c->cap = 0;
+	*out = c;
+	return ASIF_HIP_OK;
+}
+
+extern "C" int asif_hip_destroy(asif_hip_ctx *ctx)
+{
+	if (!ctx) return ASIF_HIP_EINVAL;
+	if (ctx->d_in) {
+		(void)hipSetDevice(ctx->device);
+		(void)hipFree(ctx->d_in);
+		(void)hipFree(ctx->d_out);
+		(void)hipFree(ctx->d_rc);
+	}
+	delete ctx;
+	return ASIF_HIP_OK;
+}
+
+extern "C" int asif_hip_get_dims(const asif_hip_ctx *ctx, asif_hip_dims *d)
+{
+	if (!ctx || !d) return ASIF_HIP_EINVAL;
+	*d = ctx->dims;
+	return ASIF_HIP_OK;
+}
+
+extern "C" int asif_hip_update_options(asif_hip_ctx *ctx, const asif_hip_options *opts)
+{
+	if (!ctx || !opts) return ASIF_HIP_EINVAL;
+	asif_hip_dims d;
+	DevOptions dev;
+	int r = model_dims(ctx->model, ctx->variant, *opts, d, dev);
+	if (r) return r;
+	ctx->opts = *opts;
+	ctx->dims = d;
+	ctx->dev = dev;
+	return ASIF_HIP_OK;
+}
+
+static int run_filter(asif_hip_ctx *ctx, const FilterArgs &a, bool assemble_only, hipStream_t stream)
+{
+	if (ctx->model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR && ctx->variant == ASIF_HIP_EXPLICIT)
+		return launch_explicit_di(ctx->dev, ctx->solver, a, assemble_only, stream);
+	return ASIF_HIP_EINVAL;
+}
+
+extern "C" int asif_hip_filter_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, const double *x, const double *udes,
+                                     double *uact, double *relax, int32_t *rc, double *diag, void *stream)
+{
+	if (!ctx || B < 0 || ldx < B || (B > 0 && (!x || !udes || !uact || !relax || !rc))) return ASIF_HIP_EINVAL;
+	if (B == 0) return ASIF_HIP_OK;
+	hipError_t e = hipSetDevice(ctx->device);
+	if (e != hipSuccess) return (int)e;
+	FilterArgs a = {B, ldx, x, udes, uact, relax, rc, diag, ctx->dims.ndiag, nullptr, nullptr, nullptr};
+	return run_filter(ctx, a, false, (hipStream_t)stream);
+}
+
+extern "C" int asif_hip_assemble_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, const double *x, double *A,
+                                       double *b, int32_t *code, double *diag, void *stream)
+{
+	if (!ctx || B < 0 || ldx < B || (B > 0 && (!x || !A || !b || !code))) return ASIF_HIP_EINVAL;
+	if (B == 0) return ASIF_HIP_OK;
+	hipError_t e = hipSetDevice(ctx->device);
+	if (e != hipSuccess) return (int)e;
+	FilterArgs a = {B, ldx, x, x /*unused*/, nullptr, nullptr, nullptr, diag, ctx->dims.ndiag, A, b, code};
+	return run_filter(ctx, a, true, (hipStream_t)stream);
+}
+
+extern "C" int asif_hip_qp_solve_batch(int device, const asif_hip_solver *solver, int64_t B, int64_t ld, int32_t nv,
+                                       int32_t nc, const double *Hd, const double *c, const double *A,
+                                       const double *b, const double *lb, const double *ub, const uint8_t *be,
+                                       double *sol, int32_t *status, int32_t *iters, void *stream)
+{
+	if (B < 0 || ld < B || nv < 1 || nc < 0 || nc > 64) return ASIF_HIP_EINVAL;
+	if (B == 0) return ASIF_HIP_OK;
+	if (!Hd || !c || !A || !b || !lb || !ub || !sol || !status) return ASIF_HIP_EINVAL;
+	int r = check_device(device);
+	if (r) return r;
+	hipError_t e = hipSetDevice(device);
+	if (e != hipSuccess) return (int)e;
+	asif_hip_solver S;
+	if (solver) S = *solver;
+	else asif_hip_default_solver(&S);
+	uint64_t mask = 0;
+	if (be)
+		for (int i = 0; i < nc; i++)
+			if (be[i]) mask |= (1ull << i);
+	QpArgs a = {B, ld, nv, nc, Hd, c, A, b, lb, ub, mask, sol, status, iters};
+	return launch_qp_small(S, a, (hipStream_t)stream);
+}
+
+extern "C" int asif_hip_filter_batch_host(asif_hip_ctx *ctx, int64_t B, const double *x, const double *udes,
+                                          double *uact, double *relax, int32_t *rc)
+{
+	if (!ctx || B < 0) return ASIF_HIP_EINVAL;
+	if (B == 0) return ASIF_HIP_OK;
+	if (!x || !udes || !uact || !relax || !rc) return ASIF_HIP_EINVAL;
+	hipError_t e = hipSetDevice(ctx->device);
+	if (e != hipSuccess) return (int)e;
+	const asif_hip_dims &d = ctx->dims;
+	const int nin = d.nx + d.nu, nout = d.nu + d.nrelax;
+	if (B > ctx->cap) {
+		if (ctx->d_in) {
+			(void)hipFree(ctx->d_in);
+			(void)hipFree(ctx->d_out);
+			(void)hipFree(ctx->d_rc);
+			ctx->d_in = ctx->d_out = nullptr;
+			ctx->d_rc = nullptr;
+			ctx->cap = 0;
+		}
+		if ((e = hipMalloc((void **)&ctx->d_in, sizeof(double) * nin * B)) != hipSuccess) return (int)e;
+		if ((e = hipMalloc((void **)&ctx->d_out, sizeof(double) * nout * B)) != hipSuccess) return (int)e;
+		if ((e = hipMalloc((void **)&ctx->d_rc, sizeof(int32_t) * B)) != hipSuccess) return (int)e;
+		ctx->cap = B;
+	}
+	double *dx = ctx->d_in, *du = ctx->d_in + (int64_t)d.nx * B;
+	double *dua = ctx->d_out, *drl = ctx->d_out + (int64_t)d.nu * B;
+	hipStream_t s = nullptr;
+	if ((e = hipMemcpyAsync(dx, x, sizeof(double) * d.nx * B, hipMemcpyHostToDevice, s)) != hipSuccess) return (int)e;
+	if ((e = hipMemcpyAsync(du, udes, sizeof(double) * d.nu * B, hipMemcpyHostToDevice, s)) != hipSuccess) return (int)e;
+	// slots the kernel leaves untouched must keep the caller's values
+	if ((e = hipMemcpyAsync(dua, uact, sizeof(double) * d.nu * B, hipMemcpyHostToDevice, s)) != hipSuccess) return (int)e;
+	if ((e = hipMemcpyAsync(drl, relax, sizeof(double) * d.nrelax * B, hipMemcpyHostToDevice, s)) != hipSuccess) return (int)e;
+	int r = asif_hip_filter_batch(ctx, B, B, dx, du, dua, drl, ctx->d_rc, nullptr, s);
+	if (r) return r;
+	if ((e = hipMemcpyAsync(uact, dua, sizeof(double) * d.nu * B, hipMemcpyDeviceToHost, s)) != hipSuccess) return (int)e;
+	if ((e = hipMemcpyAsync(relax, drl, sizeof(double) * d.nrelax * B, hipMemcpyDeviceToHost, s)) != hipSuccess) return (int)e;
+	if ((e = hipMemcpyAsync(rc, ctx->d_rc, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s)) != hipSuccess) return (int)e;
+	return (int)hipStreamSynchronize(s);
+}

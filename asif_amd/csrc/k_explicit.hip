@@ -1,0 +1,133 @@
+// k_explicit.hip -- fused explicit CBF filter: ASIF::filter (src/asif.cpp:176-210) for a batch.
+//
+// One launch does, per instance: safetySet + dynamics (model functors), Lfh = Dh f, Lgh = Dh g
+// (src/asif.cpp:279-284), rows A = [Lgh | h], b = -Lfh (:295-303), the QP
+//   min (u-uDes)'(u-uDes) + relaxCost (delta-relaxLb)^2   s.t. rows, lb<=u<=ub, delta pinned (:84-98)
+// solved by the in-register ADMM, then inputSaturate (:343-352) and the return code (:199-209).
+// HBM traffic is the algorithmic minimum: 8(nx+nu) bytes in, 8(nu+1)+4 bytes out per instance, SoA,
+// consecutive lanes -> consecutive instances (G = 1) so every load/store is a fully coalesced line.
+#include "admm_small.hpp"
+#include "launchers.hpp"
+
+namespace asif {
+
+template <class M, int G>
+__global__ __launch_bounds__(64) void explicit_filter_kernel(DevOptions o, asif_hip_solver S, FilterArgs a,
+                                                             bool assemble_only)
+{
+	constexpr int NX = M::NX, NU = M::NU, NP = M::NPSS, NV = NU + 1, NC = NP;
+	constexpr int RPL = (NC + G - 1) / G;
+	const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int g = (int)(tid % G);
+	int64_t i = tid / G;
+	const bool live = i < a.B;
+	if (!live) i = a.B - 1; // keep the lane in the group reductions; it never stores
+
+	double x[NX], uDes[NU];
+#pragma unroll
+	for (int k = 0; k < NX; k++) x[k] = a.x[k * a.ld + i];
+#pragma unroll
+	for (int k = 0; k < NU; k++) uDes[k] = a.udes[k * a.ld + i];
+
+	double h[NP], Dh[NP * NX], f[NX], gm[NX * NU];
+	M::safetySet(o, x, h, Dh);
+	M::dynamics(o, x, f, gm);
+	double Lfh[NP], Lgh[NP * NU];
+#pragma unroll
+	for (int r = 0; r < NP; r++) {
+		double s = 0.0;
+#pragma unroll
+		for (int k = 0; k < NX; k++) s += Dh[r + k * NP] * f[k];
+		Lfh[r] = s;
+#pragma unroll
+		for (int j = 0; j < NU; j++) {
+			double t = 0.0;
+#pragma unroll
+			for (int k = 0; k < NX; k++) t += Dh[r + k * NP] * gm[k + j * NX];
+			Lgh[r + j * NP] = t;
+		}
+	}
+	if (assemble_only) {
+		if (live && g == 0) {
+#pragma unroll
+			for (int r = 0; r < NC; r++) {
+#pragma unroll
+				for (int j = 0; j < NU; j++) a.A[(r + j * NC) * a.ld + i] = Lgh[r + j * NP];
+				a.A[(r + NU * NC) * a.ld + i] = h[r];
+				a.b[r * a.ld + i] = -Lfh[r];
+			}
+			a.code[i] = 1;
+		}
+		return;
+	}
+
+	QpLaneData<NV, RPL> qp;
+#pragma unroll
+	for (int j = 0; j < NU; j++) {
+		qp.Hd[j] = 1.0;
+		qp.c[j] = -2.0 * uDes[j];
+		qp.lb[j] = o.lb[j];
+		qp.ub[j] = o.ub[j];
+	}
+	qp.Hd[NU] = o.relaxCost;
+	qp.c[NU] = -2.0 * o.relaxCost * o.relaxLb;
+	qp.lb[NU] = o.relaxLb;
+	qp.ub[NU] = o.relaxLb; // src/asif.cpp:91: the explicit class pins the relaxation variable
+#pragma unroll
+	for (int k = 0; k < RPL; k++) {
+		// row r = g + k*G of the NC rows; out-of-range rows are inert (0.x >= -big)
+#pragma unroll
+		for (int j = 0; j < NV; j++) qp.A[k][j] = 0.0;
+		qp.b[k] = -1e20;
+		qp.eq[k] = false;
+#pragma unroll
+		for (int r = 0; r < NC; r++)
+			if (r == g + k * G) {
+#pragma unroll
+				for (int j = 0; j < NU; j++) qp.A[k][j] = Lgh[r + j * NP];
+				qp.A[k][NU] = h[r];
+				qp.b[k] = -Lfh[r];
+			}
+	}
+	AdmmSmall<NV, RPL, G> admm;
+	double sol[NV];
+	int status, iters;
+	admm.solve(qp, S, sol, status, iters);
+
+	if (live && g == 0) {
+		if (status == kStatusSolved) {
+#pragma unroll
+			for (int j = 0; j < NU; j++) a.uact[j * a.ld + i] = fmin(fmax(sol[j], o.lb[j]), o.ub[j]);
+			a.relax[i] = sol[NU];
+			a.rc[i] = ASIF_HIP_RC_OK;
+		} else {
+			a.rc[i] = ASIF_HIP_RC_QP_FAILED; // uAct and relax stay untouched, src/asif.cpp:208-209
+		}
+		if (a.diag) a.diag[(a.ndiag - 1) * a.ld + i] = (double)iters;
+	}
+}
+
+template <int G>
+static int launch_g(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                    hipStream_t stream)
+{
+	const int block = 64;
+	hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, G>), dim3(grid_for(a.B, G, block)), dim3(block), 0,
+	                   stream, o, S, a, assemble_only);
+	return (int)hipGetLastError();
+}
+
+int launch_explicit_di(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                       hipStream_t stream)
+{
+	if (a.B <= 0) return 0;
+	switch (S.lanes_per_qp) {
+	case 2: return launch_g<2>(o, S, a, assemble_only, stream);
+	case 4: return launch_g<4>(o, S, a, assemble_only, stream);
+	case 0:
+	case 1: return launch_g<1>(o, S, a, assemble_only, stream);
+	default: return ASIF_HIP_EINVAL;
+	}
+}
+
+} // namespace asif

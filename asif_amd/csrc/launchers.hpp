@@ -1,0 +1,43 @@
+// launchers.hpp -- host-side launch functions, one per kernel family (each lives in its own .hip TU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "asif_hip.h"
+#include "models.hpp"
+
+namespace asif {
+
+struct FilterArgs {
+	int64_t B, ld;
+	const double *x, *udes;
+	double *uact, *relax;
+	int32_t *rc;
+	double *diag; // [ndiag][ld] or nullptr
+	int ndiag;
+	// assemble-only mode: rows out, no solve
+	double *A, *b;
+	int32_t *code;
+};
+
+// explicit CBF filter (class ASIF), model = DoubleIntegrator
+int launch_explicit_di(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                       hipStream_t stream);
+
+struct QpArgs {
+	int64_t B, ld;
+	int nv, nc;
+	const double *Hd, *c, *A, *b, *lb, *ub;
+	uint64_t be_mask;
+	double *sol;
+	int32_t *status, *iters;
+};
+// pre-assembled QPs; returns ASIF_HIP_EUNSUPPORTED for shapes without a compiled kernel
+int launch_qp_small(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream);
+
+inline int grid_for(int64_t B, int G, int block)
+{
+	const int64_t threads = B * G;
+	return (int)((threads + block - 1) / block);
+}
+
+} // namespace asif

@@ -1,0 +1,168 @@
+/*
+ * asif_hip.h -- C ABI of libasif_hip.so: the MI355X-native batched CBF-QP safety filter.
+ *
+ * This is the drop-in boundary for the reference's per-control-step hot path
+ * (DrewSingletary/asif; paths below are relative to that tree):
+ *
+ *   asif_hip_filter_batch      replaces  ASIF::filter / ASIFimplicit::filter / ASIFimplicitTB::filter /
+ *                                        ASIFrobust::filter called once per agent
+ *                                        (src/asif.cpp:176-210, src/asif_implicit.cpp:305-356,
+ *                                         src/asif_implicit_tb.cpp:261-363, src/asif_robust.cpp:218-252)
+ *                                        = updateConstraints + QPWrapperAbstract::{updateCost,updateA,updateb,
+ *                                          solve,getSolution} + inputSaturate, fused in one launch.
+ *   asif_hip_assemble_batch    replaces  updateConstraints alone (src/asif.cpp:233-312,
+ *                                        src/asif_implicit.cpp:403-651, src/asif_implicit_tb.cpp:407-733,
+ *                                        src/asif_robust.cpp:275-367): rows A, b as handed to updateA/updateb.
+ *   asif_hip_qp_solve_batch    replaces  the QPWrapperAbstract solve path for pre-assembled problems
+ *                                        (include/qpwrapper_abstract.h:16-51; src/qpwrapper_osqp.cpp:55-261:
+ *                                         initialize + solve + getSolution, cold start).
+ *
+ * Conventions
+ *   - plain C, no C++/torch/HIP types in any signature; `stream` is a hipStream_t passed as void* (NULL = default).
+ *   - every array is a DEVICE pointer to FP64 (int32 for codes), structure-of-arrays over the batch:
+ *     component k of instance i lives at  base[k * ld + i],  ld >= B  (ld = leading dimension in elements).
+ *     Matrices keep the reference's column-major order inside an instance: A(r,c) is component r + c*nc.
+ *   - QP convention of the reference (include/qpwrapper_abstract.h:11-15):
+ *         min x'Hx + c'x   s.t.  A x >= b  (== b where be[r]),  lb <= x <= ub,   H diagonal.
+ *   - return value: 0 on success, a negative ASIF_HIP_E* code, or a positive hipError_t.
+ *     Nothing here falls back to the CPU: without a usable GPU every entry point fails.
+ *   - calls are asynchronous on `stream`; the caller synchronises.  Handles are not thread-safe.
+ */
+#ifndef ASIF_HIP_H
+#define ASIF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASIF_HIP_VERSION 100
+
+enum asif_hip_error {
+	ASIF_HIP_OK = 0,
+	ASIF_HIP_EINVAL = -1,      /* bad argument / unsupported model-variant pair */
+	ASIF_HIP_ENODEVICE = -2,   /* no HIP device, or not gfx950 */
+	ASIF_HIP_EUNSUPPORTED = -3 /* QP shape outside the compiled kernels */
+};
+
+/* Device models = the user callbacks of the reference's examples, compiled for the GPU
+ * (host std::function callbacks cannot run on device, SURVEY 7 "Hard parts"). */
+enum asif_hip_model {
+	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR = 0,       /* examples/DoubleIntegrator.cpp:12-61          */
+	ASIF_HIP_MODEL_INVERTED_PENDULUM = 1,       /* examples/InvertedPendulum_Implicit.cpp:13-80 */
+	ASIF_HIP_MODEL_SEGWAY = 2,                  /* examples/segway_implicit_tb.cpp:13-212       */
+	ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST = 3 /* examples/InvertedPendulum_Robust.cpp:20-79   */
+};
+
+enum asif_hip_variant {
+	ASIF_HIP_EXPLICIT = 0,    /* class ASIF,           include/asif.h:8-101             */
+	ASIF_HIP_IMPLICIT = 1,    /* class ASIFimplicit,   include/asif_implicit.h:17-216   */
+	ASIF_HIP_IMPLICIT_TB = 2, /* class ASIFimplicitTB, include/asif_implicit_tb.h:17-208 */
+	ASIF_HIP_ROBUST = 3       /* class ASIFrobust,     include/asif_robust.h:11-89      */
+};
+
+#define ASIF_HIP_MAX_NU 1
+#define ASIF_HIP_MAX_HALFPLANES 8
+
+/* Union of the reference's four Options structs (include/asif.h:11-17, include/asif_implicit.h:20-34,
+ * include/asif_implicit_tb.h:19-33, include/asif_robust.h:14-19) + the input bounds initialize() takes. */
+typedef struct asif_hip_options {
+	double relaxCost;
+	double relaxLb;          /* ASIF/ASIFrobust relaxLb; ASIFimplicit/TB relaxSafeLb */
+	double relaxReachLb;     /* ASIFimplicit */
+	double relaxTTS;         /* ASIFimplicitTB */
+	double relaxMinOrtho;    /* ASIFimplicitTB */
+	double backTrajHorizon;
+	double backTrajExtend;   /* ASIFimplicitTB */
+	double backTrajDt;
+	double backTrajMinOrtho; /* ASIFimplicitTB */
+	double satSharpness;
+	double inf;
+	double lb[ASIF_HIP_MAX_NU];
+	double ub[ASIF_HIP_MAX_NU];
+	/* model data of the robust pendulum (examples/InvertedPendulum_Robust.cpp:35-38,51) */
+	double pMin, pMax;
+	int32_t nHalfPlanes;
+	double halfPlanes[2 * ASIF_HIP_MAX_HALFPLANES]; /* {a0,a1}: 1 - a.x >= 0 */
+} asif_hip_options;
+
+/* In-kernel ADMM settings.  Defaults (asif_hip_default_solver) are tuned for |u - u*| <= 1e-6:
+ * OSQP-style splitting with power-of-two Ruiz scaling, per-row rho, adaptive rho, infeasibility
+ * certificates, and a KKT-validated active-set polish tried at every termination check. */
+typedef struct asif_hip_solver {
+	double rho, sigma, alpha;
+	double eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
+	double adaptive_rho_tolerance;
+	int32_t max_iter;
+	int32_t check_interval; /* termination check + polish attempt + rho adaptation every this many iterations */
+	int32_t scaling_iters;
+	int32_t polish;
+	int32_t adaptive_rho;
+	int32_t lanes_per_qp;   /* 0 = library default for the shape */
+} asif_hip_solver;
+
+typedef struct asif_hip_dims {
+	int32_t nx, nu, npSS, npBS, npBTSS, nv, nc, nrelax, npBT, ndiag;
+} asif_hip_dims;
+
+/* Per-instance return codes of asif_hip_filter_batch = the reference's filter() return values. */
+#define ASIF_HIP_RC_OK 1                 /* src/asif.cpp:206 */
+#define ASIF_HIP_RC_QP_FAILED (-1)       /* src/asif.cpp:209, src/asif_implicit.cpp:354 */
+#define ASIF_HIP_RC_IN_BACKUP_SET 2      /* src/asif_implicit_tb.cpp:307 */
+#define ASIF_HIP_RC_BACKUP_UNREACHED (-3)/* src/asif_implicit_tb.cpp:360 */
+
+/* Solver status values written by asif_hip_qp_solve_batch = QPWrapperOsqp::solve()'s contract
+ * (src/qpwrapper_osqp.cpp:225-238): 1 (FEASIBLE) when solved, otherwise the OSQP-style raw status. */
+#define ASIF_HIP_STATUS_SOLVED 1
+#define ASIF_HIP_STATUS_MAX_ITER (-2)
+#define ASIF_HIP_STATUS_PRIMAL_INFEASIBLE (-3)
+#define ASIF_HIP_STATUS_DUAL_INFEASIBLE (-4)
+
+typedef struct asif_hip_ctx asif_hip_ctx;
+
+int asif_hip_version(void);
+const char *asif_hip_error_string(int code);
+int asif_hip_device_count(void);
+
+/* Fills *o with what the named example's main() passes to initialize() (C2..C5 of BASELINE.json). */
+int asif_hip_default_options(int model, int variant, asif_hip_options *o);
+int asif_hip_default_solver(asif_hip_solver *s);
+
+/* One handle = one (model, variant, options) triple on one device: the analogue of constructing an
+ * ASIF* object and calling initialize(lb,ub,opts).  solver may be NULL (defaults). */
+int asif_hip_create(asif_hip_ctx **out, int model, int variant, const asif_hip_options *opts,
+                    const asif_hip_solver *solver, int device);
+int asif_hip_destroy(asif_hip_ctx *ctx);
+int asif_hip_get_dims(const asif_hip_ctx *ctx, asif_hip_dims *d);
+/* updateOptions(options) of the reference classes (src/asif.cpp:213-231 etc.) */
+int asif_hip_update_options(asif_hip_ctx *ctx, const asif_hip_options *opts);
+
+/* B independent filter() calls.  x[nx][ldx], udes[nu][ldx] in; uact[nu][ldx], relax[nrelax][ldx], rc[B] out.
+ * Where the reference leaves uAct/relax untouched (QP failed in ASIF/ASIFrobust, relax on any failure)
+ * the slots are left untouched too.  diag (may be NULL): [ndiag][ldx] per-instance diagnostics --
+ * TB: {TTS_, BTorthoBS_}; all: last slot = ADMM iterations used.  iters (may be NULL): int32[B]. */
+int asif_hip_filter_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, const double *x, const double *udes,
+                          double *uact, double *relax, int32_t *rc, double *diag, void *stream);
+
+/* Rows only: A[(nc*nv)][ldx], b[nc][ldx], code[B] (1; TB: 2 trivial rows, -3 backup set unreached). */
+int asif_hip_assemble_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, const double *x, double *A, double *b,
+                            int32_t *code, double *diag, void *stream);
+
+/* B pre-assembled QPs of one shape.  Hd[nv][ld] (diagonal of H), c[nv][ld], A[(nc*nv)][ld], b[nc][ld],
+ * lb[nv][ld], ub[nv][ld]; be: HOST array of nc flags shared by the batch (NULL = none);
+ * sol[nv][ld], status[B], iters[B] (may be NULL).  Cold start per instance. */
+int asif_hip_qp_solve_batch(int device, const asif_hip_solver *solver, int64_t B, int64_t ld, int32_t nv,
+                            int32_t nc, const double *Hd, const double *c, const double *A, const double *b,
+                            const double *lb, const double *ub, const uint8_t *be, double *sol,
+                            int32_t *status, int32_t *iters, void *stream);
+
+/* Host-buffer convenience (pinned or pageable host memory, blocking): H2D, filter, D2H.  AoS->SoA is the
+ * caller's business: same [component][ld] layout.  Used by the C++ class mirror for single agents. */
+int asif_hip_filter_batch_host(asif_hip_ctx *ctx, int64_t B, const double *x, const double *udes, double *uact,
+                               double *relax, int32_t *rc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

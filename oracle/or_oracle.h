@@ -130,7 +130,8 @@ typedef struct {
 	int scaling, adaptive_rho, adaptive_rho_interval, check_termination, max_iter;
 	double adaptive_rho_tolerance;
 	int reduced_kkt;  /* 0: quasi-definite (n+m) KKT like OSQP/QDLDL; 1: n x n Schur form (device layout) */
-	int polish;       /* 0 off (reference), 1 on */
+	int polish;       /* 0 off (reference), 1 on: validated active-set polish at every check */
+	int scaling_pow2; /* 0 exact Ruiz factors (reference); 1 factors rounded to powers of two (device) */
 } or_admm_settings;
 
 void or_admm_default_settings(or_admm_settings *s); /* OSQP 0.6 defaults + max_iter=2000 (src/qpwrapper_osqp.cpp:68-69) */

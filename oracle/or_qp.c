@@ -202,6 +202,7 @@ void or_admm_default_settings(or_admm_settings *s)
 	s->max_iter = 2000; /* src/qpwrapper_osqp.cpp:69 */
 	s->reduced_kkt = 0;
 	s->polish = 0;
+	s->scaling_pow2 = 0;
 }
 
 typedef struct {
@@ -227,7 +228,16 @@ static double limit_scaling(double v)
 }
 
 /* Ruiz equilibration of the KKT matrix + cost normalisation (OSQP scaling.c, scale_data) */
-static void scale_data(ws_t *w, int iters)
+static double inv_sqrt_scale(double v, int pow2)
+{
+	if (!pow2) return 1.0 / sqrt(v);
+	/* power-of-two stand-in for 1/sqrt(v): exact to apply and to undo (device scaling) */
+	int e;
+	frexp(v, &e); /* v = f * 2^e, f in [0.5,1) */
+	return ldexp(1.0, -(e >> 1));
+}
+
+static void scale_data(ws_t *w, int iters, int pow2)
 {
 	const int n = w->n, m = w->m;
 	for (int j = 0; j < n; j++) w->D[j] = 1.0;
@@ -241,7 +251,7 @@ static void scale_data(ws_t *w, int iters)
 				const double a = fabs(w->A[i * n + j]);
 				if (a > v) v = a;
 			}
-			Dt[j] = 1.0 / sqrt(limit_scaling(v));
+			Dt[j] = inv_sqrt_scale(limit_scaling(v), pow2);
 		}
 		for (int i = 0; i < m; i++) {
 			double v = 0;
@@ -249,7 +259,7 @@ static void scale_data(ws_t *w, int iters)
 				const double a = fabs(w->A[i * n + j]);
 				if (a > v) v = a;
 			}
-			Et[i] = 1.0 / sqrt(limit_scaling(v));
+			Et[i] = inv_sqrt_scale(limit_scaling(v), pow2);
 		}
 		for (int j = 0; j < n; j++) {
 			w->P[j] = Dt[j] * w->P[j] * Dt[j];
@@ -269,6 +279,11 @@ static void scale_data(ws_t *w, int iters)
 		qn = limit_scaling(qn);
 		double ct = cmean > qn ? cmean : qn;
 		ct = 1.0 / limit_scaling(ct);
+		if (pow2) {
+			int e;
+			frexp(ct, &e);
+			ct = ldexp(1.0, e - 1);
+		}
 		for (int j = 0; j < n; j++) {
 			w->P[j] *= ct;
 			w->q[j] *= ct;
@@ -373,6 +388,100 @@ static double scaled_norm_inf(const double *s, const double *v, int n)
 	return r;
 }
 
+/* Active-set polish, tried at a termination check (OSQP polish.c idea in primal Schur form):
+ * guess lower/upper-active rows from (z,y), solve the equality-constrained QP on them by the
+ * regularised system with `refine` refinement steps, and ACCEPT ONLY if the point satisfies the
+ * KKT conditions of the full problem (all rows feasible, multipliers correctly signed).  Off in
+ * the reference configuration (OSQP default polish=0); used to study the device algorithm. */
+static int try_polish(const ws_t *w, const double *z, const double *y, double *xpol, double ktol)
+{
+	const int n = w->n, m = w->m;
+	const double delta = 1e-6;
+	int act[MAXM];
+	double r[MAXM], nu[MAXM];
+	int na = 0;
+	for (int i = 0; i < m; i++) {
+		act[i] = 0;
+		if (w->u[i] - w->l[i] < RHO_TOL) { act[i] = 2; r[i] = w->l[i]; na++; } /* equality: always active, free sign */
+		else if (z[i] - w->l[i] < -y[i]) { act[i] = -1; r[i] = w->l[i]; na++; }
+		else if (w->u[i] - z[i] < y[i]) { act[i] = 1; r[i] = w->u[i]; na++; }
+		nu[i] = 0;
+	}
+	/* M = P + delta I + (1/delta) sum_act a a' ; dense LDL' */
+	double M[MAXN * MAXN], Dg[MAXN], x[MAXN] = {0}, e1[MAXN], e2[MAXM], rhs[MAXN];
+	for (int a = 0; a < n; a++)
+		for (int b = 0; b <= a; b++) {
+			double sacc = 0;
+			for (int i = 0; i < m; i++)
+				if (act[i]) sacc += w->A[i * n + a] * w->A[i * n + b];
+			M[a * n + b] = sacc / delta + (a == b ? w->P[a] + delta : 0.0);
+		}
+	for (int j = 0; j < n; j++) {
+		double d = M[j * n + j];
+		for (int k = 0; k < j; k++) d -= M[j * n + k] * M[j * n + k] * Dg[k];
+		if (!(d > 0)) return 0;
+		Dg[j] = d;
+		for (int i = j + 1; i < n; i++) {
+			double sacc = M[i * n + j];
+			for (int k = 0; k < j; k++) sacc -= M[i * n + k] * M[j * n + k] * Dg[k];
+			M[i * n + j] = sacc / d;
+		}
+	}
+	for (int it = 0; it < 4; it++) {
+		/* residual of the un-regularised KKT system at (x,nu) */
+		for (int j = 0; j < n; j++) e1[j] = -w->q[j] - w->P[j] * x[j];
+		for (int i = 0; i < m; i++) {
+			if (!act[i]) continue;
+			double ax = 0;
+			for (int j = 0; j < n; j++) ax += w->A[i * n + j] * x[j];
+			e2[i] = r[i] - ax;
+			for (int j = 0; j < n; j++) e1[j] -= w->A[i * n + j] * nu[i];
+		}
+		for (int j = 0; j < n; j++) rhs[j] = e1[j];
+		for (int i = 0; i < m; i++)
+			if (act[i])
+				for (int j = 0; j < n; j++) rhs[j] += w->A[i * n + j] * e2[i] / delta;
+		for (int i = 0; i < n; i++) {
+			double sacc = rhs[i];
+			for (int k = 0; k < i; k++) sacc -= M[i * n + k] * rhs[k];
+			rhs[i] = sacc;
+		}
+		for (int i = 0; i < n; i++) rhs[i] /= Dg[i];
+		for (int i = n - 1; i >= 0; i--) {
+			double sacc = rhs[i];
+			for (int k = i + 1; k < n; k++) sacc -= M[k * n + i] * rhs[k];
+			rhs[i] = sacc;
+		}
+		for (int i = 0; i < m; i++) {
+			if (!act[i]) continue;
+			double adx = 0;
+			for (int j = 0; j < n; j++) adx += w->A[i * n + j] * rhs[j];
+			nu[i] += (adx - e2[i]) / delta;
+		}
+		for (int j = 0; j < n; j++) x[j] += rhs[j];
+	}
+	/* KKT validation on the full problem (scaled space; rows with E scaling are O(1)) */
+	for (int i = 0; i < m; i++) {
+		double ax = 0;
+		for (int j = 0; j < n; j++) ax += w->A[i * n + j] * x[j];
+		const double tol = ktol * (1 + fabs(ax));
+		if (ax < w->l[i] - tol || ax > w->u[i] + tol) return 0;
+		if (act[i] == -1 && nu[i] > ktol * (1 + fabs(nu[i]))) return 0;
+		if (act[i] == 1 && nu[i] < -ktol * (1 + fabs(nu[i]))) return 0;
+	}
+	double sres = 0; /* stationarity after the last refinement */
+	for (int j = 0; j < n; j++) {
+		double g = w->P[j] * x[j] + w->q[j];
+		for (int i = 0; i < m; i++)
+			if (act[i]) g += w->A[i * n + j] * nu[i];
+		if (fabs(g) > sres) sres = fabs(g);
+	}
+	if (sres > 1e-7) return 0;
+	for (int j = 0; j < n; j++) xpol[j] = x[j];
+	(void)na;
+	return 1;
+}
+
 int or_qp_admm(const or_qp *qp, const or_admm_settings *s, double *xout, or_admm_info *info)
 {
 	static __thread ws_t W;
@@ -398,7 +507,7 @@ int or_qp_admm(const or_qp *qp, const or_admm_settings *s, double *xout, or_admm
 		w->l[i] = qp->lb[j];
 		w->u[i] = qp->ub[j];
 	}
-	if (s->scaling > 0) scale_data(w, s->scaling);
+	if (s->scaling > 0) scale_data(w, s->scaling, s->scaling_pow2);
 	else {
 		for (int j = 0; j < n; j++) w->D[j] = w->Dinv[j] = 1.0;
 		for (int i = 0; i < m; i++) w->E[i] = w->Einv[i] = 1.0;
@@ -475,6 +584,15 @@ int or_qp_admm(const or_qp *qp, const or_admm_settings *s, double *xout, or_admm
 		}
 		pri_res = scaled_norm_inf(w->Einv, tmpm, m);
 		dua_res = w->cinv * scaled_norm_inf(w->Dinv, tmpn, n);
+		if (s->polish && (do_check || last)) {
+			double xpol[MAXN];
+			if (try_polish(w, z, y, xpol, 1e-9)) {
+				memcpy(x, xpol, sizeof(double) * n);
+				status = OR_OSQP_SOLVED;
+				rho_updates += 1000; /* marks "ended by polish" in info */
+				break;
+			}
+		}
 		for (int approx = 0; approx <= (last ? 1 : 0); approx++) {
 			if (!(do_check || last)) break;
 			const double k = approx ? 10.0 : 1.0;

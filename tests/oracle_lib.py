@@ -40,7 +40,7 @@ class AdmmSettings(C.Structure):
                                           "eps_dual_inf")] + [
         (n, C.c_int) for n in ("scaling", "adaptive_rho", "adaptive_rho_interval", "check_termination",
                                "max_iter")] + [("adaptive_rho_tolerance", C.c_double), ("reduced_kkt", C.c_int),
-                                               ("polish", C.c_int)]
+                                               ("polish", C.c_int), ("scaling_pow2", C.c_int)]
 
 
 class AfInstr(C.Structure):

@@ -1,0 +1,80 @@
+"""C2 (BASELINE.json configs[1]): DoubleIntegrator explicit CBF filter on the GPU vs the oracle.
+
+Tolerance: the north star asks |u* - u_ref| <= 1e-5 with u_ref = exact optimum of the QP the
+reference assembles; the tests hold the HIP path to 1e-6.  Return codes must match
+exactly; rows (A, b) to 1e-12 (the only differences are FMA contractions).
+"""
+import numpy as np
+import pytest
+
+import gpu_util
+
+pytestmark = pytest.mark.gpu
+
+U_TOL = 1e-6
+
+
+def test_rows_match_oracle(hip, oracle):
+    B = 4096
+    out = gpu_util.run_assemble(2, B)
+    model, variant = oracle.CONFIGS[2]
+    o = oracle.default_options(model, variant)
+    A, b, code, _ = oracle.assemble_batch(model, variant, o, np.ascontiguousarray(out["x"].T))
+    assert np.array_equal(out["code"], code)
+    np.testing.assert_allclose(out["A"].T, A, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out["b"].T, b, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+def test_filter_matches_exact_optimum(hip, oracle, lanes):
+    B = 8192
+    s = hip.default_solver(lanes_per_qp=lanes)
+    out = gpu_util.run_filter(2, B, solver=s, uact_init=7.0, relax_init=-7.0)
+    ua, rl, rc = gpu_util.oracle_filter(oracle, 2, out["x"], out["udes"], uact_init=7.0, relax_init=-7.0)
+    assert np.array_equal(out["rc"], rc), f"rc mismatches: {(out['rc'] != rc).sum()}"
+    assert (rc == -1).sum() > 100 and (rc == 1).sum() > 1000  # both branches exercised
+    err = np.abs(out["uact"] - ua).max()
+    assert err <= U_TOL, err
+    assert np.abs(out["relax"] - rl).max() <= U_TOL
+    # untouched slots on QP failure (src/asif.cpp:208-209)
+    assert np.all(out["uact"][0, rc == -1] == 7.0) and np.all(out["relax"][0, rc == -1] == -7.0)
+
+
+def test_full_size_properties(hip):
+    """B = 65 536 (the benchmark size): feasibility of the returned u against the assembled rows,
+    input bounds, determinism, and shard equivalence (two halves == whole, bitwise)."""
+    B = 65536
+    out = gpu_util.run_filter(2, B)
+    rows = gpu_util.run_assemble(2, B)
+    ok = out["rc"] == 1
+    assert set(np.unique(out["rc"])) <= {1, -1}
+    u = out["uact"][0]
+    d = out["relax"][0]
+    assert np.all(u[ok] >= -1.0) and np.all(u[ok] <= 1.0)
+    assert np.allclose(d[ok], 5.0, atol=1e-7)  # pinned relaxation variable
+    A = rows["A"].reshape(2, 4, B)
+    lhs = A[0] * u + A[1] * d
+    viol = (rows["b"] - lhs)[:, ok].max()
+    assert viol <= 1e-6, viol
+    again = gpu_util.run_filter(2, B)
+    assert np.array_equal(again["uact"], out["uact"]) and np.array_equal(again["rc"], out["rc"])
+    h1 = gpu_util.run_filter(2, B // 2, first=0)
+    h2 = gpu_util.run_filter(2, B // 2, first=B // 2)
+    assert np.array_equal(np.concatenate([h1["uact"], h2["uact"]], axis=1), out["uact"])
+    assert np.array_equal(np.concatenate([h1["rc"], h2["rc"]]), out["rc"])
+
+
+def test_edge_cases(hip, oracle):
+    # empty batch is a no-op
+    import torch
+    flt = hip.Filter(hip.MODEL_DOUBLE_INTEGRATOR, hip.EXPLICIT)
+    e = torch.zeros((2, 0), dtype=torch.float64, device="cuda")
+    flt.filter(e, e[:1], e[:1], e[:1], torch.zeros(0, dtype=torch.int32, device="cuda"))
+    # ragged batch (not a multiple of the wave size) and special states: origin, corners, v = 0 switch
+    x = np.array([[0.0, 1.0, -1.0, 0.999, -0.999, 0.5, 0.5, 0.0, 1.2],
+                  [0.0, 1.0, -1.0, 0.0, 0.0, 0.0, -0.0, 1e-300, -1.2]])
+    ud = np.array([[1.0, 1.5, -1.5, 1.0, -1.0, 0.0, 0.3, -0.2, 1.0]])
+    out = gpu_util.run_filter(2, x.shape[1], x=x, udes=ud, uact_init=9.0)
+    ua, rl, rc = gpu_util.oracle_filter(oracle, 2, x, ud, uact_init=9.0)
+    assert np.array_equal(out["rc"], rc)
+    assert np.abs(out["uact"] - ua).max() <= U_TOL
