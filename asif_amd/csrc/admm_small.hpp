@@ -11,8 +11,10 @@
 //     P + sigma I + A' diag(rho) A, factored LDL' in registers (nv <= 4: a handful of FMAs).  The
 //     row-outer-product sum is formed once; a rho change refactors without any cross-lane traffic.
 //   * Ruiz equilibration uses power-of-two factors (exponent arithmetic, exact to apply and undo).
-//   * Every `check_interval` iterations: a KKT-validated active-set polish, the unscaled residual
-//     test (OSQP's criteria), primal/dual infeasibility certificates, and rho adaptation.
+//   * Every `check_interval` iterations: an active-set finish seeded by the iterates (exact solve on
+//     the guessed working set, primal-dual corrections, accepted only when KKT-valid or when it
+//     carries an exact Farkas certificate), then the unscaled residual test (OSQP's criteria),
+//     OSQP's primal/dual infeasibility certificates, and rho adaptation.
 // Form translation follows the wrapper the reference puts in front of OSQP (src/qpwrapper_osqp.cpp:263-376):
 //   P = 2H, q = c, rows [A; I], l = [b; lb], u = [+inf | b where be; ub].
 // General rows are one-sided (A x >= b) or equalities; `b` is data and always finite (the reference's
@@ -32,7 +34,6 @@ constexpr double kRhoEqOverIneq = 1e3;
 constexpr double kRhoTol = 1e-4;
 constexpr double kPolishDelta = 1e-6;
 constexpr double kPolishKktTol = 1e-9;
-constexpr double kPolishStatTol = 1e-7;
 
 constexpr int kStatusSolved = 1;
 constexpr int kStatusSolvedInaccurate = 2;
@@ -310,106 +311,243 @@ struct AdmmSmall {
 		}
 	}
 
-	// KKT-validated active-set polish; on success xp holds the polished (scaled) x.
-	// act: 0 inactive, -1 at lower, +1 at upper, 2 equality (always active, multiplier free).
-	__device__ __forceinline__ bool polish(double (&xp)[NV])
+	// ---- Active-set finish.  The ADMM iterates only have to point at the right working set; this
+	// routine then solves the equality-constrained QP on that set exactly (regularised primal Schur
+	// system + refinement, the idea of OSQP's polish step), classifies every row at the result, and
+	// corrects the set primal-dual-active-set style: rows found violated join, rows with a wrongly
+	// signed multiplier leave.  Nothing is accepted on trust:
+	//   return 1  the point satisfies the KKT conditions of the FULL problem (optimal; xp filled),
+	//   return 2  the least-squares residual of the working rows is a Farkas certificate
+	//             (all residuals have the sign of a violation, A_S' v = 0 by construction, and then
+	//             sum r_i v_i = |v|^2 > 0): the QP is infeasible,
+	//   return 0  undecided -> ADMM keeps iterating and the next check tries again.
+	// act: 0 inactive, -1 at lower bound, +1 at upper bound, 2 equality (always in, multiplier free).
+	__device__ __forceinline__ int finish(double (&xp)[NV], int rounds, int refine)
 	{
 		const double idelta = 1.0 / kPolishDelta;
 		int act[RPL], actb[NV];
 		double nu[RPL], nub[NV], rtb[NV];
 #pragma unroll
-		for (int r = 0; r < RPL; r++) {
-			act[r] = eqr[r] ? 2 : ((z[r] - l[r] < -y[r]) ? -1 : 0);
-			nu[r] = 0.0;
-		}
+		for (int r = 0; r < RPL; r++) act[r] = eqr[r] ? 2 : ((z[r] - l[r] < -y[r]) ? -1 : 0);
 #pragma unroll
 		for (int j = 0; j < NV; j++) {
 			actb[j] = 0;
-			rtb[j] = 0.0;
-			if (clsb[j] > 0) { actb[j] = 2; rtb[j] = lbs[j]; }
-			else if (zb[j] - lbs[j] < -yb[j]) { actb[j] = -1; rtb[j] = lbs[j]; }
+			rtb[j] = lbs[j];
+			if (clsb[j] > 0) actb[j] = 2;
+			else if (zb[j] - lbs[j] < -yb[j]) actb[j] = -1;
 			else if (ubs[j] - zb[j] < yb[j]) { actb[j] = 1; rtb[j] = ubs[j]; }
-			nub[j] = 0.0;
 		}
-		double Mp[NV][NV], Mi[NV];
-#pragma unroll
-		for (int a = 0; a < NV; a++)
-#pragma unroll
-			for (int b = 0; b <= a; b++) {
-				double s = 0.0;
-#pragma unroll
-				for (int r = 0; r < RPL; r++) s += act[r] ? A[r][a] * A[r][b] : 0.0;
-				s = gsum<G>(s) * idelta;
-				if (a == b) s += P[a] + kPolishDelta + (actb[a] ? Ab[a] * Ab[a] * idelta : 0.0);
-				Mp[a][b] = s;
-			}
-		bool ok = ldl_factor<NV>(Mp, Mi);
-#pragma unroll
-		for (int j = 0; j < NV; j++) xp[j] = 0.0;
+		int verdict = 0;
 #pragma unroll 1
-		for (int it = 0; it < 4; it++) {
-			double rhs[NV], e2[RPL], e2b[NV];
+		for (int round = 0; round <= rounds; round++) {
+			// -- equality-constrained solve on the working set
+			double Mp[NV][NV], Mi[NV];
 #pragma unroll
-			for (int j = 0; j < NV; j++) rhs[j] = 0.0;
+			for (int a = 0; a < NV; a++)
+#pragma unroll
+				for (int b = 0; b <= a; b++) {
+					double s = 0.0;
+#pragma unroll
+					for (int r = 0; r < RPL; r++) s += act[r] ? A[r][a] * A[r][b] : 0.0;
+					s = gsum<G>(s) * idelta;
+					// primal regularisation only where the cost has no curvature of its own
+					if (a == b) s += (P[a] > 0.0 ? P[a] : kPolishDelta) + (actb[a] ? Ab[a] * Ab[a] * idelta : 0.0);
+					Mp[a][b] = s;
+				}
+			bool ok = ldl_factor<NV>(Mp, Mi);
+#pragma unroll
+			for (int j = 0; j < NV; j++) { xp[j] = 0.0; nub[j] = 0.0; }
+#pragma unroll
+			for (int r = 0; r < RPL; r++) nu[r] = 0.0;
+#pragma unroll 1
+			for (int it = 0; it < refine; it++) {
+				double rhs[NV], e2[RPL], e2b[NV];
+#pragma unroll
+				for (int j = 0; j < NV; j++) rhs[j] = 0.0;
+#pragma unroll
+				for (int r = 0; r < RPL; r++) {
+					double ax = 0.0;
+#pragma unroll
+					for (int j = 0; j < NV; j++) ax += A[r][j] * xp[j];
+					e2[r] = l[r] - ax;
+					const double w = act[r] ? (e2[r] * idelta - nu[r]) : 0.0;
+#pragma unroll
+					for (int j = 0; j < NV; j++) rhs[j] += A[r][j] * w;
+				}
+#pragma unroll
+				for (int j = 0; j < NV; j++) {
+					rhs[j] = gsum<G>(rhs[j]);
+					e2b[j] = rtb[j] - Ab[j] * xp[j];
+					rhs[j] += -q[j] - P[j] * xp[j] + (actb[j] ? Ab[j] * (e2b[j] * idelta - nub[j]) : 0.0);
+				}
+				ldl_solve<NV>(Mp, Mi, rhs); // rhs = dx
+#pragma unroll
+				for (int r = 0; r < RPL; r++) {
+					double adx = 0.0;
+#pragma unroll
+					for (int j = 0; j < NV; j++) adx += A[r][j] * rhs[j];
+					nu[r] += act[r] ? (adx - e2[r]) * idelta : 0.0;
+				}
+#pragma unroll
+				for (int j = 0; j < NV; j++) {
+					nub[j] += actb[j] ? (Ab[j] * rhs[j] - e2b[j]) * idelta : 0.0;
+					xp[j] += rhs[j];
+				}
+			}
+			// -- classify every row at xp; build the corrected working set
+			int nact[RPL], nactb[NV];
+			bool viol_active = false, changed = false;
+			double g[NV], gm[NV];
+#pragma unroll
+			for (int j = 0; j < NV; j++) { g[j] = 0.0; gm[j] = 0.0; }
 #pragma unroll
 			for (int r = 0; r < RPL; r++) {
 				double ax = 0.0;
 #pragma unroll
 				for (int j = 0; j < NV; j++) ax += A[r][j] * xp[j];
-				e2[r] = l[r] - ax;
-				const double w = act[r] ? (e2[r] * idelta - nu[r]) : 0.0;
+				const double tol = kPolishKktTol * (1.0 + fabs(ax));
+				const bool below = ax < l[r] - tol, above = eqr[r] && ax > l[r] + tol;
+				const bool wrong = act[r] == -1 && nu[r] > kPolishKktTol * (1.0 + fabs(nu[r]));
+				ok = ok && !below && !above && !wrong;
+				viol_active = viol_active || ((below || above) && act[r] != 0);
+				nact[r] = eqr[r] ? 2 : (wrong ? 0 : ((below && act[r] == 0) ? -1 : act[r]));
+				changed = changed || (nact[r] != act[r]);
 #pragma unroll
-				for (int j = 0; j < NV; j++) rhs[j] += A[r][j] * w;
+				for (int j = 0; j < NV; j++) {
+					const double t = act[r] ? A[r][j] * nu[r] : 0.0;
+					g[j] += t;
+					gm[j] += fabs(t);
+				}
 			}
 #pragma unroll
 			for (int j = 0; j < NV; j++) {
-				rhs[j] = gsum<G>(rhs[j]);
-				e2b[j] = rtb[j] - Ab[j] * xp[j];
-				rhs[j] += -q[j] - P[j] * xp[j] + (actb[j] ? Ab[j] * (e2b[j] * idelta - nub[j]) : 0.0);
+				const double ax = Ab[j] * xp[j];
+				const double tol = kPolishKktTol * (1.0 + fabs(ax));
+				const bool below = ax < lbs[j] - tol, above = ax > ubs[j] + tol;
+				const double nt = kPolishKktTol * (1.0 + fabs(nub[j]));
+				const bool wrong = (actb[j] == -1 && nub[j] > nt) || (actb[j] == 1 && nub[j] < -nt);
+				ok = ok && !below && !above && !wrong;
+				viol_active = viol_active || ((below || above) && actb[j] != 0);
+				nactb[j] = actb[j] == 2 ? 2 : (wrong ? 0 : ((actb[j] == 0 && below) ? -1 : ((actb[j] == 0 && above) ? 1 : actb[j])));
+				changed = changed || (nactb[j] != actb[j]);
+				// stationarity, relative to the size of its own terms (a column can be scaled very small)
+				const double tb = actb[j] ? Ab[j] * nub[j] : 0.0;
+				const double gj = gsum<G>(g[j]) + P[j] * xp[j] + q[j] + tb;
+				const double mag = gsum<G>(gm[j]) + fabs(P[j] * xp[j]) + fabs(q[j]) + fabs(tb);
+				ok = ok && !(fabs(gj) > 1e-10 * mag + 1e-300);
 			}
-			ldl_solve<NV>(Mp, Mi, rhs); // rhs = dx
+			if (gand<G>(ok ? 1 : 0)) { verdict = 1; break; }
+			// -- infeasibility: least-squares point of the working rows.  Rows met with slack there
+			//    leave (removal only -> monotone), the rest must all show the sign of a violation.
+			if (gand<G>(viol_active ? 0 : 1) == 0) {
+				int fa[RPL], fab[NV];
 #pragma unroll
-			for (int r = 0; r < RPL; r++) {
-				double adx = 0.0;
+				for (int r = 0; r < RPL; r++) fa[r] = act[r];
 #pragma unroll
-				for (int j = 0; j < NV; j++) adx += A[r][j] * rhs[j];
-				nu[r] += act[r] ? (adx - e2[r]) * idelta : 0.0;
+				for (int j = 0; j < NV; j++) fab[j] = actb[j];
+				bool cert = false;
+#pragma unroll 1
+				for (int fi = 0; fi <= 4; fi++) {
+					double Ms[NV][NV], Msi[NV], wv[NV], dmax = 0.0;
+#pragma unroll
+					for (int a = 0; a < NV; a++)
+#pragma unroll
+						for (int b = 0; b <= a; b++) {
+							double s = 0.0;
+#pragma unroll
+							for (int r = 0; r < RPL; r++) s += fa[r] ? A[r][a] * A[r][b] : 0.0;
+							s = gsum<G>(s);
+							if (a == b) {
+								s += fab[a] ? Ab[a] * Ab[a] : 0.0;
+								dmax = fmax(dmax, s);
+							}
+							Ms[a][b] = s;
+						}
+#pragma unroll
+					for (int a = 0; a < NV; a++) Ms[a][a] += 1e-14 * dmax + 1e-300;
+					bool fk = ldl_factor<NV>(Ms, Msi);
+#pragma unroll
+					for (int j = 0; j < NV; j++) {
+						double s = 0.0;
+#pragma unroll
+						for (int r = 0; r < RPL; r++) s += fa[r] ? A[r][j] * l[r] : 0.0;
+						wv[j] = gsum<G>(s) + (fab[j] ? Ab[j] * rtb[j] : 0.0);
+					}
+					ldl_solve<NV>(Ms, Msi, wv);
+					{ // one refinement step removes the footprint of the regularisation from A_S' v
+						double g2[NV];
+#pragma unroll
+						for (int j = 0; j < NV; j++) g2[j] = 0.0;
+#pragma unroll
+						for (int r = 0; r < RPL; r++) {
+							double ax = 0.0;
+#pragma unroll
+							for (int j = 0; j < NV; j++) ax += A[r][j] * wv[j];
+							const double v = fa[r] ? l[r] - ax : 0.0;
+#pragma unroll
+							for (int j = 0; j < NV; j++) g2[j] += A[r][j] * v;
+						}
+#pragma unroll
+						for (int j = 0; j < NV; j++)
+							g2[j] = gsum<G>(g2[j]) + (fab[j] ? Ab[j] * (rtb[j] - Ab[j] * wv[j]) : 0.0);
+						ldl_solve<NV>(Ms, Msi, g2);
+#pragma unroll
+						for (int j = 0; j < NV; j++) wv[j] += g2[j];
+					}
+					bool signs_ok = true;
+					double vmax = 0.0, atv[NV];
+#pragma unroll
+					for (int j = 0; j < NV; j++) atv[j] = 0.0;
+#pragma unroll
+					for (int r = 0; r < RPL; r++) {
+						double ax = 0.0;
+#pragma unroll
+						for (int j = 0; j < NV; j++) ax += A[r][j] * wv[j];
+						double v = fa[r] ? l[r] - ax : 0.0;
+						if (fa[r] == -1 && v < -1e-12) { // met with slack: leaves the set
+							signs_ok = false;
+							fa[r] = 0;
+							v = 0.0;
+						}
+						vmax = fmax(vmax, fabs(v));
+#pragma unroll
+						for (int j = 0; j < NV; j++) atv[j] += A[r][j] * v;
+					}
+					double vb[NV];
+#pragma unroll
+					for (int j = 0; j < NV; j++) {
+						vb[j] = fab[j] ? rtb[j] - Ab[j] * wv[j] : 0.0;
+						if ((fab[j] == -1 && vb[j] < -1e-12) || (fab[j] == 1 && vb[j] > 1e-12)) {
+							signs_ok = false;
+							fab[j] = 0;
+							vb[j] = 0.0;
+						}
+						vmax = fmax(vmax, fabs(vb[j]));
+					}
+					vmax = gmax<G>(vmax);
+					if (gand<G>(signs_ok ? 1 : 0)) {
+						fk = fk && (vmax > 1e-7);
+#pragma unroll
+						for (int j = 0; j < NV; j++) {
+							const double gj = gsum<G>(atv[j]) + Ab[j] * vb[j];
+							fk = fk && !(fabs(gj) > 1e-9 * vmax);
+						}
+						cert = gand<G>(fk ? 1 : 0) != 0;
+						break;
+					}
+				}
+				if (cert) { verdict = 2; break; }
 			}
+			if (gand<G>(changed ? 0 : 1)) break; // nothing to correct: leave it to ADMM
+#pragma unroll
+			for (int r = 0; r < RPL; r++) act[r] = nact[r];
 #pragma unroll
 			for (int j = 0; j < NV; j++) {
-				nub[j] += actb[j] ? (Ab[j] * rhs[j] - e2b[j]) * idelta : 0.0;
-				xp[j] += rhs[j];
+				actb[j] = nactb[j];
+				rtb[j] = actb[j] == 1 ? ubs[j] : lbs[j];
 			}
 		}
-		// validate against the KKT conditions of the FULL problem
-		double g[NV];
-#pragma unroll
-		for (int j = 0; j < NV; j++) g[j] = 0.0;
-#pragma unroll
-		for (int r = 0; r < RPL; r++) {
-			double ax = 0.0;
-#pragma unroll
-			for (int j = 0; j < NV; j++) ax += A[r][j] * xp[j];
-			const double tol = kPolishKktTol * (1.0 + fabs(ax));
-			ok = ok && !(ax < l[r] - tol) && !(eqr[r] && ax > l[r] + tol);
-			const double nt = kPolishKktTol * (1.0 + fabs(nu[r]));
-			ok = ok && !(act[r] == -1 && nu[r] > nt);
-#pragma unroll
-			for (int j = 0; j < NV; j++) g[j] += act[r] ? A[r][j] * nu[r] : 0.0;
-		}
-		double sres = 0.0;
-#pragma unroll
-		for (int j = 0; j < NV; j++) {
-			const double ax = Ab[j] * xp[j];
-			const double tol = kPolishKktTol * (1.0 + fabs(ax));
-			ok = ok && !(ax < lbs[j] - tol || ax > ubs[j] + tol);
-			const double nt = kPolishKktTol * (1.0 + fabs(nub[j]));
-			ok = ok && !(actb[j] == -1 && nub[j] > nt) && !(actb[j] == 1 && nub[j] < -nt);
-			const double gj = gsum<G>(g[j]) + P[j] * xp[j] + q[j] + (actb[j] ? Ab[j] * nub[j] : 0.0);
-			sres = fmax(sres, fabs(gj));
-		}
-		ok = ok && (sres <= kPolishStatTol);
-		return gand<G>(ok ? 1 : 0) != 0;
+		return verdict;
 	}
 
 	// Cold-start solve.  `status` follows QPWrapperOsqp::solve() (src/qpwrapper_osqp.cpp:225-238):
@@ -436,135 +574,150 @@ struct AdmmSmall {
 			it += K;
 			const bool last = it >= S_.max_iter;
 
-			// ---- residual norms, unscaled (termination) and scaled (rho estimate)
-			double aty[NV], pri = 0.0, nz = 0.0, nax = 0.0, pri_s = 0.0, nz_s = 0.0, nax_s = 0.0;
-#pragma unroll
-			for (int j = 0; j < NV; j++) aty[j] = 0.0;
-#pragma unroll
-			for (int r = 0; r < RPL; r++) {
-				double ax = 0.0;
-#pragma unroll
-				for (int j = 0; j < NV; j++) {
-					ax += A[r][j] * x[j];
-					aty[j] += A[r][j] * y[r];
-				}
-				const double ei = pow2_inv(E[r]);
-				pri = fmax(pri, fabs(ei * (ax - z[r])));
-				nz = fmax(nz, fabs(ei * z[r]));
-				nax = fmax(nax, fabs(ei * ax));
-				pri_s = fmax(pri_s, fabs(ax - z[r]));
-				nz_s = fmax(nz_s, fabs(z[r]));
-				nax_s = fmax(nax_s, fabs(ax));
-			}
-			double dua = 0.0, nq = 0.0, naty = 0.0, npx = 0.0, dua_s = 0.0, nq_s = 0.0, naty_s = 0.0, npx_s = 0.0;
-#pragma unroll
-			for (int j = 0; j < NV; j++) {
-				const double ax = Ab[j] * x[j];
-				const double ei = pow2_inv(Eb[j]);
-				pri = fmax(pri, fabs(ei * (ax - zb[j])));
-				nz = fmax(nz, fabs(ei * zb[j]));
-				nax = fmax(nax, fabs(ei * ax));
-				pri_s = fmax(pri_s, fabs(ax - zb[j]));
-				nz_s = fmax(nz_s, fabs(zb[j]));
-				nax_s = fmax(nax_s, fabs(ax));
-				const double at = gsum<G>(aty[j]) + Ab[j] * yb[j];
-				const double px = P[j] * x[j];
-				const double di = pow2_inv(D[j]);
-				const double rd = px + q[j] + at;
-				dua = fmax(dua, fabs(di * rd));
-				nq = fmax(nq, fabs(di * q[j]));
-				naty = fmax(naty, fabs(di * at));
-				npx = fmax(npx, fabs(di * px));
-				dua_s = fmax(dua_s, fabs(rd));
-				nq_s = fmax(nq_s, fabs(q[j]));
-				naty_s = fmax(naty_s, fabs(at));
-				npx_s = fmax(npx_s, fabs(px));
-			}
-			pri = gmax<G>(pri); nz = gmax<G>(nz); nax = gmax<G>(nax);
-			pri_s = gmax<G>(pri_s); nz_s = gmax<G>(nz_s); nax_s = gmax<G>(nax_s);
-			dua *= cinv;
-
 			int st = 0;
 			double xs[NV]; // candidate solution, scaled
 #pragma unroll
 			for (int j = 0; j < NV; j++) xs[j] = x[j];
 			if (S_.polish) {
 				double xp[NV];
-				if (polish(xp)) {
+				const int v = finish(xp, S_.active_set_rounds, S_.refine_steps);
+				if (v == 1) {
 					st = kStatusSolved;
 #pragma unroll
 					for (int j = 0; j < NV; j++) xs[j] = xp[j];
+				} else if (v == 2) {
+					st = kStatusPrimalInf;
 				}
 			}
-			// ---- primal-infeasibility certificate from the last delta_y (projected on the polar cone)
-			double ndy = 0.0, lhs = 0.0, atdy[NV];
+			// The residual tests below are only needed by lanes the finish left undecided
+			// (wave-uniform branch: the block contains group reductions).
+			if (__any(st == 0 && status == 0)) {
+				// ---- residual norms, unscaled (termination) and scaled (rho estimate)
+				double aty[NV], pri = 0.0, nz = 0.0, nax = 0.0, pri_s = 0.0, nz_s = 0.0, nax_s = 0.0;
 #pragma unroll
-			for (int j = 0; j < NV; j++) atdy[j] = 0.0;
+				for (int j = 0; j < NV; j++) aty[j] = 0.0;
 #pragma unroll
-			for (int r = 0; r < RPL; r++) {
-				const double v = eqr[r] ? dy[r] : fmin(dy[r], 0.0);
-				ndy = fmax(ndy, fabs(E[r] * v));
-				lhs += l[r] * v;
+				for (int r = 0; r < RPL; r++) {
+					double ax = 0.0;
 #pragma unroll
-				for (int j = 0; j < NV; j++) atdy[j] += A[r][j] * v;
-			}
-			ndy = gmax<G>(ndy);
-			lhs = gsum<G>(lhs);
-			double natdy = 0.0;
-			{
-				double vb[NV];
+					for (int j = 0; j < NV; j++) {
+						ax += A[r][j] * x[j];
+						aty[j] += A[r][j] * y[r];
+					}
+					const double ei = pow2_inv(E[r]);
+					pri = fmax(pri, fabs(ei * (ax - z[r])));
+					nz = fmax(nz, fabs(ei * z[r]));
+					nax = fmax(nax, fabs(ei * ax));
+					pri_s = fmax(pri_s, fabs(ax - z[r]));
+					nz_s = fmax(nz_s, fabs(z[r]));
+					nax_s = fmax(nax_s, fabs(ax));
+				}
+				double dua = 0.0, nq = 0.0, naty = 0.0, npx = 0.0, dua_s = 0.0, nq_s = 0.0, naty_s = 0.0, npx_s = 0.0;
 #pragma unroll
 				for (int j = 0; j < NV; j++) {
-					double v = dyb[j];
-					if (ubs[j] > kInfty * kMinScaling) v = (lbs[j] < -kInfty * kMinScaling) ? 0.0 : fmin(v, 0.0);
-					else if (lbs[j] < -kInfty * kMinScaling) v = fmax(v, 0.0);
-					vb[j] = v;
-					ndy = fmax(ndy, fabs(Eb[j] * v));
-					lhs += ubs[j] * fmax(v, 0.0) + lbs[j] * fmin(v, 0.0);
+					const double ax = Ab[j] * x[j];
+					const double ei = pow2_inv(Eb[j]);
+					pri = fmax(pri, fabs(ei * (ax - zb[j])));
+					nz = fmax(nz, fabs(ei * zb[j]));
+					nax = fmax(nax, fabs(ei * ax));
+					pri_s = fmax(pri_s, fabs(ax - zb[j]));
+					nz_s = fmax(nz_s, fabs(zb[j]));
+					nax_s = fmax(nax_s, fabs(ax));
+					const double at = gsum<G>(aty[j]) + Ab[j] * yb[j];
+					const double px = P[j] * x[j];
+					const double di = pow2_inv(D[j]);
+					const double rd = px + q[j] + at;
+					dua = fmax(dua, fabs(di * rd));
+					nq = fmax(nq, fabs(di * q[j]));
+					naty = fmax(naty, fabs(di * at));
+					npx = fmax(npx, fabs(di * px));
+					dua_s = fmax(dua_s, fabs(rd));
+					nq_s = fmax(nq_s, fabs(q[j]));
+					naty_s = fmax(naty_s, fabs(at));
+					npx_s = fmax(npx_s, fabs(px));
 				}
+				pri = gmax<G>(pri); nz = gmax<G>(nz); nax = gmax<G>(nax);
+				pri_s = gmax<G>(pri_s); nz_s = gmax<G>(nz_s); nax_s = gmax<G>(nax_s);
+				dua *= cinv;
+				// ---- primal-infeasibility certificate from the last delta_y (projected on the polar cone)
+				double ndy = 0.0, lhs = 0.0, atdy[NV];
 #pragma unroll
-				for (int j = 0; j < NV; j++) {
-					const double t = (gsum<G>(atdy[j]) + Ab[j] * vb[j]) * pow2_inv(D[j]);
-					natdy = fmax(natdy, fabs(t));
+				for (int j = 0; j < NV; j++) atdy[j] = 0.0;
+#pragma unroll
+				for (int r = 0; r < RPL; r++) {
+					const double v = eqr[r] ? dy[r] : fmin(dy[r], 0.0);
+					ndy = fmax(ndy, fabs(E[r] * v));
+					lhs += l[r] * v;
+#pragma unroll
+					for (int j = 0; j < NV; j++) atdy[j] += A[r][j] * v;
 				}
-			}
-			// ---- dual-infeasibility certificate pieces (delta_x)
-			double ndx = 0.0, qdx = 0.0, npdx = 0.0;
+				ndy = gmax<G>(ndy);
+				lhs = gsum<G>(lhs);
+				double natdy = 0.0;
+				{
+					double vb[NV];
 #pragma unroll
-			for (int j = 0; j < NV; j++) {
-				ndx = fmax(ndx, fabs(D[j] * dx[j]));
-				qdx += q[j] * dx[j];
-				npdx = fmax(npdx, fabs(P[j] * dx[j] * pow2_inv(D[j])));
-			}
-#pragma unroll 1
-			for (int approx = 0; approx <= (last ? 1 : 0); approx++) {
-				if (st) break;
-				const double k = approx ? 10.0 : 1.0;
-				const double ea = k * S_.eps_abs, er = k * S_.eps_rel;
-				const double epi = k * S_.eps_prim_inf, edi = k * S_.eps_dual_inf;
-				const double eps_pri = ea + er * fmax(nz, nax);
-				const double eps_dua = ea + er * cinv * fmax(nq, fmax(naty, npx));
-				const bool prim_ok = pri < eps_pri, dual_ok = dua < eps_dua;
-				if (prim_ok && dual_ok) st = approx ? kStatusSolvedInaccurate : kStatusSolved;
-				else if (!prim_ok && ndy > epi && lhs < -epi * ndy && natdy < epi * ndy)
-					st = approx ? kStatusPrimalInfInaccurate : kStatusPrimalInf;
-				else if (!dual_ok && ndx > edi && qdx < -cs * edi * ndx && npdx < cs * edi * ndx) {
-					bool cone = true;
-#pragma unroll
-					for (int r = 0; r < RPL; r++) {
-						double a = 0.0;
-#pragma unroll
-						for (int j = 0; j < NV; j++) a += A[r][j] * dx[j];
-						a *= pow2_inv(E[r]);
-						cone = cone && !((eqr[r] && a > edi * ndx) || a < -edi * ndx);
+					for (int j = 0; j < NV; j++) {
+						double v = dyb[j];
+						if (ubs[j] > kInfty * kMinScaling) v = (lbs[j] < -kInfty * kMinScaling) ? 0.0 : fmin(v, 0.0);
+						else if (lbs[j] < -kInfty * kMinScaling) v = fmax(v, 0.0);
+						vb[j] = v;
+						ndy = fmax(ndy, fabs(Eb[j] * v));
+						lhs += ubs[j] * fmax(v, 0.0) + lbs[j] * fmin(v, 0.0);
 					}
 #pragma unroll
 					for (int j = 0; j < NV; j++) {
-						const double a = Ab[j] * dx[j] * pow2_inv(Eb[j]);
-						cone = cone && !((ubs[j] < kInfty * kMinScaling && a > edi * ndx) ||
-						                 (lbs[j] > -kInfty * kMinScaling && a < -edi * ndx));
+						const double t = (gsum<G>(atdy[j]) + Ab[j] * vb[j]) * pow2_inv(D[j]);
+						natdy = fmax(natdy, fabs(t));
 					}
-					if (gand<G>(cone ? 1 : 0)) st = approx ? kStatusDualInfInaccurate : kStatusDualInf;
+				}
+				// ---- dual-infeasibility certificate pieces (delta_x)
+				double ndx = 0.0, qdx = 0.0, npdx = 0.0;
+#pragma unroll
+				for (int j = 0; j < NV; j++) {
+					ndx = fmax(ndx, fabs(D[j] * dx[j]));
+					qdx += q[j] * dx[j];
+					npdx = fmax(npdx, fabs(P[j] * dx[j] * pow2_inv(D[j])));
+				}
+#pragma unroll 1
+				for (int approx = 0; approx <= (last ? 1 : 0); approx++) {
+					if (st) break;
+					const double k = approx ? 10.0 : 1.0;
+					const double ea = k * S_.eps_abs, er = k * S_.eps_rel;
+					const double epi = k * S_.eps_prim_inf, edi = k * S_.eps_dual_inf;
+					const double eps_pri = ea + er * fmax(nz, nax);
+					const double eps_dua = ea + er * cinv * fmax(nq, fmax(naty, npx));
+					const bool prim_ok = pri < eps_pri, dual_ok = dua < eps_dua;
+					if (prim_ok && dual_ok) st = approx ? kStatusSolvedInaccurate : kStatusSolved;
+					else if (!prim_ok && ndy > epi && lhs < -epi * ndy && natdy < epi * ndy)
+						st = approx ? kStatusPrimalInfInaccurate : kStatusPrimalInf;
+					else if (!dual_ok && ndx > edi && qdx < -cs * edi * ndx && npdx < cs * edi * ndx) {
+						bool cone = true;
+#pragma unroll
+						for (int r = 0; r < RPL; r++) {
+							double a = 0.0;
+#pragma unroll
+							for (int j = 0; j < NV; j++) a += A[r][j] * dx[j];
+							a *= pow2_inv(E[r]);
+							cone = cone && !((eqr[r] && a > edi * ndx) || a < -edi * ndx);
+						}
+#pragma unroll
+						for (int j = 0; j < NV; j++) {
+							const double a = Ab[j] * dx[j] * pow2_inv(Eb[j]);
+							cone = cone && !((ubs[j] < kInfty * kMinScaling && a > edi * ndx) ||
+							                 (lbs[j] > -kInfty * kMinScaling && a < -edi * ndx));
+						}
+						if (gand<G>(cone ? 1 : 0)) st = approx ? kStatusDualInfInaccurate : kStatusDualInf;
+					}
+				}
+				// ---- rho adaptation (OSQP's estimate on the scaled residuals); lane-local refactor
+				if (S_.adaptive_rho && !last) {
+					const double pr = pri_s / (fmax(nz_s, nax_s) + 1e-10);
+					const double dr = dua_s / (fmax(nq_s, fmax(naty_s, npx_s)) + 1e-10);
+					double rn = rho * sqrt(pr / (dr + 1e-10));
+					rn = fmin(fmax(rn, kRhoMin), kRhoMax);
+					if (rn > rho * S_.adaptive_rho_tolerance || rn < rho / S_.adaptive_rho_tolerance)
+						fact_ok = set_rho_and_factor(rn, S_.sigma) && fact_ok;
 				}
 			}
 			if (!st && (last || !fact_ok)) st = kStatusMaxIter;
@@ -573,15 +726,6 @@ struct AdmmSmall {
 				iters = it;
 #pragma unroll
 				for (int j = 0; j < NV; j++) xout[j] = D[j] * xs[j];
-			}
-			// ---- rho adaptation (OSQP's estimate on the scaled residuals); lane-local refactor
-			if (S_.adaptive_rho && !last) {
-				const double pr = pri_s / (fmax(nz_s, nax_s) + 1e-10);
-				const double dr = dua_s / (fmax(nq_s, fmax(naty_s, npx_s)) + 1e-10);
-				double rn = rho * sqrt(pr / (dr + 1e-10));
-				rn = fmin(fmax(rn, kRhoMin), kRhoMax);
-				if (rn > rho * S_.adaptive_rho_tolerance || rn < rho / S_.adaptive_rho_tolerance)
-					fact_ok = set_rho_and_factor(rn, S_.sigma) && fact_ok;
 			}
 		}
 		if (status == 0) { // max_iter == 0

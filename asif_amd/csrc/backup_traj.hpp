@@ -1,0 +1,129 @@
+// backup_traj.hpp -- the backup closed loop and its sensitivity, shared by the implicit and TB filters.
+//
+// Restates, for one instance per lane and nu == 1:
+//   inputSaturateSoft   src/asif_implicit.cpp:682-737  (== src/asif_implicit_tb.cpp:764-819)
+//   backupCLdynamics    src/asif_implicit.cpp:751-815  (separate dynamics/dynamicsGradients branch)
+//   ODErhs              src/asif_implicit.cpp:817-827  z = [x; vec Q], zdot = [fCL; DfCL Q]
+// plus a register-resident running selection of the K smallest safety margins along the trajectory,
+// which replaces the reference's full trajectory storage (5001 x 18 doubles on the stack,
+// src/asif_implicit.cpp:441-443) and its std::sort of every sample (:487).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "models.hpp"
+
+namespace asif {
+
+template <class M>
+struct BackupLoop {
+	static constexpr int NX = M::NX, NZ = NX + NX * NX;
+	static_assert(M::NU == 1, "backup loop is written for single-input models (every shipped example)");
+
+	// bevelled smooth saturation of the backup input; DuSat is d uSat / d u in the reference's own
+	// (normalised-arc) convention -- reproduced literally
+	__device__ __forceinline__ static void saturateSoft(const DevOptions &o, double u, double &uSat, double &DuSat)
+	{
+		const double r = o.satSharpness;
+		const double mi = o.lb[0], ma = o.ub[0];
+		const double range = ma - mi;
+		const double middle = (ma + mi) / 2;
+		const double uc = 2 * (u - middle) / range;
+		const double xc = o.bevelStop;
+		const double yc = 1 - r;
+		uSat = u;
+		DuSat = 1;
+		if (uc >= o.bevelStop) {
+			uSat = ma;
+			DuSat = 0;
+		} else if (uc <= -o.bevelStop) {
+			uSat = mi;
+			DuSat = 0;
+		} else if (uc > o.bevelStart) {
+			const double s = sqrt(r * r - (uc - xc) * (uc - xc));
+			DuSat = (xc - uc) / s;
+			uSat = 0.5 * (s + yc) * range + middle;
+		} else if (uc < -o.bevelStart) {
+			const double s = sqrt(r * r - (uc + xc) * (uc + xc));
+			DuSat = (xc + uc) / s;
+			uSat = 0.5 * (-s - yc) * range + middle;
+		}
+	}
+
+	__device__ __forceinline__ static void closedLoop(const DevOptions &o, const double (&x)[NX], double (&fCL)[NX],
+	                                                  double (&DfCL)[NX * NX])
+	{
+		double f[NX], g[NX], Df[NX * NX], Dg[NX * NX], u[1], Du[NX], uSat, DuSat;
+		M::backupController(o, x, u, Du);
+		saturateSoft(o, u[0], uSat, DuSat);
+		M::dynamicsAndGradients(o, x, f, g, Df, Dg);
+#pragma unroll
+		for (int i = 0; i < NX; i++) {
+#pragma unroll
+			for (int j = 0; j < NX; j++)
+				DfCL[i + j * NX] = Df[i + j * NX] + (Dg[i + j * NX] * uSat + g[i] * DuSat * Du[j]);
+			fCL[i] = g[i] * uSat + f[i];
+		}
+	}
+
+	// one forward-Euler step of [x; vec Q] (src/asif_implicit.cpp:470-477: rhs*dt + previous)
+	__device__ __forceinline__ static void eulerStep(const DevOptions &o, double (&z)[NZ])
+	{
+		double x[NX], fCL[NX], DfCL[NX * NX], zd[NZ];
+#pragma unroll
+		for (int i = 0; i < NX; i++) x[i] = z[i];
+		closedLoop(o, x, fCL, DfCL);
+#pragma unroll
+		for (int i = 0; i < NX; i++) zd[i] = fCL[i];
+#pragma unroll
+		for (int i = 0; i < NX; i++)
+#pragma unroll
+			for (int j = 0; j < NX; j++) {
+				double s = 0.0;
+#pragma unroll
+				for (int k = 0; k < NX; k++) s += DfCL[i + k * NX] * z[NX + k + j * NX];
+				zd[NX + i + j * NX] = s;
+			}
+#pragma unroll
+		for (int k = 0; k < NZ; k++) z[k] = zd[k] * o.trajDt + z[k];
+	}
+};
+
+// The K smallest keys seen so far, ascending, ties -> earlier sample first (this build's fixed
+// tie rule; the reference's std::sort leaves it implementation-defined).
+// Each entry owns a payload slot in LDS; insert() returns the slot the caller must overwrite, or -1.
+template <int K>
+struct TopK {
+	double key[K];
+	int idx[K], slot[K];
+	__device__ __forceinline__ void init()
+	{
+#pragma unroll
+		for (int p = 0; p < K; p++) {
+			key[p] = __builtin_huge_val();
+			idx[p] = -1;
+			slot[p] = p;
+		}
+	}
+	__device__ __forceinline__ int insert(double kv, int iv)
+	{
+		if (!(kv < key[K - 1])) return -1;
+		const int s = slot[K - 1];
+		int pos = 0;
+#pragma unroll
+		for (int p = 0; p < K - 1; p++) pos += (key[p] <= kv) ? 1 : 0;
+#pragma unroll
+		for (int p = K - 1; p >= 1; p--) {
+			const bool shift = p > pos, here = p == pos;
+			key[p] = here ? kv : (shift ? key[p - 1] : key[p]);
+			idx[p] = here ? iv : (shift ? idx[p - 1] : idx[p]);
+			slot[p] = here ? s : (shift ? slot[p - 1] : slot[p]);
+		}
+		if (pos == 0) {
+			key[0] = kv;
+			idx[0] = iv;
+			slot[0] = s;
+		}
+		return s;
+	}
+};
+
+} // namespace asif

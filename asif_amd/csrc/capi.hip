@@ -20,6 +20,11 @@ struct asif_hip_ctx {
 	double *d_in, *d_out;
 	int32_t *d_rc;
 	int64_t cap;
+	// rows staged between the trajectory kernel and the QP kernel (implicit / TB / robust)
+	double *s_rows;
+	int64_t s_cap;
+	int32_t *s_code;
+	int64_t s_code_cap;
 };
 
 extern "C" int asif_hip_version(void) { return ASIF_HIP_VERSION; }
@@ -116,15 +121,18 @@ extern "C" int asif_hip_default_solver(asif_hip_solver *s)
 	s->eps_dual_inf = 1e-4;
 	s->adaptive_rho_tolerance = 5.0;
 	s->max_iter = 4000;
-	s->check_interval = 10;
+	s->check_interval = 5;
 	s->scaling_iters = 4;
 	s->polish = 1;
+	s->active_set_rounds = 12;
+	s->refine_steps = 2;
 	s->adaptive_rho = 1;
 	s->lanes_per_qp = 0;
 	return ASIF_HIP_OK;
 }
 
-static int model_dims(int model, int variant, const asif_hip_options &o, asif_hip_dims &d, DevOptions &dev)
+static int model_dims(int model, int variant, const asif_hip_options &o, asif_hip_dims &d, DevOptions &dev,
+                      bool after_update = false)
 {
 	std::memset(&d, 0, sizeof(d));
 	std::memset(&dev, 0, sizeof(dev));
@@ -157,6 +165,46 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 		d.nc = d.npSS;    // src/asif.cpp:21-22 (npSSmax = -1 clamps to npSS)
 		d.nrelax = 1;
 		d.ndiag = 1;
+		return ASIF_HIP_OK;
+	}
+	if (model == ASIF_HIP_MODEL_INVERTED_PENDULUM && variant == ASIF_HIP_IMPLICIT) {
+		d.nx = 2; d.nu = 1; d.npSS = 4; d.npBS = 1;
+		d.npBTSS = 10;                          // examples/InvertedPendulum_Implicit.cpp:17
+		d.nv = d.nu + 2;                        // src/asif_implicit.cpp:125
+		d.nc = d.npBTSS * d.npSS + d.npBS;      // src/asif_implicit.cpp:129
+		d.nrelax = 2;
+		// src/asif_implicit.cpp:211-216
+		double dt = o.backTrajDt;
+		int npBT = (int)(std::round(o.backTrajHorizon / dt) + 1);
+		if (npBT < d.npBTSS) {
+			npBT = d.npBTSS;
+			dt = o.backTrajHorizon / (double)(npBT - 1);
+		}
+		d.npBT = npBT;
+		dev.npBT = npBT;
+		dev.trajDt = dt;
+		d.ndiag = d.npBTSS + 1;                 // critical sample indexes, ADMM iterations
+		return ASIF_HIP_OK;
+	}
+	if (model == ASIF_HIP_MODEL_SEGWAY && variant == ASIF_HIP_IMPLICIT_TB) {
+		d.nx = 4; d.nu = 1; d.npSS = 4; d.npBS = 1;
+		d.npBTSS = 4;                           // examples/segway_implicit_tb.cpp:16
+		d.nv = d.nu + 1;                        // src/asif_implicit_tb.cpp:122
+		d.nc = d.npBTSS * d.npSS + 2;           // src/asif_implicit_tb.cpp:125
+		d.nrelax = 1;
+		// initialize() stretches the horizon by (1+backTrajExtend) (src/asif_implicit_tb.cpp:177-182);
+		// updateOptions() does not (:377-382) -- preserved
+		const double T = after_update ? o.backTrajHorizon : o.backTrajHorizon * (1.0 + o.backTrajExtend);
+		double dt = o.backTrajDt;
+		int npBT = (int)(std::round(T / dt) + 1);
+		if (npBT < d.npBTSS) {
+			npBT = d.npBTSS;
+			dt = T / (double)(npBT - 1);
+		}
+		d.npBT = npBT;
+		dev.npBT = npBT;
+		dev.trajDt = dt;
+		d.ndiag = 3 + d.npBTSS + 1;             // TTS_, BTorthoBS_, idxHit, critical samples, ADMM iterations
 		return ASIF_HIP_OK;
 	}
 	return ASIF_HIP_EINVAL;
@@ -200,6 +248,10 @@ extern "C" int asif_hip_create(asif_hip_ctx **out, int model, int variant, const
 	c->d_in = c->d_out = nullptr;
 	c->d_rc = nullptr;
 	c->cap = 0;
+	c->s_rows = nullptr;
+	c->s_cap = 0;
+	c->s_code = nullptr;
+	c->s_code_cap = 0;
 	*out = c;
 	return ASIF_HIP_OK;
 }
@@ -207,6 +259,14 @@ extern "C" int asif_hip_create(asif_hip_ctx **out, int model, int variant, const
 extern "C" int asif_hip_destroy(asif_hip_ctx *ctx)
 {
 	if (!ctx) return ASIF_HIP_EINVAL;
+	if (ctx->s_rows) {
+		(void)hipSetDevice(ctx->device);
+		(void)hipFree(ctx->s_rows);
+	}
+	if (ctx->s_code) {
+		(void)hipSetDevice(ctx->device);
+		(void)hipFree(ctx->s_code);
+	}
 	if (ctx->d_in) {
 		(void)hipSetDevice(ctx->device);
 		(void)hipFree(ctx->d_in);
@@ -229,7 +289,7 @@ extern "C" int asif_hip_update_options(asif_hip_ctx *ctx, const asif_hip_options
 	if (!ctx || !opts) return ASIF_HIP_EINVAL;
 	asif_hip_dims d;
 	DevOptions dev;
-	int r = model_dims(ctx->model, ctx->variant, *opts, d, dev);
+	int r = model_dims(ctx->model, ctx->variant, *opts, d, dev, true);
 	if (r) return r;
 	ctx->opts = *opts;
 	ctx->dims = d;
@@ -237,10 +297,51 @@ extern "C" int asif_hip_update_options(asif_hip_ctx *ctx, const asif_hip_options
 	return ASIF_HIP_OK;
 }
 
-static int run_filter(asif_hip_ctx *ctx, const FilterArgs &a, bool assemble_only, hipStream_t stream)
+// Two-stage variants park their rows in a per-handle staging buffer, grown on demand (the only
+// allocation a filter call can make; size it once with a first call before capturing a graph).
+static int stage_rows(asif_hip_ctx *ctx, FilterArgs &a)
+{
+	const int64_t need = (int64_t)(ctx->dims.nc * ctx->dims.nv + ctx->dims.nc) * a.ld;
+	if (need > ctx->s_cap) {
+		if (ctx->s_rows) (void)hipFree(ctx->s_rows);
+		ctx->s_rows = nullptr;
+		ctx->s_cap = 0;
+		hipError_t e = hipMalloc((void **)&ctx->s_rows, sizeof(double) * need);
+		if (e != hipSuccess) return (int)e;
+		ctx->s_cap = need;
+	}
+	if (a.B > ctx->s_code_cap) {
+		if (ctx->s_code) (void)hipFree(ctx->s_code);
+		ctx->s_code = nullptr;
+		ctx->s_code_cap = 0;
+		hipError_t e = hipMalloc((void **)&ctx->s_code, sizeof(int32_t) * a.B);
+		if (e != hipSuccess) return (int)e;
+		ctx->s_code_cap = a.B;
+	}
+	a.A = ctx->s_rows;
+	a.b = ctx->s_rows + (int64_t)ctx->dims.nc * ctx->dims.nv * a.ld;
+	a.code = ctx->s_code;
+	return 0;
+}
+
+static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipStream_t stream)
 {
 	if (ctx->model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR && ctx->variant == ASIF_HIP_EXPLICIT)
 		return launch_explicit_di(ctx->dev, ctx->solver, a, assemble_only, stream);
+	if (ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM && ctx->variant == ASIF_HIP_IMPLICIT) {
+		if (!assemble_only) {
+			int r = stage_rows(ctx, a);
+			if (r) return r;
+		}
+		return launch_implicit_ip(ctx->dev, ctx->solver, a, assemble_only, stream);
+	}
+	if (ctx->model == ASIF_HIP_MODEL_SEGWAY && ctx->variant == ASIF_HIP_IMPLICIT_TB) {
+		if (!assemble_only) {
+			int r = stage_rows(ctx, a);
+			if (r) return r;
+		}
+		return launch_tb_segway(ctx->dev, ctx->solver, a, assemble_only, stream);
+	}
 	return ASIF_HIP_EINVAL;
 }
 

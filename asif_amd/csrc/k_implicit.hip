@@ -1,0 +1,182 @@
+// k_implicit.hip -- implicit (backup-trajectory) filter: ASIFimplicit::filter, src/asif_implicit.cpp:305-356.
+//
+// Stage 1  implicit_rows_kernel: ASIFimplicit::updateConstraints (:403-651), one instance per lane.
+//   Forward-Euler integration of the backup closed loop with its sensitivity Q = d phi_t / d x0
+//   (:461-484), the safety margin sampled at every point, the npBTSS most critical samples kept by a
+//   running selection (their states parked in LDS, lane-contiguous -> bank-conflict free) instead of
+//   the reference's stored trajectory + full sort (:441-443,487), then the rows
+//     safe row  (k,i): [ Dh_i(x_k) Q_k g | h_i(x_k) | 0 ],  b = -Dh_i(x_k) Q_k f      (:517-540,564-611)
+//     backup row     : [ Dh_B(x_T) Q_T g | 0 | h_B(x_T) ],  b = -Dh_B(x_T) Q_T f      (:542-554)
+//   written SoA to HBM (the same layout asif_hip_assemble_batch hands out).
+// Stage 2  qp_policy_kernel<3,41,G>: cost/bounds of initialize()/updateCost() (:237-254,653-664),
+//   in-register ADMM, then the epilogue of filter(): inputSaturate + relax on success (:338-347),
+//   saturated backup controller and rc = -1 on failure (:348-355).
+// The 5000-step trajectory is ~99 % of the work and is inherently sequential per instance; the solve
+// is re-dealt G lanes per QP so the second launch fills the whole chip.
+#include "backup_traj.hpp"
+#include "qp_kernel.hpp"
+
+namespace asif {
+
+template <class M>
+__global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterArgs a)
+{
+	constexpr int NX = M::NX, NP = M::NPSS, K = M::NPBTSS, NB = M::NPBS, NZ = NX + NX * NX;
+	constexpr int NC = K * NP + NB;
+	static_assert(NB == 1, "one backup-set function");
+	__shared__ double pay[K * NZ * 64];
+	const int lane = threadIdx.x;
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const bool live = i < a.B;
+	if (!live) i = a.B - 1;
+
+	double x0[NX], f0[NX], g0[NX];
+#pragma unroll
+	for (int k = 0; k < NX; k++) x0[k] = a.x[k * a.ld + i];
+	M::dynamics(o, x0, f0, g0); // :414
+
+	double z[NZ];
+#pragma unroll
+	for (int k = 0; k < NZ; k++) z[k] = 0.0;
+#pragma unroll
+	for (int k = 0; k < NX; k++) {
+		z[k] = x0[k];
+		z[NX + k * (NX + 1)] = 1.0; // Q(0) = I, :417-425
+	}
+	TopK<K> top;
+	top.init();
+#pragma unroll 1
+	for (int s = 0; s < o.npBT; s++) {
+		if (s > 0) BackupLoop<M>::eulerStep(o, z);
+		double xs[NX];
+#pragma unroll
+		for (int k = 0; k < NX; k++) xs[k] = z[k];
+		const int slot = top.insert(M::safetyMin(o, xs), s);
+		if (slot >= 0) {
+#pragma unroll
+			for (int k = 0; k < NZ; k++) pay[(slot * NZ + k) * 64 + lane] = z[k];
+		}
+	}
+	if (!live) return;
+	const int64_t ld = a.ld;
+	// safe rows from the parked critical samples
+#pragma unroll 1
+	for (int k = 0; k < K; k++) {
+		double zk[NZ], xs[NX], h[NP], Dh[NP * NX];
+		const int slot = top.slot[k];
+#pragma unroll
+		for (int c = 0; c < NZ; c++) zk[c] = pay[(slot * NZ + c) * 64 + lane];
+#pragma unroll
+		for (int c = 0; c < NX; c++) xs[c] = zk[c];
+		M::safetySet(o, xs, h, Dh);
+#pragma unroll
+		for (int r = 0; r < NP; r++) {
+			double DhQ[NX];
+#pragma unroll
+			for (int j = 0; j < NX; j++) {
+				double s = 0.0;
+#pragma unroll
+				for (int c = 0; c < NX; c++) s += Dh[r + c * NP] * zk[NX + c + j * NX];
+				DhQ[j] = s;
+			}
+			double Lf = 0.0, Lg = 0.0;
+#pragma unroll
+			for (int j = 0; j < NX; j++) {
+				Lf += DhQ[j] * f0[j];
+				Lg += DhQ[j] * g0[j];
+			}
+			const int row = k * NP + r;
+			a.A[(int64_t)(row + 0 * NC) * ld + i] = Lg;
+			a.A[(int64_t)(row + 1 * NC) * ld + i] = h[r];
+			a.A[(int64_t)(row + 2 * NC) * ld + i] = 0.0;
+			a.b[(int64_t)row * ld + i] = -Lf;
+		}
+		if (a.diag) a.diag[(int64_t)k * ld + i] = (double)top.idx[k];
+	}
+	// backup-set row at the end of the trajectory
+	{
+		double xs[NX], hB, DhB[NX], DDh[NX * NX];
+#pragma unroll
+		for (int c = 0; c < NX; c++) xs[c] = z[c];
+		M::backupSet(o, xs, hB, DhB, DDh);
+		double Lf = 0.0, Lg = 0.0;
+#pragma unroll
+		for (int j = 0; j < NX; j++) {
+			double s = 0.0;
+#pragma unroll
+			for (int c = 0; c < NX; c++) s += DhB[c] * z[NX + c + j * NX];
+			Lf += s * f0[j];
+			Lg += s * g0[j];
+		}
+		const int row = K * NP;
+		a.A[(int64_t)(row + 0 * NC) * ld + i] = Lg;
+		a.A[(int64_t)(row + 1 * NC) * ld + i] = 0.0;
+		a.A[(int64_t)(row + 2 * NC) * ld + i] = hB;
+		a.b[(int64_t)row * ld + i] = -Lf;
+	}
+	if (a.code) a.code[i] = 1;
+}
+
+template <class M>
+struct ImplicitPolicy {
+	int64_t B;
+	DevOptions o;
+	FilterArgs a; // a.A / a.b = staged rows
+
+	template <int NV, int NC, int G>
+	__device__ __forceinline__ void load(int64_t i, int g, QpLaneData<NV, (NC + G - 1) / G> &qp) const
+	{
+		static_assert(NV == 3, "nu + 2 variables");
+		qp.Hd[0] = 1.0;
+		qp.Hd[1] = o.relaxCost;
+		qp.Hd[2] = o.relaxCost;
+		qp.c[0] = -2.0 * a.udes[i];
+		qp.c[1] = -2.0 * o.relaxCost * o.relaxLb;
+		qp.c[2] = -2.0 * o.relaxCost * o.relaxReachLb;
+		qp.lb[0] = o.lb[0];
+		qp.lb[1] = o.relaxLb;
+		qp.lb[2] = o.relaxReachLb;
+		qp.ub[0] = o.ub[0];
+		qp.ub[1] = o.inf;
+		qp.ub[2] = o.inf;
+		load_rows<NV, NC, G>(a.A, a.b, a.ld, i, g, 0ull, qp);
+	}
+	template <int NV>
+	__device__ __forceinline__ void store(int64_t i, const double (&sol)[NV], int st, int it) const
+	{
+		if (st == kStatusSolved) {
+			a.uact[i] = fmin(fmax(sol[0], o.lb[0]), o.ub[0]);
+			a.relax[i] = sol[1];
+			a.relax[a.ld + i] = sol[2];
+			a.rc[i] = ASIF_HIP_RC_OK;
+		} else {
+			double x[M::NX], u[1], Du[M::NX];
+#pragma unroll
+			for (int k = 0; k < M::NX; k++) x[k] = a.x[k * a.ld + i];
+			M::backupController(o, x, u, Du);
+			a.uact[i] = fmin(fmax(u[0], o.lb[0]), o.ub[0]);
+			a.rc[i] = ASIF_HIP_RC_QP_FAILED;
+		}
+		if (a.diag) a.diag[(int64_t)(a.ndiag - 1) * a.ld + i] = (double)it;
+	}
+};
+
+int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                       hipStream_t stream)
+{
+	using M = InvertedPendulum;
+	if (a.B <= 0) return 0;
+	hipLaunchKernelGGL((implicit_rows_kernel<M>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
+	int e = (int)hipGetLastError();
+	if (e || assemble_only) return e;
+	const ImplicitPolicy<M> p = {a.B, o, a};
+	switch (S.lanes_per_qp) {
+	case 0:
+	case 8: return launch_policy<3, 41, 8>(S, p, stream);
+	case 4: return launch_policy<3, 41, 4>(S, p, stream);
+	case 16: return launch_policy<3, 41, 16>(S, p, stream);
+	default: return ASIF_HIP_EINVAL;
+	}
+}
+
+} // namespace asif

@@ -2,89 +2,62 @@
 // initialize -> solve -> getSolution (include/qpwrapper_abstract.h:30-43; src/qpwrapper_osqp.cpp:55-261),
 // cold start, one QP per lane group, SoA in HBM (component-major, instance-minor) so that the G=1
 // mapping reads whole 512-byte lines per wave instruction.
-#include "admm_small.hpp"
-#include "launchers.hpp"
+#include "qp_kernel.hpp"
 
 namespace asif {
 
-template <int NV, int NC, int G>
-__global__ __launch_bounds__(64) void qp_small_kernel(asif_hip_solver S, QpArgs a)
-{
-	constexpr int RPL = (NC + G - 1) / G;
-	const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	const int g = (int)(tid % G);
-	int64_t i = tid / G;
-	const bool live = i < a.B;
-	if (!live) i = a.B - 1;
+struct GenericQpPolicy {
+	int64_t B, ld;
+	const double *Hd, *c, *A, *b, *lb, *ub;
+	uint64_t be_mask;
+	double *sol;
+	int32_t *status, *iters;
 
-	QpLaneData<NV, RPL> qp;
-#pragma unroll
-	for (int j = 0; j < NV; j++) {
-		qp.Hd[j] = a.Hd[j * a.ld + i];
-		qp.c[j] = a.c[j * a.ld + i];
-		qp.lb[j] = a.lb[j * a.ld + i];
-		qp.ub[j] = a.ub[j * a.ld + i];
-	}
-#pragma unroll
-	for (int k = 0; k < RPL; k++) {
-		const int r = g + k * G;
-		const bool valid = r < NC;
-		const int rr = valid ? r : 0;
+	template <int NV, int NC, int G>
+	__device__ __forceinline__ void load(int64_t i, int g, QpLaneData<NV, (NC + G - 1) / G> &qp) const
+	{
 #pragma unroll
 		for (int j = 0; j < NV; j++) {
-			const double v = a.A[(int64_t)(rr + j * NC) * a.ld + i];
-			qp.A[k][j] = valid ? v : 0.0;
+			qp.Hd[j] = Hd[j * ld + i];
+			qp.c[j] = c[j * ld + i];
+			qp.lb[j] = lb[j * ld + i];
+			qp.ub[j] = ub[j * ld + i];
 		}
-		const double bv = a.b[(int64_t)rr * a.ld + i];
-		qp.b[k] = valid ? bv : -1e20;
-		qp.eq[k] = valid && ((a.be_mask >> rr) & 1ull);
+		load_rows<NV, NC, G>(A, b, ld, i, g, be_mask, qp);
 	}
-	AdmmSmall<NV, RPL, G> admm;
-	double sol[NV];
-	int status, iters;
-	admm.solve(qp, S, sol, status, iters);
-	if (live && g == 0) {
+	template <int NV>
+	__device__ __forceinline__ void store(int64_t i, const double (&x)[NV], int st, int it) const
+	{
 #pragma unroll
-		for (int j = 0; j < NV; j++) a.sol[j * a.ld + i] = sol[j];
-		a.status[i] = status;
-		if (a.iters) a.iters[i] = iters;
+		for (int j = 0; j < NV; j++) sol[j * ld + i] = x[j];
+		status[i] = st;
+		if (iters) iters[i] = it;
 	}
-}
-
-template <int NV, int NC, int G>
-static int launch(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
-{
-	const int block = 64;
-	hipLaunchKernelGGL((qp_small_kernel<NV, NC, G>), dim3(grid_for(a.B, G, block)), dim3(block), 0, stream, S, a);
-	return (int)hipGetLastError();
-}
+};
 
 int launch_qp_small(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
 {
 	if (a.B <= 0) return 0;
+	const GenericQpPolicy p = {a.B, a.ld, a.Hd, a.c, a.A, a.b, a.lb, a.ub, a.be_mask, a.sol, a.status, a.iters};
 	const int G = S.lanes_per_qp;
-	// shapes of the four filter classes at the configs' sizes (C2 2x4, C3 3x41, C4 2x18)
+	// shapes of the filter classes at the configs' sizes (C2 2x4, C3 3x41, C4 2x18)
 	if (a.nv == 2 && a.nc == 4) {
-		if (G == 0 || G == 1) return launch<2, 4, 1>(S, a, stream);
-		if (G == 2) return launch<2, 4, 2>(S, a, stream);
-		if (G == 4) return launch<2, 4, 4>(S, a, stream);
+		if (G == 0 || G == 1) return launch_policy<2, 4, 1>(S, p, stream);
+		if (G == 2) return launch_policy<2, 4, 2>(S, p, stream);
+		if (G == 4) return launch_policy<2, 4, 4>(S, p, stream);
 		return ASIF_HIP_EINVAL;
 	}
 	if (a.nv == 2 && a.nc == 18) {
-		if (G == 0 || G == 2) return launch<2, 18, 2>(S, a, stream);
-		if (G == 1) return launch<2, 18, 1>(S, a, stream);
-		if (G == 4) return launch<2, 18, 4>(S, a, stream);
+		if (G == 0 || G == 2) return launch_policy<2, 18, 2>(S, p, stream);
+		if (G == 1) return launch_policy<2, 18, 1>(S, p, stream);
+		if (G == 4) return launch_policy<2, 18, 4>(S, p, stream);
 		return ASIF_HIP_EINVAL;
 	}
 	if (a.nv == 3 && a.nc == 41) {
-		if (G == 0 || G == 4) return launch<3, 41, 4>(S, a, stream);
-		if (G == 8) return launch<3, 41, 8>(S, a, stream);
-		if (G == 16) return launch<3, 41, 16>(S, a, stream);
+		if (G == 0 || G == 4) return launch_policy<3, 41, 4>(S, p, stream);
+		if (G == 8) return launch_policy<3, 41, 8>(S, p, stream);
+		if (G == 16) return launch_policy<3, 41, 16>(S, p, stream);
 		return ASIF_HIP_EINVAL;
-	}
-	// a few generic small shapes so that the entry point is usable beyond the shipped configs
-	if (a.nv == 1 && a.nc <= 8) {
-		// not compiled yet
 	}
 	return ASIF_HIP_EUNSUPPORTED;
 }

@@ -1,0 +1,272 @@
+// k_tb.hip -- "time to backup set" implicit filter: ASIFimplicitTB::filter, src/asif_implicit_tb.cpp:261-363.
+//
+// Stage 1  tb_rows_kernel, one instance per lane:
+//   * backupSet(x) >= 0  -> trivial rows A = 0, b = -inf (updateConstraintsTrivial, :716-733), code 2;
+//   * otherwise forward-Euler integration of the backup closed loop + sensitivity (:464-488) until the
+//     first sample inside the backup set ("first hit wins", :505-528 -- nothing past that sample is
+//     ever read by the reference, so the lane stops integrating there); no hit within the horizon
+//     -> code -3 (:529-536);
+//   * rows (:539-674): the npBTSS most critical samples of [0, idxHit] (padded with inert rows h=1,
+//     Dh=0 when the trajectory is shorter), the time-to-safety row and the orthogonality row with its
+//     analytic gradient through the hitting map.
+//   Lanes of a wave stop at different samples; the loop runs to the wave's slowest lane.
+// Stage 2  qp_policy_kernel<2,18,G> with the TB epilogue: rc 2 / 1 / -1 / raw solver status / -3 and the
+//   saturated backup controller on every failure (:290-361).
+#include "backup_traj.hpp"
+#include "qp_kernel.hpp"
+
+namespace asif {
+
+template <class M>
+__global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o, FilterArgs a)
+{
+	constexpr int NX = M::NX, NP = M::NPSS, K = M::NPBTSS, NZ = NX + NX * NX;
+	constexpr int NC = K * NP + 2, NV = 2;
+	__shared__ double pay[K * NZ * 64];
+	const int lane = threadIdx.x;
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const bool live = i < a.B;
+	if (!live) i = a.B - 1;
+	const int64_t ld = a.ld;
+
+	double x0[NX], f0[NX], g0[NX];
+#pragma unroll
+	for (int k = 0; k < NX; k++) x0[k] = a.x[k * ld + i];
+	const bool inside = M::backupSetValue(o, x0) >= 0; // :278-290
+	M::dynamics(o, x0, f0, g0);
+
+	double z[NZ];
+#pragma unroll
+	for (int k = 0; k < NZ; k++) z[k] = 0.0;
+#pragma unroll
+	for (int k = 0; k < NX; k++) {
+		z[k] = x0[k];
+		z[NX + k * (NX + 1)] = 1.0;
+	}
+	TopK<K> top;
+	top.init();
+	{
+		const int slot = top.insert(M::safetyMin(o, x0), 0);
+#pragma unroll
+		for (int k = 0; k < NZ; k++) pay[(slot * NZ + k) * 64 + lane] = z[k];
+	}
+	bool done = inside || !live, hit = false;
+	int idxHit = 0;
+	double t = 0.0, tHit = 0.0;
+#pragma unroll 1
+	for (int s = 1; s < o.npBT; s++) {
+		if (__all(done)) break;
+		if (!done) {
+			BackupLoop<M>::eulerStep(o, z);
+			t = t + o.trajDt; // backTraj_[i].first accumulates, :475
+			double xs[NX];
+#pragma unroll
+			for (int k = 0; k < NX; k++) xs[k] = z[k];
+			const int slot = top.insert(M::safetyMin(o, xs), s);
+			if (slot >= 0) {
+#pragma unroll
+				for (int k = 0; k < NZ; k++) pay[(slot * NZ + k) * 64 + lane] = z[k];
+			}
+			if (M::backupSetValue(o, xs) >= 0.0) {
+				hit = true;
+				done = true;
+				idxHit = s;
+				tHit = t;
+			}
+		}
+	}
+	if (!live) return;
+
+	const int code = inside ? 2 : (hit ? 1 : -3);
+	if (a.code) a.code[i] = code;
+	double TTS = 0.0, ortho = inside ? 1.0 : 0.0;
+	if (code != 1) {
+		// trivial rows; also what the staging buffer holds for code -3 (the reference leaves A_, b_
+		// untouched there and never solves; an inert QP keeps stage 2 uniform)
+#pragma unroll 1
+		for (int r = 0; r < NC; r++) {
+#pragma unroll
+			for (int j = 0; j < NV; j++) a.A[(int64_t)(r + j * NC) * ld + i] = 0.0;
+			a.b[(int64_t)r * ld + i] = -o.inf;
+		}
+	} else {
+		// safety rows of the critical samples in [0, idxHit]
+#pragma unroll 1
+		for (int k = 0; k < K; k++) {
+			if (k > idxHit) { // fewer samples than rows: inert padding, :556-566
+#pragma unroll
+				for (int r = 0; r < NP; r++) {
+					const int row = k * NP + r;
+					a.A[(int64_t)(row + 0 * NC) * ld + i] = 0.0;
+					a.A[(int64_t)(row + 1 * NC) * ld + i] = 1.0;
+					a.b[(int64_t)row * ld + i] = -0.0;
+				}
+				continue;
+			}
+			double zk[NZ], xs[NX], h[NP], Dh[NP * NX];
+			const int slot = top.slot[k];
+#pragma unroll
+			for (int c = 0; c < NZ; c++) zk[c] = pay[(slot * NZ + c) * 64 + lane];
+#pragma unroll
+			for (int c = 0; c < NX; c++) xs[c] = zk[c];
+			M::safetySet(o, xs, h, Dh);
+#pragma unroll
+			for (int r = 0; r < NP; r++) {
+				double Lf = 0.0, Lg = 0.0;
+#pragma unroll
+				for (int j = 0; j < NX; j++) {
+					double s = 0.0;
+#pragma unroll
+					for (int c = 0; c < NX; c++) s += Dh[r + c * NP] * zk[NX + c + j * NX];
+					Lf += s * f0[j];
+					Lg += s * g0[j];
+				}
+				const int row = k * NP + r;
+				a.A[(int64_t)(row + 0 * NC) * ld + i] = Lg;
+				a.A[(int64_t)(row + 1 * NC) * ld + i] = h[r];
+				a.b[(int64_t)row * ld + i] = -Lf;
+			}
+		}
+		// quantities at the hitting sample (z is still the state at idxHit)
+		double xh[NX], hBS, DhBS[NX], DDh[NX * NX], fCl[NX], DfCl[NX * NX];
+#pragma unroll
+		for (int c = 0; c < NX; c++) xh[c] = z[c];
+		M::backupSet(o, xh, hBS, DhBS, DDh);
+		BackupLoop<M>::closedLoop(o, xh, fCl, DfCl);
+		double cosT = 0.0, n1 = 0.0, n2 = 0.0;
+#pragma unroll
+		for (int c = 0; c < NX; c++) {
+			cosT += DhBS[c] * fCl[c];
+			n1 += DhBS[c] * DhBS[c];
+			n2 += fCl[c] * fCl[c];
+		}
+		const double den1 = sqrt(n1), den2 = sqrt(n2), den = den1 * den2;
+		ortho = cosT / den; // BTorthoBS_, :516-522
+		TTS = tHit;
+		const double hReach = o.backTrajHorizon - tHit;
+		double DhQ[NX]; // Dh_B(x_hit) Q_hit
+#pragma unroll
+		for (int j = 0; j < NX; j++) {
+			double s = 0.0;
+#pragma unroll
+			for (int c = 0; c < NX; c++) s += DhBS[c] * z[NX + c + j * NX];
+			DhQ[j] = s;
+		}
+		{ // time-to-safety row, :588-599 and :673
+			double Lf = 0.0, Lg = 0.0;
+#pragma unroll
+			for (int j = 0; j < NX; j++) {
+				const double dj = DhQ[j] / cosT;
+				Lf += dj * f0[j];
+				Lg += dj * g0[j];
+			}
+			const int row = K * NP;
+			a.A[(int64_t)(row + 0 * NC) * ld + i] = Lg;
+			a.A[(int64_t)(row + 1 * NC) * ld + i] = 0.0;
+			a.b[(int64_t)row * ld + i] = -Lf - o.relaxTTS * hReach;
+		}
+		{ // orthogonality row: gradient of cos(angle(grad h_B, f_cl)) at the hit w.r.t. x0, :601-641
+			double DxHit[NX * NX];
+#pragma unroll
+			for (int r = 0; r < NX; r++)
+#pragma unroll
+				for (int j = 0; j < NX; j++) DxHit[r + j * NX] = z[NX + r + j * NX] - fCl[r] * DhQ[j];
+			const double den2sq = den * den;
+			double Lf = 0.0, Lg = 0.0;
+#pragma unroll
+			for (int c = 0; c < NX; c++) {
+				double Dnum = 0.0, Dd1 = 0.0, Dd2 = 0.0;
+#pragma unroll
+				for (int k = 0; k < NX; k++) {
+					double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+					for (int l = 0; l < NX; l++) {
+						t1 += DDh[k + l * NX] * DxHit[l + c * NX];
+						t2 += DfCl[k + l * NX] * DxHit[l + c * NX];
+					}
+					const double t3 = DhBS[k] * t2, t4 = t1 * fCl[k];
+					Dd1 += t3;
+					Dd2 += t4;
+					Dnum += t3 + t4;
+				}
+				const double Dden = den2 * Dd1 / den1 + den1 * Dd2 / den2;
+				const double dc = (Dnum * den - cosT * Dden) / den2sq;
+				Lf += dc * f0[c];
+				Lg += dc * g0[c];
+			}
+			const int row = K * NP + 1;
+			a.A[(int64_t)(row + 0 * NC) * ld + i] = Lg;
+			a.A[(int64_t)(row + 1 * NC) * ld + i] = 0.0;
+			a.b[(int64_t)row * ld + i] = -Lf - o.relaxMinOrtho * (ortho - o.backTrajMinOrtho);
+		}
+	}
+	if (a.diag) {
+		a.diag[0 * ld + i] = TTS;
+		a.diag[1 * ld + i] = ortho;
+		a.diag[2 * ld + i] = (double)idxHit;
+#pragma unroll 1
+		for (int k = 0; k < K; k++) a.diag[(int64_t)(3 + k) * ld + i] = (code == 1 && k <= idxHit) ? (double)top.idx[k] : -1.0;
+	}
+}
+
+template <class M>
+struct TbPolicy {
+	int64_t B;
+	DevOptions o;
+	FilterArgs a; // a.A / a.b = staged rows, a.code = staged branch codes
+
+	template <int NV, int NC, int G>
+	__device__ __forceinline__ void load(int64_t i, int g, QpLaneData<NV, (NC + G - 1) / G> &qp) const
+	{
+		static_assert(NV == 2, "nu + 1 variables");
+		// src/asif_implicit_tb.cpp:198-210
+		qp.Hd[0] = 1.0;
+		qp.Hd[1] = o.relaxCost;
+		qp.c[0] = -2.0 * a.udes[i];
+		qp.c[1] = -2.0 * o.relaxCost * o.relaxLb;
+		qp.lb[0] = o.lb[0];
+		qp.lb[1] = o.relaxLb;
+		qp.ub[0] = o.ub[0];
+		qp.ub[1] = o.inf;
+		load_rows<NV, NC, G>(a.A, a.b, a.ld, i, g, 0ull, qp);
+	}
+	template <int NV>
+	__device__ __forceinline__ void store(int64_t i, const double (&sol)[NV], int st, int it) const
+	{
+		const int code = a.code[i];
+		if (code != -3 && st == kStatusSolved) {
+			a.uact[i] = fmin(fmax(sol[0], o.lb[0]), o.ub[0]);
+			a.relax[i] = sol[1];
+			a.rc[i] = code; // 2 inside the backup set (:307), 1 otherwise (:343)
+		} else {
+			double x[M::NX], u[1], Du[M::NX];
+#pragma unroll
+			for (int k = 0; k < M::NX; k++) x[k] = a.x[k * a.ld + i];
+			M::backupController(o, x, u, Du);
+			a.uact[i] = fmin(fmax(u[0], o.lb[0]), o.ub[0]);
+			// :315 (-1 on the trivial branch), :351 (the raw solver status leaks), :360 (-3)
+			a.rc[i] = code == -3 ? ASIF_HIP_RC_BACKUP_UNREACHED : (code == 2 ? ASIF_HIP_RC_QP_FAILED : st);
+		}
+		if (a.diag) a.diag[(int64_t)(a.ndiag - 1) * a.ld + i] = (double)it;
+	}
+};
+
+int launch_tb_segway(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                     hipStream_t stream)
+{
+	using M = Segway;
+	if (a.B <= 0) return 0;
+	hipLaunchKernelGGL((tb_rows_kernel<M>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
+	int e = (int)hipGetLastError();
+	if (e || assemble_only) return e;
+	const TbPolicy<M> p = {a.B, o, a};
+	switch (S.lanes_per_qp) {
+	case 0:
+	case 2: return launch_policy<2, 18, 2>(S, p, stream);
+	case 1: return launch_policy<2, 18, 1>(S, p, stream);
+	case 4: return launch_policy<2, 18, 4>(S, p, stream);
+	default: return ASIF_HIP_EINVAL;
+	}
+}
+
+} // namespace asif

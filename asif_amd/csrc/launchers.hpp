@@ -23,6 +23,16 @@ struct FilterArgs {
 int launch_explicit_di(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                        hipStream_t stream);
 
+// implicit backup-trajectory filter (class ASIFimplicit), model = InvertedPendulum.
+// Filter mode needs a.A / a.b to point at staging rows of (nc*nv + nc) * ld doubles.
+int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                       hipStream_t stream);
+
+// time-to-backup-set filter (class ASIFimplicitTB), model = Segway.
+// Filter mode additionally needs a.code to point at B staged int32 branch codes.
+int launch_tb_segway(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                     hipStream_t stream);
+
 struct QpArgs {
 	int64_t B, ld;
 	int nv, nc;

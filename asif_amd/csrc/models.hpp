@@ -56,4 +56,216 @@ struct DoubleIntegrator {
 	}
 };
 
+// ---------------------------------------------------------------------------------------------
+// Inverted pendulum with an LQR-like backup controller, examples/InvertedPendulum_Implicit.cpp:13-80.
+struct InvertedPendulum {
+	static constexpr int NX = 2, NU = 1, NPSS = 4, NPBS = 1, NPBTSS = 10;
+
+	// :31-37  box |theta| <= pi, |omega| <= pi
+	__device__ static void safetySet(const DevOptions &, const double (&x)[NX], double (&h)[NPSS], double (&Dh)[NPSS * NX])
+	{
+		h[0] = -x[0] + kPi; Dh[0] = -1.0; Dh[4] = 0.0;
+		h[1] = x[0] + kPi;  Dh[1] = 1.0;  Dh[5] = 0.0;
+		h[2] = x[1] + kPi;  Dh[2] = 0.0;  Dh[6] = 1.0;
+		h[3] = -x[1] + kPi; Dh[3] = 0.0;  Dh[7] = -1.0;
+	}
+	__device__ static double safetyMin(const DevOptions &, const double (&x)[NX])
+	{
+		return fmin(fmin(-x[0] + kPi, x[0] + kPi), fmin(x[1] + kPi, -x[1] + kPi));
+	}
+	// :39-52  ellipsoid Pv - x'Px >= 0, P = [1.25 .25; .25 .25]; gradient -(P+P')x
+	__device__ static void backupSet(const DevOptions &, const double (&x)[NX], double &h, double (&Dh)[NX],
+	                                 double (&DDh)[NX * NX])
+	{
+		const double P00 = 1.25, P10 = 0.25, P01 = 0.25, P11 = 0.25;
+		double v = 0.05;
+		v -= P00 * x[0] * x[0];
+		v -= P01 * x[0] * x[1];
+		v -= P10 * x[1] * x[0];
+		v -= P11 * x[1] * x[1];
+		h = v;
+		Dh[0] = -2.5 * x[0] + -0.5 * x[1];
+		Dh[1] = -0.5 * x[0] + -0.5 * x[1];
+		DDh[0] = -2.5; DDh[1] = -0.5; DDh[2] = -0.5; DDh[3] = -0.5; // not used by ASIFimplicit
+	}
+	// :55-62 and :73-80  f = (omega, sin theta), g = (0,1); Df = [0 1; cos theta 0], Dg = 0
+	__device__ static void dynamics(const DevOptions &, const double (&x)[NX], double (&f)[NX], double (&g)[NX * NU])
+	{
+		f[0] = x[1];
+		f[1] = sin(x[0]);
+		g[0] = 0.0;
+		g[1] = 1.0;
+	}
+	__device__ static void dynamicsAndGradients(const DevOptions &, const double (&x)[NX], double (&f)[NX],
+	                                            double (&g)[NX * NU], double (&Df)[NX * NX], double (&Dg)[NX * NU * NX])
+	{
+		double s, c;
+		sincos(x[0], &s, &c);
+		f[0] = x[1];
+		f[1] = s;
+		g[0] = 0.0;
+		g[1] = 1.0;
+		Df[0] = 0.0; Df[2] = 1.0;
+		Df[1] = c;   Df[3] = 0.0;
+#pragma unroll
+		for (int i = 0; i < NX * NU * NX; i++) Dg[i] = 0.0;
+	}
+	// :63-71  u = K x, K = (-3,-3)
+	__device__ static void backupController(const DevOptions &, const double (&x)[NX], double (&u)[NU], double (&Du)[NU * NX])
+	{
+		u[0] = -3.0 * x[0] + -3.0 * x[1];
+		Du[0] = -3.0;
+		Du[1] = -3.0;
+	}
+};
+
+// ---------------------------------------------------------------------------------------------
+// Segway, examples/segway_implicit_tb.cpp:13-212 (MATLAB-generated dynamics and Jacobians).
+// x = (position, velocity, pitch, pitch rate).  The friction factor of f is multiplied by 0.0 in the
+// reference (:78) so its terms vanish identically; the Jacobian was generated WITH the tanh friction
+// model and is reproduced as shipped.
+struct Segway {
+	static constexpr int NX = 4, NU = 1, NPSS = 4, NPBS = 1, NPBTSS = 4;
+
+	__device__ static double xb(int i) { return i < 2 ? 3.0 : (i == 2 ? kPi / 6 : kPi); }
+
+	// :27-38  h_i = xBound_i^2 - x_i^2
+	__device__ static void safetySet(const DevOptions &, const double (&x)[NX], double (&h)[NPSS], double (&Dh)[NPSS * NX])
+	{
+#pragma unroll
+		for (int i = 0; i < NPSS * NX; i++) Dh[i] = 0.0;
+#pragma unroll
+		for (int i = 0; i < NX; i++) {
+			h[i] = (xb(i) * xb(i)) - (x[i] * x[i]);
+			Dh[i * (NX + 1)] = -2.0 * x[i];
+		}
+	}
+	__device__ static double safetyMin(const DevOptions &, const double (&x)[NX])
+	{
+		double m = (xb(0) * xb(0)) - (x[0] * x[0]);
+#pragma unroll
+		for (int i = 1; i < NX; i++) m = fmin(m, (xb(i) * xb(i)) - (x[i] * x[i]));
+		return m;
+	}
+	// :40-54  Pv^2 - sum (x_i/xBound_i)^2 with gradient and (diagonal) Hessian
+	__device__ static void backupSet(const DevOptions &, const double (&x)[NX], double &h, double (&Dh)[NX],
+	                                 double (&DDh)[NX * NX])
+	{
+#pragma unroll
+		for (int i = 0; i < NX * NX; i++) DDh[i] = 0.0;
+		double v = 0.05 * 0.05;
+#pragma unroll
+		for (int i = 0; i < NX; i++) {
+			const double q = x[i] / xb(i);
+			v -= q * q;
+			Dh[i] = -2.0 * x[i] / (xb(i) * xb(i));
+			DDh[i * (NX + 1)] = -2.0 / (xb(i) * xb(i));
+		}
+		h = v;
+	}
+	__device__ static double backupSetValue(const DevOptions &, const double (&x)[NX])
+	{
+		double v = 0.05 * 0.05;
+#pragma unroll
+		for (int i = 0; i < NX; i++) {
+			const double q = x[i] / xb(i);
+			v -= q * q;
+		}
+		return v;
+	}
+	// :56-68  u = K (x + x_eq)
+	__device__ static void backupController(const DevOptions &, const double (&x)[NX], double (&u)[NU], double (&Du)[NU * NX])
+	{
+		const double K0 = 44.7214, K1 = 44.6528, K2 = 150.1612, K3 = 37.6492;
+		u[0] = K0 * (0. + x[0]) + K1 * (0. + x[1]) + K2 * (-0.1383244254 + x[2]) + K3 * (0. + x[3]);
+		Du[0] = K0; Du[1] = K1; Du[2] = K2; Du[3] = K3;
+	}
+	struct Trig { double s1, c1, s2, c2; };
+	__device__ static Trig trig(double pitch)
+	{
+		Trig t;
+		sincos(pitch, &t.s1, &t.c1);
+		sincos(2.0 * pitch, &t.s2, &t.c2);
+		return t;
+	}
+	// :70-111
+	__device__ static void dynamicsT(const double (&X)[NX], const Trig &t, double (&f)[NX], double (&g)[NX * NU])
+	{
+		const double w2 = X[3] * X[3];
+		const double iden = 1.0 / ((14.553176960783997 + -2.0831375273848773 * t.c2) + -0.59146430898882 * t.s2);
+		f[0] = X[1];
+		f[1] = 0.0975 * ((((((44.798 * (((-0.2693850964936445 * w2) + -0.0022454764220255392 * w2) +
+		                                 -0.11586336477125109 * w2) * 0.195 * t.c1 +
+		                       59.510408935182809 * t.c2) + 86.686408318784913 * w2 * 0.195 * t.s1) +
+		                     0.72258001100852454 * w2 * 0.195 * t.s1) + 37.284092841364554 * w2 * 0.195 * t.s1) +
+		                   4.1423245261005457 * t.s2) + -213.73800805067131 * t.s2) * iden;
+		f[2] = X[3];
+		f[3] = iden * (((((((89.596 * (-0.45669752988922296) * t.c1 + 15.554616935932147 * w2 * 0.038025 * t.c2) +
+		                    16.405863695295427 * t.s1) + 249.80488266222164 * t.s1) + 27.713966400983114 * t.s1) +
+		                 1.0827059060875992 * w2 * 0.038025 * t.s2) + -55.866072832711595 * w2 * 0.038025 * t.s2));
+		g[0] = 0.0;
+		const double gc = 1.4575004011882324 * t.c1;
+		const double gs = 0.20290365220710288 * t.s1;
+		g[1] = 0.551244194154502 * ((4.1706936767483551 + gc) + gs) *
+		       (1.0 / (((8.3593271361634187 + -2.1243074194638587 * (t.c1 * t.c1)) +
+		                -0.04116989207898096 * (t.s1 * t.s1)) + -0.29573215449441 * t.s2));
+		g[2] = 0.0;
+		g[3] = -5.65378660671284 * ((2.0043013906215941 + gc) + gs) * iden;
+	}
+	__device__ static void dynamics(const DevOptions &, const double (&x)[NX], double (&f)[NX], double (&g)[NX * NU])
+	{
+		dynamicsT(x, trig(x[2]), f, g);
+	}
+	// :113-212
+	__device__ static void dynamicsAndGradients(const DevOptions &, const double (&x)[NX], double (&f)[NX],
+	                                            double (&g)[NX * NU], double (&Df)[NX * NX], double (&Dg)[NX * NU * NX])
+	{
+		const Trig t = trig(x[2]);
+		dynamicsT(x, t, f, g);
+		const double c1 = t.c1, s1 = t.s1, c2 = t.c2, s2 = t.s2;
+		const double w2 = x[3] * x[3];
+		const double th = tanh(x[1] * 1000.0);
+		const double th2 = th * th;
+		const double t25 = th * 15.13175750513302 - 40.918271887954823;
+		const double t26 = w2 * 3.3849959169972448 + th * 30.26351501026604;
+		const double t23 = 1.0 / ((c2 * 2.0831375273848769 + s2 * 0.59146430898882) - 14.553176960784);
+#pragma unroll
+		for (int i = 0; i < NX * NX; i++) Df[i] = 0.0;
+		Df[4] = 1.0;
+		const double e1 = s1 * (th2 * 1000.0 - 1000.0);
+		Df[5] = -t23 * (((th2 * 8443.5211353581435 + e1 * 0.41077609832706019) +
+		                 c1 * (th2 * 30263.515010266041 - 30263.515010266041) * 0.0975) - 8443.5211353581435);
+		Df[7] = t23 * (((th2 * 20808.641003022261 + e1 * 2.1065440939849238) +
+		                c1 * (th2 * 15131.75750513302 - 15131.75750513302)) - 20808.641003022261);
+		const double cth = c1 * th;
+		const double sth = s1 * th;
+		const double e3 = (c2 * 1.18292861797764 + -(s2 * 4.1662750547697547)) * (t23 * t23);
+		Df[9] = t23 * ((((c2 * 40.8711582872913 + s2 * 11.604529742360651) - c1 * w2 * 2.3707272057666411) +
+		                cth * 0.41077609832706019) - s1 * t26 * 0.0975) -
+		        e3 * (((((c2 * -5.8022648711803244 + s2 * 20.435579143645651) + th * 8.443521135358143) -
+		                s1 * w2 * 2.3707272057666411) + sth * 0.41077609832706019) + c1 * t26 * 0.0975);
+		const double wc = w2 * c2;
+		const double ws = w2 * s2;
+		Df[11] = t23 * ((((c1 * -293.92471275850022 - cth * 2.1065440939849238) + wc * 4.1662750547697547) +
+		                 ws * 1.18292861797764) + s1 * t25) +
+		         e3 * (((((s1 * 293.92471275850022 + th * 20.808641003022259) + wc * 0.59146430898881985) +
+		                 sth * 2.1065440939849238) - ws * 2.0831375273848769) + c1 * t25);
+		Df[13] = t23 * (c1 * x[3] * 0.6600742038144628 - s1 * x[3] * 4.7414544115332831);
+		Df[14] = 1.0;
+		Df[15] = -t23 * (c2 * x[3] * 1.18292861797764 - s2 * x[3] * 4.1662750547697547);
+
+		const double d4 = (c2 * 2.0831375273848769 + s2 * 0.59146430898882) - 14.553176960784;
+		const double d26 = ((c1 * c1 * 2.1243074194638591 + s2 * 0.29573215449441) + s1 * s1 * 0.04116989207898096) -
+		                   8.3593271361634187;
+#pragma unroll
+		for (int i = 0; i < NX * NU * NX; i++) Dg[i] = 0.0;
+		Dg[9] = -(c1 * 0.1118494602519098 - s1 * 0.80343863413287053) / d26 +
+		        1.0 / (d26 * d26) * (c2 * 0.59146430898882 - c1 * s1 * 4.1662750547697547) *
+		            ((c1 * 0.80343863413287053 + s1 * 0.1118494602519098) + 2.2990706749044238);
+		Dg[11] = (c1 * 1.1471739513016379 - s1 * 8.24039624751662) / d4 -
+		         1.0 / (d4 * d4) * (c2 * 1.18292861797764 - s2 * 4.1662750547697547) *
+		             ((c1 * 8.24039624751662 + s1 * 1.1471739513016379) + 11.33189235811229);
+	}
+};
+
 } // namespace asif

@@ -1,0 +1,59 @@
+// qp_kernel.hpp -- one batched-QP kernel body, parameterised by where the problem comes from and
+// where the answer goes.  The generic C-ABI entry (k_qp.hip) and the two-stage filters (implicit, TB:
+// rows staged in HBM by the trajectory kernel) instantiate it with different policies.
+#pragma once
+#include "admm_small.hpp"
+#include "launchers.hpp"
+
+namespace asif {
+
+// Rows staged in HBM: A[(nc*nv)][ld] column-major inside an instance, b[nc][ld].
+template <int NV, int NC, int G>
+__device__ __forceinline__ void load_rows(const double *A, const double *b, int64_t ld, int64_t i, int g,
+                                          uint64_t be_mask, QpLaneData<NV, (NC + G - 1) / G> &qp)
+{
+	constexpr int RPL = (NC + G - 1) / G;
+#pragma unroll
+	for (int k = 0; k < RPL; k++) {
+		const int r = g + k * G;
+		const bool valid = r < NC;
+		const int rr = valid ? r : 0;
+#pragma unroll
+		for (int j = 0; j < NV; j++) {
+			const double v = A[(int64_t)(rr + j * NC) * ld + i];
+			qp.A[k][j] = valid ? v : 0.0;
+		}
+		const double bv = b[(int64_t)rr * ld + i];
+		qp.b[k] = valid ? bv : -1e20; // out-of-range rows are inert: 0.x >= -big
+		qp.eq[k] = valid && ((be_mask >> rr) & 1ull);
+	}
+}
+
+template <int NV, int NC, int G, class Policy>
+__global__ __launch_bounds__(64) void qp_policy_kernel(asif_hip_solver S, Policy pol)
+{
+	constexpr int RPL = (NC + G - 1) / G;
+	const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int g = (int)(tid % G);
+	int64_t i = tid / G;
+	const bool live = i < pol.B;
+	if (!live) i = pol.B - 1;
+	QpLaneData<NV, RPL> qp;
+	pol.template load<NV, NC, G>(i, g, qp);
+	AdmmSmall<NV, RPL, G> admm;
+	double sol[NV];
+	int status, iters;
+	admm.solve(qp, S, sol, status, iters);
+	if (live && g == 0) pol.template store<NV>(i, sol, status, iters);
+}
+
+template <int NV, int NC, int G, class Policy>
+static int launch_policy(const asif_hip_solver &S, const Policy &pol, hipStream_t stream)
+{
+	const int block = 64;
+	hipLaunchKernelGGL((qp_policy_kernel<NV, NC, G, Policy>), dim3(grid_for(pol.B, G, block)), dim3(block), 0, stream,
+	                   S, pol);
+	return (int)hipGetLastError();
+}
+
+} // namespace asif

@@ -89,7 +89,8 @@ typedef struct asif_hip_options {
 
 /* In-kernel ADMM settings.  Defaults (asif_hip_default_solver) are tuned for |u - u*| <= 1e-6:
  * OSQP-style splitting with power-of-two Ruiz scaling, per-row rho, adaptive rho, infeasibility
- * certificates, and a KKT-validated active-set polish tried at every termination check. */
+ * certificates, and at every termination check an active-set finish seeded by the iterates whose
+ * result is accepted only when it is KKT-valid (optimal) or carries a Farkas certificate (infeasible). */
 typedef struct asif_hip_solver {
 	double rho, sigma, alpha;
 	double eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
@@ -97,7 +98,9 @@ typedef struct asif_hip_solver {
 	int32_t max_iter;
 	int32_t check_interval; /* termination check + polish attempt + rho adaptation every this many iterations */
 	int32_t scaling_iters;
-	int32_t polish;
+	int32_t polish;            /* 1: run the active-set finish at every check */
+	int32_t active_set_rounds; /* primal-dual working-set corrections per finish */
+	int32_t refine_steps;      /* refinement steps of each regularised working-set solve */
 	int32_t adaptive_rho;
 	int32_t lanes_per_qp;   /* 0 = library default for the shape */
 } asif_hip_solver;

@@ -388,34 +388,19 @@ static double scaled_norm_inf(const double *s, const double *v, int n)
 	return r;
 }
 
-/* Active-set polish, tried at a termination check (OSQP polish.c idea in primal Schur form):
- * guess lower/upper-active rows from (z,y), solve the equality-constrained QP on them by the
- * regularised system with `refine` refinement steps, and ACCEPT ONLY if the point satisfies the
- * KKT conditions of the full problem (all rows feasible, multipliers correctly signed).  Off in
- * the reference configuration (OSQP default polish=0); used to study the device algorithm. */
-static int try_polish(const ws_t *w, const double *z, const double *y, double *xpol, double ktol)
+/* ---- Active-set finish, tried at a termination check (device algorithm study; the reference
+ * configuration has OSQP's polish off).  Three pieces, all in the scaled space and in the primal
+ * Schur form of the KKT system:
+ *   as_solve   : equality-constrained QP on a working set by the regularised system + refinement
+ *                (OSQP polish.c idea), then classification of every row at that point;
+ *   as_farkas  : least-squares point of the working rows; if every residual has the sign of a
+ *                violation the residual vector is an exact Farkas certificate of infeasibility;
+ *   try_polish : working set guessed from (z,y), then a few primal-dual active-set corrections
+ *                (add violated rows, drop wrongly signed multipliers).  A result is ACCEPTED ONLY if
+ *                it satisfies the KKT conditions of the full problem (returns 1) or carries a valid
+ *                certificate (returns 2); otherwise ADMM simply continues (returns 0). */
+static int small_ldl(int n, double *M, double *Dg)
 {
-	const int n = w->n, m = w->m;
-	const double delta = 1e-6;
-	int act[MAXM];
-	double r[MAXM], nu[MAXM];
-	int na = 0;
-	for (int i = 0; i < m; i++) {
-		act[i] = 0;
-		if (w->u[i] - w->l[i] < RHO_TOL) { act[i] = 2; r[i] = w->l[i]; na++; } /* equality: always active, free sign */
-		else if (z[i] - w->l[i] < -y[i]) { act[i] = -1; r[i] = w->l[i]; na++; }
-		else if (w->u[i] - z[i] < y[i]) { act[i] = 1; r[i] = w->u[i]; na++; }
-		nu[i] = 0;
-	}
-	/* M = P + delta I + (1/delta) sum_act a a' ; dense LDL' */
-	double M[MAXN * MAXN], Dg[MAXN], x[MAXN] = {0}, e1[MAXN], e2[MAXM], rhs[MAXN];
-	for (int a = 0; a < n; a++)
-		for (int b = 0; b <= a; b++) {
-			double sacc = 0;
-			for (int i = 0; i < m; i++)
-				if (act[i]) sacc += w->A[i * n + a] * w->A[i * n + b];
-			M[a * n + b] = sacc / delta + (a == b ? w->P[a] + delta : 0.0);
-		}
 	for (int j = 0; j < n; j++) {
 		double d = M[j * n + j];
 		for (int k = 0; k < j; k++) d -= M[j * n + k] * M[j * n + k] * Dg[k];
@@ -427,31 +412,53 @@ static int try_polish(const ws_t *w, const double *z, const double *y, double *x
 			M[i * n + j] = sacc / d;
 		}
 	}
-	for (int it = 0; it < 4; it++) {
-		/* residual of the un-regularised KKT system at (x,nu) */
-		for (int j = 0; j < n; j++) e1[j] = -w->q[j] - w->P[j] * x[j];
+	return 1;
+}
+static void small_ldl_solve(int n, const double *M, const double *Dg, double *v)
+{
+	for (int i = 0; i < n; i++) {
+		double sacc = v[i];
+		for (int k = 0; k < i; k++) sacc -= M[i * n + k] * v[k];
+		v[i] = sacc;
+	}
+	for (int i = 0; i < n; i++) v[i] /= Dg[i];
+	for (int i = n - 1; i >= 0; i--) {
+		double sacc = v[i];
+		for (int k = i + 1; k < n; k++) sacc -= M[k * n + i] * v[k];
+		v[i] = sacc;
+	}
+}
+
+static int g_as_refine = 3; /* refinement steps of the regularised solve (device default) */
+
+/* returns 1 valid KKT point; 0 otherwise with viol[i] (-1 below l, +1 above u) and wrong[i] filled */
+static int as_solve(const ws_t *w, const int *act, const double *r, double *x, double *nu, int *viol, int *wrong,
+                    double ktol)
+{
+	const int n = w->n, m = w->m;
+	const double delta = 1e-6;
+	double M[MAXN * MAXN], Dg[MAXN], e2[MAXM], rhs[MAXN];
+	for (int a = 0; a < n; a++)
+		for (int b = 0; b <= a; b++) {
+			double sacc = 0;
+			for (int i = 0; i < m; i++)
+				if (act[i]) sacc += w->A[i * n + a] * w->A[i * n + b];
+			/* primal regularisation only where the cost has no curvature of its own */
+			M[a * n + b] = sacc / delta + (a == b ? (w->P[a] > 0 ? w->P[a] : delta) : 0.0);
+		}
+	for (int i = 0; i < m; i++) { nu[i] = 0; viol[i] = 0; wrong[i] = 0; }
+	for (int j = 0; j < n; j++) x[j] = 0;
+	if (!small_ldl(n, M, Dg)) return 0;
+	for (int it = 0; it < g_as_refine; it++) {
+		for (int j = 0; j < n; j++) rhs[j] = -w->q[j] - w->P[j] * x[j];
 		for (int i = 0; i < m; i++) {
 			if (!act[i]) continue;
 			double ax = 0;
 			for (int j = 0; j < n; j++) ax += w->A[i * n + j] * x[j];
 			e2[i] = r[i] - ax;
-			for (int j = 0; j < n; j++) e1[j] -= w->A[i * n + j] * nu[i];
+			for (int j = 0; j < n; j++) rhs[j] += w->A[i * n + j] * (e2[i] / delta - nu[i]);
 		}
-		for (int j = 0; j < n; j++) rhs[j] = e1[j];
-		for (int i = 0; i < m; i++)
-			if (act[i])
-				for (int j = 0; j < n; j++) rhs[j] += w->A[i * n + j] * e2[i] / delta;
-		for (int i = 0; i < n; i++) {
-			double sacc = rhs[i];
-			for (int k = 0; k < i; k++) sacc -= M[i * n + k] * rhs[k];
-			rhs[i] = sacc;
-		}
-		for (int i = 0; i < n; i++) rhs[i] /= Dg[i];
-		for (int i = n - 1; i >= 0; i--) {
-			double sacc = rhs[i];
-			for (int k = i + 1; k < n; k++) sacc -= M[k * n + i] * rhs[k];
-			rhs[i] = sacc;
-		}
+		small_ldl_solve(n, M, Dg, rhs);
 		for (int i = 0; i < m; i++) {
 			if (!act[i]) continue;
 			double adx = 0;
@@ -460,26 +467,137 @@ static int try_polish(const ws_t *w, const double *z, const double *y, double *x
 		}
 		for (int j = 0; j < n; j++) x[j] += rhs[j];
 	}
-	/* KKT validation on the full problem (scaled space; rows with E scaling are O(1)) */
+	int bad = 0;
 	for (int i = 0; i < m; i++) {
 		double ax = 0;
 		for (int j = 0; j < n; j++) ax += w->A[i * n + j] * x[j];
 		const double tol = ktol * (1 + fabs(ax));
-		if (ax < w->l[i] - tol || ax > w->u[i] + tol) return 0;
-		if (act[i] == -1 && nu[i] > ktol * (1 + fabs(nu[i]))) return 0;
-		if (act[i] == 1 && nu[i] < -ktol * (1 + fabs(nu[i]))) return 0;
+		if (ax < w->l[i] - tol) { viol[i] = -1; bad = 1; }
+		else if (ax > w->u[i] + tol) { viol[i] = 1; bad = 1; }
+		const double nt = ktol * (1 + fabs(nu[i]));
+		if ((act[i] == -1 && nu[i] > nt) || (act[i] == 1 && nu[i] < -nt)) { wrong[i] = 1; bad = 1; }
 	}
-	double sres = 0; /* stationarity after the last refinement */
+	/* stationarity, relative to the size of its own terms (a column can be scaled very small) */
 	for (int j = 0; j < n; j++) {
 		double g = w->P[j] * x[j] + w->q[j];
+		double mag = fabs(w->P[j] * x[j]) + fabs(w->q[j]);
 		for (int i = 0; i < m; i++)
-			if (act[i]) g += w->A[i * n + j] * nu[i];
-		if (fabs(g) > sres) sres = fabs(g);
+			if (act[i]) {
+				g += w->A[i * n + j] * nu[i];
+				mag += fabs(w->A[i * n + j] * nu[i]);
+			}
+		if (fabs(g) > 1e-10 * mag + 1e-300) bad = 1;
 	}
-	if (sres > 1e-7) return 0;
-	for (int j = 0; j < n; j++) xpol[j] = x[j];
-	(void)na;
-	return 1;
+	return !bad;
+}
+
+/* Infeasibility test = phase 1 of the problem: minimise the one-sided least squares
+ * sum_i max(0, violation_i(x))^2 by working-set iterations (least-squares point of the rows in S,
+ * then S := rows violated there, equalities always in).  At a stationary S every residual has the
+ * sign of a violation, A_S' v = 0 by construction and sum r_i v_i = |v|^2 > 0: v is a Farkas
+ * certificate as soon as it is not (numerically) zero.  `act0` seeds S. */
+static int g_farkas_iters = 4;
+static int as_farkas(const ws_t *w, const int *act0, const double *r0)
+{
+	const int n = w->n, m = w->m;
+	int act[MAXM];
+	double r[MAXM], MS[MAXN * MAXN], DS[MAXN], wv[MAXN], v[MAXM];
+	for (int i = 0; i < m; i++) { act[i] = act0[i]; r[i] = r0[i]; }
+	for (int iter = 0;; iter++) {
+		double dmax = 0;
+		for (int a = 0; a < n; a++)
+			for (int b = 0; b <= a; b++) {
+				double sacc = 0;
+				for (int i = 0; i < m; i++)
+					if (act[i]) sacc += w->A[i * n + a] * w->A[i * n + b];
+				MS[a * n + b] = sacc;
+				if (a == b && sacc > dmax) dmax = sacc;
+			}
+		for (int a = 0; a < n; a++) MS[a * n + a] += 1e-14 * dmax + 1e-300;
+		if (!small_ldl(n, MS, DS)) return 0;
+		for (int j = 0; j < n; j++) {
+			double sacc = 0;
+			for (int i = 0; i < m; i++)
+				if (act[i]) sacc += w->A[i * n + j] * r[i];
+			wv[j] = sacc;
+		}
+		small_ldl_solve(n, MS, DS, wv);
+		{ /* one refinement step removes the footprint of the 1e-14 regularisation from A_S' v */
+			double g2[MAXN];
+			for (int j = 0; j < n; j++) g2[j] = 0;
+			for (int i = 0; i < m; i++) {
+				if (!act[i]) continue;
+				double ax = 0;
+				for (int j = 0; j < n; j++) ax += w->A[i * n + j] * wv[j];
+				for (int j = 0; j < n; j++) g2[j] += w->A[i * n + j] * (r[i] - ax);
+			}
+			small_ldl_solve(n, MS, DS, g2);
+			for (int j = 0; j < n; j++) wv[j] += g2[j];
+		}
+		/* residuals of the working rows at the least-squares point; rows met with slack leave
+		 * (removal only, so the iteration is monotone and ends) */
+		int signs_ok = 1;
+		double vmax = 0;
+		for (int i = 0; i < m; i++) {
+			v[i] = 0.0;
+			if (!act[i]) continue;
+			double ax = 0;
+			for (int j = 0; j < n; j++) ax += w->A[i * n + j] * wv[j];
+			v[i] = r[i] - ax;
+			if ((act[i] == -1 && v[i] < -1e-12) || (act[i] == 1 && v[i] > 1e-12)) {
+				signs_ok = 0;
+				act[i] = 0;
+				continue;
+			}
+			if (fabs(v[i]) > vmax) vmax = fabs(v[i]);
+		}
+		if (signs_ok) {
+			if (!(vmax > 1e-7)) return 0;
+			for (int j = 0; j < n; j++) {
+				double g = 0;
+				for (int i = 0; i < m; i++) g += w->A[i * n + j] * v[i];
+				if (fabs(g) > 1e-9 * vmax) return 0;
+			}
+			return 1;
+		}
+		if (iter >= g_farkas_iters) return 0;
+	}
+}
+
+static int g_as_rounds = 12; /* active-set corrections per attempt (device default) */
+void or_set_as_rounds(int k) { g_as_rounds = k; }
+void or_set_as_refine(int k) { g_as_refine = k; }
+
+static int try_polish(const ws_t *w, const double *z, const double *y, double *xpol, double ktol)
+{
+	const int n = w->n, m = w->m;
+	int act[MAXM], viol[MAXM], wrong[MAXM];
+	double r[MAXM], nu[MAXM], x[MAXN];
+	for (int i = 0; i < m; i++) {
+		act[i] = 0;
+		r[i] = 0;
+		if (w->u[i] - w->l[i] < RHO_TOL) { act[i] = 2; r[i] = w->l[i]; } /* equality: always active, free sign */
+		else if (z[i] - w->l[i] < -y[i]) { act[i] = -1; r[i] = w->l[i]; }
+		else if (w->u[i] - z[i] < y[i]) { act[i] = 1; r[i] = w->u[i]; }
+	}
+	for (int round = 0;; round++) {
+		if (as_solve(w, act, r, x, nu, viol, wrong, ktol)) {
+			for (int j = 0; j < n; j++) xpol[j] = x[j];
+			return 1;
+		}
+		int viol_active = 0;
+		for (int i = 0; i < m; i++)
+			if (viol[i] && act[i]) viol_active = 1;
+		if (viol_active && as_farkas(w, act, r)) return 2;
+		if (round >= g_as_rounds) return 0;
+		int changed = 0;
+		for (int i = 0; i < m; i++) {
+			if (act[i] == 2) continue;
+			if (wrong[i]) { act[i] = 0; changed = 1; }
+			else if (viol[i] && !act[i]) { act[i] = viol[i]; r[i] = viol[i] < 0 ? w->l[i] : w->u[i]; changed = 1; }
+		}
+		if (!changed) return 0;
+	}
 }
 
 int or_qp_admm(const or_qp *qp, const or_admm_settings *s, double *xout, or_admm_info *info)
@@ -586,10 +704,16 @@ int or_qp_admm(const or_qp *qp, const or_admm_settings *s, double *xout, or_admm
 		dua_res = w->cinv * scaled_norm_inf(w->Dinv, tmpn, n);
 		if (s->polish && (do_check || last)) {
 			double xpol[MAXN];
-			if (try_polish(w, z, y, xpol, 1e-9)) {
+			const int pr = try_polish(w, z, y, xpol, 1e-9);
+			if (pr == 1) {
 				memcpy(x, xpol, sizeof(double) * n);
 				status = OR_OSQP_SOLVED;
 				rho_updates += 1000; /* marks "ended by polish" in info */
+				break;
+			}
+			if (pr == 2) {
+				status = OR_OSQP_PRIMAL_INFEASIBLE;
+				rho_updates += 2000; /* marks "ended by the Farkas attempt" */
 				break;
 			}
 		}

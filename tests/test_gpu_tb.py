@@ -1,0 +1,72 @@
+"""C4 (BASELINE.json configs[3]): segway time-to-backup-set filter on the GPU vs the oracle.
+
+Branch codes (2 inside the backup set / 1 rows assembled / -3 backup set never reached) and the final
+return codes must be identical.  Rows pass through 300 Euler steps of trig-heavy dynamics with FMA
+contraction and ocml vs glibc transcendentals: compared at rtol 1e-7 (observed ~1e-11); u* <= 1e-6
+against the exact optimum.
+"""
+import numpy as np
+import pytest
+
+import gpu_util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rows_codes_and_diagnostics(hip, oracle):
+    B = 2048
+    out = gpu_util.run_assemble(4, B)
+    model, variant = oracle.CONFIGS[4]
+    o = oracle.default_options(model, variant)
+    A, b, code, diag = oracle.assemble_batch(model, variant, o, np.ascontiguousarray(out["x"].T))
+    assert np.array_equal(out["code"], code)
+    assert {1, 2, -3} <= set(np.unique(code))
+    m = code == 1
+    np.testing.assert_allclose(out["A"].T[m], A[m], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(out["b"].T[m], b[m], rtol=1e-7, atol=1e-9)
+    t = code == 2  # trivial rows: A = 0, b = -inf (1e20)
+    assert np.all(out["A"].T[t] == 0.0) and np.all(out["b"].T[t] == -1e20)
+    np.testing.assert_allclose(out["diag"][0][m], diag[m, 0], rtol=1e-12)  # TTS_
+    np.testing.assert_allclose(out["diag"][1][m], diag[m, 1], rtol=1e-8)   # BTorthoBS_
+    assert np.array_equal(out["diag"][2][m], diag[m, 2])                    # idxHit
+    assert np.all(out["diag"][1][t] == 1.0) and np.all(out["diag"][1][code == -3] == 0.0)
+
+
+@pytest.mark.parametrize("lanes", [2, 4])
+def test_filter_matches_exact_optimum(hip, oracle, lanes):
+    B = 4096
+    s = hip.default_solver(lanes_per_qp=lanes)
+    out = gpu_util.run_filter(4, B, solver=s, uact_init=77.0, relax_init=-7.0)
+    ua, rl, rc = gpu_util.oracle_filter(oracle, 4, out["x"], out["udes"], uact_init=77.0, relax_init=-7.0)
+    assert np.array_equal(out["rc"], rc), f"rc mismatches {(out['rc'] != rc).sum()}"
+    assert (rc == 2).sum() > 500 and (rc == -3).sum() > 1000 and (rc == 1).sum() >= 10
+    assert np.abs(out["uact"] - ua).max() <= 1e-6
+    ok = (rc == 1) | (rc == 2)
+    assert np.abs(out["relax"][:, ok] - rl[:, ok]).max() <= 1e-6
+    assert np.all(out["relax"][:, ~ok] == -7.0)
+
+
+def test_full_size_properties(hip):
+    """One GPU's share of C4 (32 768 instances): fallback = saturated backup controller, solved
+    instances satisfy their rows, halves == whole."""
+    B = 32768
+    out = gpu_util.run_filter(4, B)
+    rows = gpu_util.run_assemble(4, B)
+    rc = out["rc"]
+    assert set(np.unique(rc)) <= {1, 2, -1, -2, -3}
+    x = out["x"]
+    K = np.array([44.7214, 44.6528, 150.1612, 37.6492])
+    xt = x + np.array([0.0, 0.0, -0.1383244254, 0.0])[:, None]
+    ub = np.clip(K @ xt, -20.0, 20.0)
+    fb = rc < 0
+    assert np.allclose(out["uact"][0][fb], ub[fb], rtol=0, atol=1e-12)
+    ok = (rc == 1) | (rc == 2)
+    A = rows["A"].reshape(2, 18, B)
+    lhs = A[0] * out["uact"][0] + A[1] * out["relax"][0]
+    assert (rows["b"] - lhs)[:, ok].max() <= 1e-6
+    inside = rc == 2
+    assert np.allclose(out["uact"][0][inside], np.clip(out["udes"][0][inside], -20, 20), atol=1e-9)
+    h1 = gpu_util.run_filter(4, B // 2, first=0)
+    h2 = gpu_util.run_filter(4, B // 2, first=B // 2)
+    assert np.array_equal(np.concatenate([h1["uact"], h2["uact"]], axis=1), out["uact"])
+    assert np.array_equal(np.concatenate([h1["rc"], h2["rc"]]), rc)
