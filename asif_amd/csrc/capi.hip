@@ -207,6 +207,16 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 		d.ndiag = 3 + d.npBTSS + 1;             // TTS_, BTorthoBS_, idxHit, critical samples, ADMM iterations
 		return ASIF_HIP_OK;
 	}
+	if (model == ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST && variant == ASIF_HIP_ROBUST) {
+		if (o.nHalfPlanes < 1 || o.nHalfPlanes > ASIF_HIP_MAX_HALFPLANES) return ASIF_HIP_EINVAL;
+		d.nx = 2; d.nu = 1;
+		d.npSS = o.nHalfPlanes;                         // npSSmax = npSS
+		d.nv = d.nu + 1 + d.npSS * 2 * (d.nu + 1);      // src/asif_robust.cpp:21
+		d.nc = d.npSS * (1 + (d.nu + 1));               // src/asif_robust.cpp:22
+		d.nrelax = 1;
+		d.ndiag = 1;
+		return ASIF_HIP_OK;
+	}
 	return ASIF_HIP_EINVAL;
 }
 
@@ -301,7 +311,14 @@ extern "C" int asif_hip_update_options(asif_hip_ctx *ctx, const asif_hip_options
 // allocation a filter call can make; size it once with a first call before capturing a graph).
 static int stage_rows(asif_hip_ctx *ctx, FilterArgs &a)
 {
-	const int64_t need = (int64_t)(ctx->dims.nc * ctx->dims.nv + ctx->dims.nc) * a.ld;
+	// the robust filter stages its reduced 2-variable rows (2 x 16 + 16 per instance), which can be
+	// more than nc*nv + nc when there are few half-planes
+	int64_t nA = (int64_t)ctx->dims.nc * ctx->dims.nv, nb = ctx->dims.nc;
+	if (ctx->variant == ASIF_HIP_ROBUST) {
+		if (nA < 2 * 2 * ASIF_HIP_MAX_HALFPLANES) nA = 2 * 2 * ASIF_HIP_MAX_HALFPLANES;
+		if (nb < 2 * ASIF_HIP_MAX_HALFPLANES) nb = 2 * ASIF_HIP_MAX_HALFPLANES;
+	}
+	const int64_t need = (nA + nb) * a.ld;
 	if (need > ctx->s_cap) {
 		if (ctx->s_rows) (void)hipFree(ctx->s_rows);
 		ctx->s_rows = nullptr;
@@ -319,7 +336,7 @@ static int stage_rows(asif_hip_ctx *ctx, FilterArgs &a)
 		ctx->s_code_cap = a.B;
 	}
 	a.A = ctx->s_rows;
-	a.b = ctx->s_rows + (int64_t)ctx->dims.nc * ctx->dims.nv * a.ld;
+	a.b = ctx->s_rows + nA * a.ld;
 	a.code = ctx->s_code;
 	return 0;
 }
@@ -341,6 +358,13 @@ static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipSt
 			if (r) return r;
 		}
 		return launch_tb_segway(ctx->dev, ctx->solver, a, assemble_only, stream);
+	}
+	if (ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST && ctx->variant == ASIF_HIP_ROBUST) {
+		if (!assemble_only) {
+			int r = stage_rows(ctx, a);
+			if (r) return r;
+		}
+		return launch_robust_ip(ctx->dev, ctx->solver, a, assemble_only, stream);
 	}
 	return ASIF_HIP_EINVAL;
 }

@@ -268,4 +268,25 @@ struct Segway {
 	}
 };
 
+// ---------------------------------------------------------------------------------------------
+// Robust inverted pendulum, examples/InvertedPendulum_Robust.cpp:20-79: half-plane safety set
+// 1 - a.x >= 0 (data in DevOptions: the shipped SafetySetData vector is empty, :51) and dynamics in
+// affine arithmetic with the input gain uncertain in [pMin, pMax].  Functor methods that take affine
+// forms are declared in k_robust.hip next to their only user.
+struct InvertedPendulumRobust {
+	static constexpr int NX = 2, NU = 1, MAXNP = ASIF_HIP_MAX_HALFPLANES;
+
+	// :53-61
+	__device__ static void safetySet(const DevOptions &o, const double (&x)[NX], double (&h)[MAXNP],
+	                                 double (&Dh)[MAXNP * NX])
+	{
+		const int N = o.nHalfPlanes;
+		for (int i = 0; i < N; i++) {
+			h[i] = 1. - o.halfPlanes[2 * i] * x[0] - o.halfPlanes[2 * i + 1] * x[1];
+			Dh[i] = -o.halfPlanes[2 * i];
+			Dh[i + N] = -o.halfPlanes[2 * i + 1];
+		}
+	}
+};
+
 } // namespace asif
