@@ -1,0 +1,56 @@
+"""Multi-GPU plumbing: the batch axis shards embarrassingly, so the only distributed
+pieces are the rendezvous, the barrier around the timed region and the max-over-ranks of the elapsed
+time.  There is no data-path collective.  backend "nccl" is RCCL on ROCm; tests use "gloo" on CPU.
+"""
+import os
+
+import torch
+
+
+class Group:
+    def __init__(self, backend=None):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            backend = backend or "nccl"
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+            dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+            self.dist = dist
+            self.backend = backend
+
+    def shard(self, per_rank_batch):
+        """(first instance, count) of this rank's slice of the seeded instance stream: rank r owns
+        [r*B, (r+1)*B) -- weak scaling, every rank the same amount of work."""
+        return self.rank * per_rank_batch, per_rank_batch
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, value, device=None):
+        if self.dist is None:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, value, device=None):
+        if self.dist is None:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+            self.dist = None

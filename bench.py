@@ -3,12 +3,12 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--batch B]
 
-One "step" = one pass of the fused filter kernel (constraint assembly + in-kernel ADMM solve +
-saturation + return code) over one batch of synthetic states that is already resident in HBM.
+One "step" = one pass of the filter (constraint assembly + in-kernel ADMM solve + saturation + return
+code) over one batch of synthetic states that is already resident in HBM when the timed region starts.
 Default workload: BASELINE.json configs[1] -- DoubleIntegrator explicit CBF, batch 65 536 per GPU.
-N > 1: one process per GPU (torchrun), the batch axis is sharded -- every rank owns its own
-65 536 seeded instances (weak scaling), no data-path collective; torch.distributed is used only for
-the barrier and the max-over-ranks of the elapsed time.
+N > 1: one process per GPU (torchrun), the batch axis is sharded -- every rank owns its own slice of
+the seeded instance stream (weak scaling), no data-path collective; torch.distributed (RCCL) is used
+only for the barrier and the max-over-ranks of the elapsed time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -24,44 +24,49 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from asif_amd import capi, workloads  # noqa: E402
+from asif_amd import capi, dist, workloads  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
-# algorithmic HBM bytes per instance of the fused state->input path: read 8(nx+nu),
-# write 8(nu+nrelax)+4
+# algorithmic HBM bytes per instance of the state->input path: read 8(nx+nu), write 8(nu+nrelax)+4
 ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44}
 WORKLOAD = {
     2: "C2 DoubleIntegrator explicit CBF (ASIF::filter), seeded x in U[-1.2,1.2]^2, uDes in U[-1.5,1.5]",
     3: "C3 InvertedPendulum_Implicit (ASIFimplicit::filter, 5001-step backup trajectory)",
-    4: "C4 segway_implicit_tb (ASIFimplicitTB::filter, 316-step backup trajectory)",
+    4: "C4 segway_implicit_tb (ASIFimplicitTB::filter, 316-step backup trajectory), one GPU's share",
     5: "C5 InvertedPendulum_Robust (ASIFrobust::filter, affine-arithmetic rows, nv=18 nc=12)",
 }
 
 
+def host_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))  # the GPU box's CPU share for one GPU is 16
+
+
 def cpu_baseline(cfg, gpu_uact, gpu_rc, x, udes):
     """Rank 0, N=1 only: the oracle's OSQP-style restatement (OSQP 0.6 defaults, cold start) timed on
-    the host cores over a bounded sample of the same workload, plus the parity numbers the metric
-    asks for (max|u - u_ref| against the exact optimum, rc mismatches)."""
+    the host cores over a bounded sample of the same workload, plus the parity numbers the metric asks
+    for (max|u - u_ref| against the exact optimum, rc mismatches) with the oracle as the checker."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     O.build()
     model, variant = O.CONFIGS[cfg]
     o = O.default_options(model, variant)
-    cores = os.cpu_count() or 1
-    # size the sample for roughly 10 s of CPU work from a short probe
+    cores = host_cores()
     probe = {2: 20000, 3: 16, 4: 256, 5: 2000}[cfg]
     xs, us = O.make_batch(cfg, probe)
     t = time.perf_counter()
     O.filter_batch(model, variant, o, xs, us, O.SOLVER_ADMM, None, 1)
     per = (time.perf_counter() - t) / probe
-    n = int(max(cores * 64, min(10.0 / per, 4e6)))
+    n = int(max(cores * 16, min(15.0 / per, 4e6)))  # about 15 s of CPU work in total
     xs, us = O.make_batch(cfg, n)
     t = time.perf_counter()
     O.filter_batch(model, variant, o, xs, us, O.SOLVER_ADMM, None, cores)
     dt = time.perf_counter() - t
-    # parity of the GPU result on the first instances of the bench batch (oracle = checker)
-    m = min(x.shape[1], {2: 65536, 3: 256, 4: 8192, 5: 8192}[cfg])
+    m = min(x.shape[1], {2: 65536, 3: 512, 4: 16384, 5: 8192}[cfg])
     ua, _, rc = O.filter_batch(model, variant, o, np.ascontiguousarray(x[:, :m].T),
                                np.ascontiguousarray(udes[:, :m].T), O.SOLVER_EXACT, None, cores,
                                uact_init=np.zeros((m, 1)))
@@ -70,7 +75,8 @@ def cpu_baseline(cfg, gpu_uact, gpu_rc, x, udes):
     mism = int((rc != gpu_rc[:m]).sum())
     return ({"value": n / dt, "unit": "QP solves/s", "cores": cores, "kind": "port",
              "sample": f"{n} instances of the same seeded workload, OSQP-style ADMM restatement "
-                       f"(eps 1e-3, max_iter 2000, cold start) over {cores} host threads"},
+                       f"(eps 1e-3, max_iter 2000, cold start, {per * 1e6:.2f} us per filter() on one core) "
+                       f"over {cores} host threads"},
             {"max_abs_u_err_vs_exact": err, "rc_mismatches": mism, "checked_instances": m})
 
 
@@ -85,19 +91,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    else:
+    grp = dist.Group(backend="nccl")
+    if grp.world == 1:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", grp.local_rank if grp.world > 1 else 0)
 
     cfg = args.config
     model, variant, default_b = capi.CONFIGS[cfg]
@@ -105,48 +102,39 @@ def main():
     solver = capi.default_solver(lanes_per_qp=args.lanes)
     flt = capi.Filter(model, variant, solver=solver, device=dev.index)
     d = flt.dims
-    # shard = this rank's own slice of the seeded instance stream (weak scaling, no collective)
-    x, udes = workloads.make_batch(cfg, B, first=rank * B)
+    first, count = grp.shard(B)  # this rank's own slice of the seeded instance stream
+    x, udes = workloads.make_batch(cfg, count, first=first)
     tx = torch.from_numpy(x).to(dev)
     tu = torch.from_numpy(udes).to(dev)
     uact = torch.zeros((d.nu, B), dtype=torch.float64, device=dev)
     relax = torch.zeros((d.nrelax, B), dtype=torch.float64, device=dev)
     rc = torch.zeros(B, dtype=torch.int32, device=dev)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         flt.filter(tx, tu, uact, relax, rc)
-    barrier()
-    # per-launch device durations from HIP events on the launch stream (torch's current stream)
+    grp.barrier()
+    # per-step device durations from HIP events on the launch stream (torch's current stream, which is
+    # the stream handed to the library)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
         flt.filter(tx, tu, uact, relax, rc)
         ev[k][1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    grp.barrier()
+    elapsed = grp.max_over_ranks(time.perf_counter() - t0, device=dev if grp.world > 1 else None)
+    step_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
 
     rc_host = rc.cpu().numpy()
     solved = int(np.isin(rc_host, (1, 2, -1)).sum())
-    total_instances = B * world * args.steps
-    value = total_instances / elapsed
+    value = B * grp.world * args.steps / elapsed
     alg_bytes = ALG_BYTES[cfg] * B
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    achieved = alg_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
     out = {
         "metric": "QP solves/sec (batched filter())",
         "value": value,
         "unit": "QP solves/s",
-        "n_gpus": world,
+        "n_gpus": grp.world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
@@ -161,19 +149,18 @@ def main():
                    "qp_solved_fraction": solved / B},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel_avg_us": kern_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "FP64-VALU/latency bound by design (44-60 B per instance); see DESIGN.md"},
+                     "kernel_avg_us": step_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "FP64-VALU/latency bound by design (44-60 algorithmic bytes per instance); see DESIGN.md"},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if grp.rank == 0 and grp.world == 1 and not args.no_cpu_baseline:
         base, parity = cpu_baseline(cfg, uact.cpu().numpy(), rc_host, x, udes)
         out["cpu_baseline"] = base
         out["parity"] = parity
-    elif rank == 0:
+    elif grp.rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0:
+    if grp.rank == 0:
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

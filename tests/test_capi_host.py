@@ -1,0 +1,80 @@
+"""The C-ABI library without a GPU: it loads, exports every function include/asif_hip.h declares,
+its host-side option/dimension logic matches the oracle's restatement of the reference constructors,
+and it FAILS LOUDLY (no CPU fallback) when no gfx950 device is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__  # builds in-tree if needed
+    from asif_amd import capi
+    if not os.path.exists(capi.LIB_PATH):
+        __graft_entry__.build()
+    capi.load()
+    return capi
+
+
+def test_exports_every_declared_symbol(capi):
+    header = open(os.path.join(ROOT, "include", "asif_hip.h")).read()
+    declared = set(re.findall(r"\b(asif_hip_[a-z_]+)\s*\(", header))
+    assert len(declared) >= 12
+    lib = capi.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(capi.EXPORTS)
+    assert lib.asif_hip_version() >= 100
+    assert b"gfx950" in lib.asif_hip_error_string(-2)
+
+
+def test_default_options_match_oracle(capi, oracle):
+    for cfg, (model, variant, _) in capi.CONFIGS.items():
+        o = capi.default_options(model, variant)
+        ref = oracle.default_options(*oracle.CONFIGS[cfg])
+        for name, _ in capi.Options._fields_:
+            a, b = getattr(o, name), getattr(ref, name)
+            if hasattr(a, "__len__"):
+                assert list(a) == list(b), (cfg, name)
+            else:
+                assert a == b, (cfg, name)
+
+
+def test_struct_layouts_match_header(capi):
+    # sizes the C compiler gives the same structs (gcc on the public header)
+    import subprocess, tempfile
+    src = '#include "asif_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu\\n",sizeof(asif_hip_options),sizeof(asif_hip_solver),sizeof(asif_hip_dims));return 0;}\n'
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "s.c")
+        open(p, "w").write(src)
+        exe = os.path.join(td, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), p, "-o", exe])
+        sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    assert sizes == [C.sizeof(capi.Options), C.sizeof(capi.Solver), C.sizeof(capi.Dims)]
+
+
+def test_no_gpu_means_loud_failure(capi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.AsifHipError):
+        capi.Filter(capi.MODEL_DOUBLE_INTEGRATOR, capi.EXPLICIT)
+    lib = capi.load()
+    s = capi.default_solver()
+    r = lib.asif_hip_qp_solve_batch(0, C.byref(s), 4, 4, 2, 4, *([C.c_void_p(8)] * 6), None, C.c_void_p(8),
+                                    C.c_void_p(8), None, None)
+    assert r == -2  # ASIF_HIP_ENODEVICE
+
+
+def test_bad_arguments_are_rejected(capi):
+    lib = capi.load()
+    assert lib.asif_hip_default_options(99, 0, C.byref(capi.Options())) == -1
+    assert lib.asif_hip_default_solver(None) == -1
+    h = C.c_void_p()
+    assert lib.asif_hip_create(C.byref(h), 0, 3, None, None, 0) != 0  # DoubleIntegrator has no robust variant
+    assert not h.value

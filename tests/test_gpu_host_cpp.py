@@ -1,0 +1,47 @@
+"""C1 (BASELINE.json configs[0]): the reference's DoubleIntegrator closed loop, single agent, on this
+build's C++ mirror of the reference API (ASIF::ASIF + ASIF::QPWrapperHip, asif_amd/host/).  The program
+is the drop-in test: same constructor, initialize(), filter() and plant integration as
+examples/DoubleIntegrator.cpp:63-116, first 2500 steps.  Compared step by step with the oracle's closed
+loop (exact QP optimum): |uAct - u_ref| <= 1e-6 (north star 1e-5), identical rc, state within 1e-9.
+It also pushes 256 copies of the state through filterBatch() every 100 steps (must equal filter())."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "asif_amd", "host")
+
+
+def test_double_integrator_closed_loop(hip, oracle):
+    exe = os.path.join(HOST, "double_integrator")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HOST, "-s"])
+    steps = 2500
+    out = subprocess.run([exe, "--steps", str(steps), "--batch", "256"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = np.array([[float(v) for v in line.split(",")] for line in out.stdout.strip().split("\n")[1:]])
+    assert rows.shape == (steps, 7)
+    model, variant = oracle.CONFIGS[2]
+    o = oracle.default_options(model, variant)
+    # Per step, on the state the program was actually in: its input must be the exact optimum.
+    # (A free-running second closed loop is not comparable to 1e-6: as the agent comes to rest at the
+    # wall, Lgh = -v -> 0 and du/dx grows without bound, so 1e-16 differences are amplified.)
+    xprev = np.vstack([[0.0, 0.0], rows[:-1, 1:3]])
+    ua, rl, rc = oracle.filter_batch(model, variant, o, xprev, np.ones((steps, 1)), oracle.SOLVER_EXACT)
+    assert np.array_equal(rows[:, 6].astype(int), rc) and np.all(rc == 1)
+    assert np.abs(rows[:, 4] - ua[:, 0]).max() <= 1e-6
+    assert np.abs(rows[:, 5] - 5.0).max() <= 1e-9  # pinned relaxation variable
+    # plant integration of the example (explicit Euler, dt = 1 ms) reproduced from its own inputs
+    xn = xprev + 0.001 * np.stack([xprev[:, 1], rows[:, 4]], axis=1)
+    assert np.abs(xn - rows[:, 1:3]).max() <= 1e-15
+    # and the free-running oracle loop agrees while the loop gain is still moderate
+    x = np.zeros(2)
+    for k in range(800):
+        u1, _, _ = oracle.filter_batch(model, variant, o, x[None, :], np.array([[1.0]]), oracle.SOLVER_EXACT)
+        x = x + 0.001 * np.array([x[1], u1[0, 0]])
+        assert np.abs(rows[k, 1:3] - x).max() <= 1e-9
+    # the filter must have intervened: uDes = 1 drives the agent towards the x = 1 wall
+    assert rows[:, 4].min() < 0.0 and rows[:, 1].max() < 1.0 + 1e-6

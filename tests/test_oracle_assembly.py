@@ -1,0 +1,75 @@
+"""Oracle assembly (oracle/or_assembly.c) against the known answers SURVEY.md 8(c) recorded from the
+reference code, plus properties that hold for any correct restatement."""
+import json
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_survey_known_answers(oracle):
+    g = json.load(open(os.path.join(GOLD, "survey_known_answers.json")))
+    di = g["double_integrator_explicit"]
+    o = oracle.default_options(oracle.MODEL_DI, oracle.VAR_EXPLICIT)
+    A, b, code, _ = oracle.assemble_batch(oracle.MODEL_DI, oracle.VAR_EXPLICIT, o, np.array([di["x"]]))
+    assert np.array_equal(A[0], np.array(di["A_colmajor_4x2"]))
+    assert np.array_equal(b[0], np.array(di["b"]))
+
+    ip = g["inverted_pendulum_implicit"]
+    o = oracle.default_options(oracle.MODEL_IP, oracle.VAR_IMPLICIT)
+    d = oracle.dims(oracle.MODEL_IP, oracle.VAR_IMPLICIT, o)
+    assert (d.nv, d.nc, d.npBT) == (3, 41, 5001)
+    A, b, code, _ = oracle.assemble_batch(oracle.MODEL_IP, oracle.VAR_IMPLICIT, o, np.array([ip["x"]]))
+    crit = oracle.last_crit_idx()
+    assert sorted(crit) == sorted(ip["reference_critical_indices"])
+    A = A[0].reshape(3, 41).T
+    for row, key in ((4, "sample1_h0_row"), (6, "sample1_h2_row"), (40, "backup_row")):
+        assert np.array_equal(A[row], np.array(ip[key]["A"])), key
+        assert b[0][row] == ip[key]["b"], key
+
+
+def test_implicit_rows_are_directional_derivatives(oracle):
+    """Row = grad h_i(phi_t(x)) Q_t: its contraction with g must equal the finite-difference derivative
+    of h_i(phi_t(x + eps g)) -- an independent check of the sensitivity integration."""
+    model, variant = oracle.MODEL_IP, oracle.VAR_IMPLICIT
+    o = oracle.default_options(model, variant)
+    o.backTrajHorizon = 0.5  # shorter trajectory: the check is about the formula, not the length
+    x = np.array([[0.4, -0.3], [-0.9, 0.8], [1.2, 0.2]])
+    eps = 1e-6
+    g = np.array([0.0, 1.0])
+    A0, b0, _, _ = oracle.assemble_batch(model, variant, o, x)
+    Ap, _, _, _ = oracle.assemble_batch(model, variant, o, x + eps * g)
+    Am, _, _, _ = oracle.assemble_batch(model, variant, o, x - eps * g)
+    for k in range(len(x)):
+        a0, ap, am = (M[k].reshape(3, 41).T for M in (A0, Ap, Am))
+        hcol0, hcolp, hcolm = (np.where(np.arange(41) < 40, a[:, 1], a[:, 2]) for a in (a0, ap, am))
+        fd = (hcolp - hcolm) / (2 * eps)
+        np.testing.assert_allclose(a0[:, 0], fd, rtol=2e-5, atol=2e-7)
+
+
+def test_tb_branches_and_codes(oracle):
+    model, variant = oracle.MODEL_SEGWAY, oracle.VAR_TB
+    o = oracle.default_options(model, variant)
+    d = oracle.dims(model, variant, o)
+    assert (d.nv, d.nc, d.npBT) == (2, 18, 316)
+    x, u = oracle.make_batch(4, 2048)
+    A, b, code, diag = oracle.assemble_batch(model, variant, o, x)
+    frac = {c: float((code == c).mean()) for c in (2, 1, -3)}
+    # ~32 % inside the backup set, ~1 % assembled, ~66 % never reach it
+    assert 0.25 < frac[2] < 0.40 and 0.003 < frac[1] < 0.03 and 0.55 < frac[-3] < 0.75
+    t = code == 2
+    assert np.all(A[t] == 0) and np.all(b[t] == -1e20) and np.all(diag[t, 1] == 1.0)
+    m = code == 1
+    assert np.all(diag[m, 2] >= 1) and np.all(diag[m, 0] > 0)
+    # inside the backup set at x = 0
+    A0, b0, c0, _ = oracle.assemble_batch(model, variant, o, np.zeros((1, 4)))
+    assert c0[0] == 2
+
+
+def test_rng_and_workloads_match_product_side(oracle):
+    from asif_amd import workloads
+    for cfg in (2, 3, 4, 5):
+        x, u = oracle.make_batch(cfg, 777, first=4242)
+        x2, u2 = workloads.make_batch(cfg, 777, first=4242)
+        assert np.array_equal(x.T, x2) and np.array_equal(u.T, u2)
