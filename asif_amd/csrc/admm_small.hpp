@@ -43,25 +43,48 @@ constexpr int kStatusMaxIter = -2;
 constexpr int kStatusPrimalInf = -3;
 constexpr int kStatusDualInf = -4;
 
+// Cross-lane exchange inside a group of G <= 16 consecutive lanes by DPP (data-parallel primitives:
+// the permutation rides on the VALU operand fetch, no LDS crossbar round trip like ds_bpermute).
+// Butterfly stage m: 1 -> quad_perm[1,0,3,2], 2 -> quad_perm[2,3,0,1]; after those two all four lanes
+// of a quad agree, so stage 4 may use row_half_mirror (i <-> 7-i) and stage 8 row_mirror (i <-> 15-i).
+template <int M>
+__device__ __forceinline__ int dpp_xchg(int v)
+{
+	constexpr int ctrl = M == 1 ? 0xB1 : (M == 2 ? 0x4E : (M == 4 ? 0x141 : 0x140));
+	return __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false);
+}
+template <int M>
+__device__ __forceinline__ double dpp_xchg(double v)
+{
+	const int lo = dpp_xchg<M>(__double2loint(v)), hi = dpp_xchg<M>(__double2hiint(v));
+	return __hiloint2double(hi, lo);
+}
 template <int G>
 __device__ __forceinline__ double gsum(double v)
 {
-#pragma unroll
-	for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
+	static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "lanes per QP");
+	if (G >= 2) v += dpp_xchg<1>(v);
+	if (G >= 4) v += dpp_xchg<2>(v);
+	if (G >= 8) v += dpp_xchg<4>(v);
+	if (G >= 16) v += dpp_xchg<8>(v);
 	return v;
 }
 template <int G>
 __device__ __forceinline__ double gmax(double v)
 {
-#pragma unroll
-	for (int m = 1; m < G; m <<= 1) v = fmax(v, __shfl_xor(v, m, 64));
+	if (G >= 2) v = fmax(v, dpp_xchg<1>(v));
+	if (G >= 4) v = fmax(v, dpp_xchg<2>(v));
+	if (G >= 8) v = fmax(v, dpp_xchg<4>(v));
+	if (G >= 16) v = fmax(v, dpp_xchg<8>(v));
 	return v;
 }
 template <int G>
 __device__ __forceinline__ int gand(int p)
 {
-#pragma unroll
-	for (int m = 1; m < G; m <<= 1) p &= __shfl_xor(p, m, 64);
+	if (G >= 2) p &= dpp_xchg<1>(p);
+	if (G >= 4) p &= dpp_xchg<2>(p);
+	if (G >= 8) p &= dpp_xchg<4>(p);
+	if (G >= 16) p &= dpp_xchg<8>(p);
 	return p;
 }
 
@@ -157,6 +180,8 @@ struct AdmmSmall {
 	// rho + factor
 	double rho, rinv, rinv_eq, rb[NV], rbinv[NV];
 	double L[NV][NV], Dinv[NV];
+	// diagnostics: working-set solves and certificate iterations this lane went through
+	int stat_rounds, stat_farkas;
 
 	__device__ __forceinline__ void load_and_scale(const QpLaneData<NV, RPL> &in, int iters)
 	{
@@ -340,6 +365,7 @@ struct AdmmSmall {
 		int verdict = 0;
 #pragma unroll 1
 		for (int round = 0; round <= rounds; round++) {
+			stat_rounds++;
 			// -- equality-constrained solve on the working set
 			double Mp[NV][NV], Mi[NV];
 #pragma unroll
@@ -395,9 +421,9 @@ struct AdmmSmall {
 				}
 			}
 			// -- classify every row at xp; build the corrected working set
-			int nact[RPL], nactb[NV];
+			int nact[RPL], nactb[NV], sideb[NV];
 			bool viol_active = false, changed = false;
-			double g[NV], gm[NV];
+			double g[NV], gm[NV], vm[RPL], vmb[NV], worst = 0.0;
 #pragma unroll
 			for (int j = 0; j < NV; j++) { g[j] = 0.0; gm[j] = 0.0; }
 #pragma unroll
@@ -410,8 +436,10 @@ struct AdmmSmall {
 				const bool wrong = act[r] == -1 && nu[r] > kPolishKktTol * (1.0 + fabs(nu[r]));
 				ok = ok && !below && !above && !wrong;
 				viol_active = viol_active || ((below || above) && act[r] != 0);
-				nact[r] = eqr[r] ? 2 : (wrong ? 0 : ((below && act[r] == 0) ? -1 : act[r]));
+				nact[r] = eqr[r] ? 2 : (wrong ? 0 : act[r]);
 				changed = changed || (nact[r] != act[r]);
+				vm[r] = (below && act[r] == 0) ? l[r] - ax : 0.0; // candidate to join, by violation
+				worst = fmax(worst, vm[r]);
 #pragma unroll
 				for (int j = 0; j < NV; j++) {
 					const double t = act[r] ? A[r][j] * nu[r] : 0.0;
@@ -428,8 +456,11 @@ struct AdmmSmall {
 				const bool wrong = (actb[j] == -1 && nub[j] > nt) || (actb[j] == 1 && nub[j] < -nt);
 				ok = ok && !below && !above && !wrong;
 				viol_active = viol_active || ((below || above) && actb[j] != 0);
-				nactb[j] = actb[j] == 2 ? 2 : (wrong ? 0 : ((actb[j] == 0 && below) ? -1 : ((actb[j] == 0 && above) ? 1 : actb[j])));
+				nactb[j] = actb[j] == 2 ? 2 : (wrong ? 0 : actb[j]);
 				changed = changed || (nactb[j] != actb[j]);
+				vmb[j] = (actb[j] == 0 && below) ? lbs[j] - ax : ((actb[j] == 0 && above) ? ax - ubs[j] : 0.0);
+				sideb[j] = above ? 1 : -1;
+				worst = fmax(worst, vmb[j]);
 				// stationarity, relative to the size of its own terms (a column can be scaled very small)
 				const double tb = actb[j] ? Ab[j] * nub[j] : 0.0;
 				const double gj = gsum<G>(g[j]) + P[j] * xp[j] + q[j] + tb;
@@ -447,7 +478,8 @@ struct AdmmSmall {
 				for (int j = 0; j < NV; j++) fab[j] = actb[j];
 				bool cert = false;
 #pragma unroll 1
-				for (int fi = 0; fi <= 4; fi++) {
+				for (int fi = 0; fi <= 2; fi++) {
+					stat_farkas++;
 					double Ms[NV][NV], Msi[NV], wv[NV], dmax = 0.0;
 #pragma unroll
 					for (int a = 0; a < NV; a++)
@@ -538,12 +570,15 @@ struct AdmmSmall {
 				}
 				if (cert) { verdict = 2; break; }
 			}
-			if (gand<G>(changed ? 0 : 1)) break; // nothing to correct: leave it to ADMM
+			// of the rows found violated only the most violated one(s) join: the working set then stays
+			// consistent on feasible problems and an inconsistency points at a genuine conflict
+			worst = gmax<G>(worst);
+			if (gand<G>((changed || worst > 0.0) ? 0 : 1)) break; // nothing to correct: leave it to ADMM
 #pragma unroll
-			for (int r = 0; r < RPL; r++) act[r] = nact[r];
+			for (int r = 0; r < RPL; r++) act[r] = (worst > 0.0 && vm[r] == worst) ? -1 : nact[r];
 #pragma unroll
 			for (int j = 0; j < NV; j++) {
-				actb[j] = nactb[j];
+				actb[j] = (worst > 0.0 && vmb[j] == worst) ? sideb[j] : nactb[j];
 				rtb[j] = actb[j] == 1 ? ubs[j] : lbs[j];
 			}
 		}
@@ -563,6 +598,8 @@ struct AdmmSmall {
 		for (int r = 0; r < RPL; r++) { z[r] = 0.0; y[r] = 0.0; dy[r] = 0.0; }
 		status = 0;
 		iters = 0;
+		stat_rounds = 0;
+		stat_farkas = 0;
 		bool fact_ok = set_rho_and_factor(S_.rho, S_.sigma);
 		const double cinv = pow2_inv(cs);
 		int it = 0;

@@ -121,7 +121,7 @@ extern "C" int asif_hip_default_solver(asif_hip_solver *s)
 	s->eps_dual_inf = 1e-4;
 	s->adaptive_rho_tolerance = 5.0;
 	s->max_iter = 4000;
-	s->check_interval = 5;
+	s->check_interval = 2;
 	s->scaling_iters = 4;
 	s->polish = 1;
 	s->active_set_rounds = 12;
@@ -164,7 +164,7 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 		d.nv = d.nu + 1;  // src/asif.cpp:19
 		d.nc = d.npSS;    // src/asif.cpp:21-22 (npSSmax = -1 clamps to npSS)
 		d.nrelax = 1;
-		d.ndiag = 1;
+		d.ndiag = 3; // working-set solves, certificate iterations, ADMM iterations
 		return ASIF_HIP_OK;
 	}
 	if (model == ASIF_HIP_MODEL_INVERTED_PENDULUM && variant == ASIF_HIP_IMPLICIT) {

@@ -103,7 +103,11 @@ __global__ __launch_bounds__(64) void explicit_filter_kernel(DevOptions o, asif_
 		} else {
 			a.rc[i] = ASIF_HIP_RC_QP_FAILED; // uAct and relax stay untouched, src/asif.cpp:208-209
 		}
-		if (a.diag) a.diag[(a.ndiag - 1) * a.ld + i] = (double)iters;
+		if (a.diag) {
+			a.diag[0 * a.ld + i] = (double)admm.stat_rounds;
+			a.diag[1 * a.ld + i] = (double)admm.stat_farkas;
+			a.diag[(a.ndiag - 1) * a.ld + i] = (double)iters;
+		}
 	}
 }
 

@@ -30,6 +30,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 # algorithmic HBM bytes per instance of the state->input path: read 8(nx+nu), write 8(nu+nrelax)+4
 ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44}
+PMC_SUMMARY = {2: "r01/c2_v1_pmc_summary.json"}
 WORKLOAD = {
     2: "C2 DoubleIntegrator explicit CBF (ASIF::filter), seeded x in U[-1.2,1.2]^2, uDes in U[-1.5,1.5]",
     3: "C3 InvertedPendulum_Implicit (ASIFimplicit::filter, 5001-step backup trajectory)",
@@ -110,26 +111,62 @@ def main():
     relax = torch.zeros((d.nrelax, B), dtype=torch.float64, device=dev)
     rc = torch.zeros(B, dtype=torch.int32, device=dev)
 
+    # Hot loop: one C-ABI call per step with every argument marshalled once (a Python-side wrapper per
+    # call costs more than this 20 us kernel).
+    import ctypes as C
+    fn = flt.lib.asif_hip_filter_batch
+    stream = torch.cuda.current_stream()
+    call_args = (flt.handle, B, tx.stride(0), C.c_void_p(tx.data_ptr()), C.c_void_p(tu.data_ptr()),
+                 C.c_void_p(uact.data_ptr()), C.c_void_p(relax.data_ptr()), C.c_void_p(rc.data_ptr()), None,
+                 C.c_void_p(stream.cuda_stream))
+
+    def step():
+        r = fn(*call_args)
+        if r != 0:
+            capi.check(r)
+
     for _ in range(args.warmup):
-        flt.filter(tx, tu, uact, relax, rc)
+        step()
     grp.barrier()
     # per-step device durations from HIP events on the launch stream (torch's current stream, which is
     # the stream handed to the library)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # (raw hipEvent* through ctypes: a torch.cuda.Event.record costs more host time than this kernel runs)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+    hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+    # One event pair brackets the K back-to-back launches: an event between every two kernels puts a
+    # barrier packet into the queue and stretches a 19 us step to 27 us.  average launch duration =
+    # device time between the two events / K (includes the ~1 us launch-to-launch gap).
+    ev = []
+    for _ in range(2):
+        e = C.c_void_p()
+        assert hip.hipEventCreate(C.byref(e)) == 0
+        ev.append(e)
+    sptr = C.c_void_p(stream.cuda_stream)
     t0 = time.perf_counter()
+    hip.hipEventRecord(ev[0], sptr)
     for k in range(args.steps):
-        ev[k][0].record()
-        flt.filter(tx, tu, uact, relax, rc)
-        ev[k][1].record()
+        step()
+    hip.hipEventRecord(ev[1], sptr)
     grp.barrier()
     elapsed = grp.max_over_ranks(time.perf_counter() - t0, device=dev if grp.world > 1 else None)
-    step_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
+    ms = C.c_float()
+    assert hip.hipEventElapsedTime(C.byref(ms), ev[0], ev[1]) == 0
+    for e in ev:
+        hip.hipEventDestroy(e)
+    step_ms = ms.value / max(args.steps, 1)
 
     rc_host = rc.cpu().numpy()
     solved = int(np.isin(rc_host, (1, 2, -1)).sum())
     value = B * grp.world * args.steps / elapsed
     alg_bytes = ALG_BYTES[cfg] * B
     achieved = alg_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
+    # HBM traffic per launch: rocprofv3 PMC passes cannot run inside this process; the number comes from
+    # the committed summary of the same command (profiles/, FETCH_SIZE x2 + WRITE_SIZE, in bytes)
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY.get(cfg, ""))
+    if B == default_b and os.path.isfile(pmc):
+        traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
     out = {
         "metric": "QP solves/sec (batched filter())",
         "value": value,
@@ -148,7 +185,7 @@ def main():
                    "rc_histogram": {str(int(k)): int(v) for k, v in zip(*np.unique(rc_host, return_counts=True))},
                    "qp_solved_fraction": solved / B},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_avg_us": step_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "FP64-VALU/latency bound by design (44-60 algorithmic bytes per instance); see DESIGN.md"},
     }

@@ -433,7 +433,7 @@ static int g_as_refine = 3; /* refinement steps of the regularised solve (device
 
 /* returns 1 valid KKT point; 0 otherwise with viol[i] (-1 below l, +1 above u) and wrong[i] filled */
 static int as_solve(const ws_t *w, const int *act, const double *r, double *x, double *nu, int *viol, int *wrong,
-                    double ktol)
+                    double *vmag, double ktol)
 {
 	const int n = w->n, m = w->m;
 	const double delta = 1e-6;
@@ -446,7 +446,7 @@ static int as_solve(const ws_t *w, const int *act, const double *r, double *x, d
 			/* primal regularisation only where the cost has no curvature of its own */
 			M[a * n + b] = sacc / delta + (a == b ? (w->P[a] > 0 ? w->P[a] : delta) : 0.0);
 		}
-	for (int i = 0; i < m; i++) { nu[i] = 0; viol[i] = 0; wrong[i] = 0; }
+	for (int i = 0; i < m; i++) { nu[i] = 0; viol[i] = 0; wrong[i] = 0; vmag[i] = 0; }
 	for (int j = 0; j < n; j++) x[j] = 0;
 	if (!small_ldl(n, M, Dg)) return 0;
 	for (int it = 0; it < g_as_refine; it++) {
@@ -472,8 +472,8 @@ static int as_solve(const ws_t *w, const int *act, const double *r, double *x, d
 		double ax = 0;
 		for (int j = 0; j < n; j++) ax += w->A[i * n + j] * x[j];
 		const double tol = ktol * (1 + fabs(ax));
-		if (ax < w->l[i] - tol) { viol[i] = -1; bad = 1; }
-		else if (ax > w->u[i] + tol) { viol[i] = 1; bad = 1; }
+		if (ax < w->l[i] - tol) { viol[i] = -1; bad = 1; vmag[i] = w->l[i] - ax; }
+		else if (ax > w->u[i] + tol) { viol[i] = 1; bad = 1; vmag[i] = ax - w->u[i]; }
 		const double nt = ktol * (1 + fabs(nu[i]));
 		if ((act[i] == -1 && nu[i] > nt) || (act[i] == 1 && nu[i] < -nt)) { wrong[i] = 1; bad = 1; }
 	}
@@ -496,7 +496,7 @@ static int as_solve(const ws_t *w, const int *act, const double *r, double *x, d
  * then S := rows violated there, equalities always in).  At a stationary S every residual has the
  * sign of a violation, A_S' v = 0 by construction and sum r_i v_i = |v|^2 > 0: v is a Farkas
  * certificate as soon as it is not (numerically) zero.  `act0` seeds S. */
-static int g_farkas_iters = 4;
+static int g_farkas_iters = 2;
 static int as_farkas(const ws_t *w, const int *act0, const double *r0)
 {
 	const int n = w->n, m = w->m;
@@ -572,7 +572,7 @@ static int try_polish(const ws_t *w, const double *z, const double *y, double *x
 {
 	const int n = w->n, m = w->m;
 	int act[MAXM], viol[MAXM], wrong[MAXM];
-	double r[MAXM], nu[MAXM], x[MAXN];
+	double r[MAXM], nu[MAXM], x[MAXN], vmag[MAXM];
 	for (int i = 0; i < m; i++) {
 		act[i] = 0;
 		r[i] = 0;
@@ -581,7 +581,7 @@ static int try_polish(const ws_t *w, const double *z, const double *y, double *x
 		else if (w->u[i] - z[i] < y[i]) { act[i] = 1; r[i] = w->u[i]; }
 	}
 	for (int round = 0;; round++) {
-		if (as_solve(w, act, r, x, nu, viol, wrong, ktol)) {
+		if (as_solve(w, act, r, x, nu, viol, wrong, vmag, ktol)) {
 			for (int j = 0; j < n; j++) xpol[j] = x[j];
 			return 1;
 		}
@@ -594,8 +594,18 @@ static int try_polish(const ws_t *w, const double *z, const double *y, double *x
 		for (int i = 0; i < m; i++) {
 			if (act[i] == 2) continue;
 			if (wrong[i]) { act[i] = 0; changed = 1; }
-			else if (viol[i] && !act[i]) { act[i] = viol[i]; r[i] = viol[i] < 0 ? w->l[i] : w->u[i]; changed = 1; }
 		}
+		/* of the rows found violated only the most violated one(s) join: the working set then stays
+		 * consistent on feasible problems and an inconsistency points at a genuine conflict */
+		double worst = 0;
+		for (int i = 0; i < m; i++)
+			if (viol[i] && !act[i] && vmag[i] > worst) worst = vmag[i];
+		for (int i = 0; i < m; i++)
+			if (viol[i] && !act[i] && worst > 0 && vmag[i] == worst) {
+				act[i] = viol[i];
+				r[i] = viol[i] < 0 ? w->l[i] : w->u[i];
+				changed = 1;
+			}
 		if (!changed) return 0;
 	}
 }
