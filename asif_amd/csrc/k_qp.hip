@@ -3,8 +3,11 @@
 // cold start, one QP per lane group, SoA in HBM (component-major, instance-minor) so that the G=1
 // mapping reads whole 512-byte lines per wave instruction.
 #include "qp_kernel.hpp"
+#include "admm_wave.hpp"
 
 namespace asif {
+
+int launch_qp_wave(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream);
 
 struct GenericQpPolicy {
 	int64_t B, ld;
@@ -40,6 +43,7 @@ int launch_qp_small(const asif_hip_solver &S, const QpArgs &a, hipStream_t strea
 	if (a.B <= 0) return 0;
 	const GenericQpPolicy p = {a.B, a.ld, a.Hd, a.c, a.A, a.b, a.lb, a.ub, a.be_mask, a.sol, a.status, a.iters};
 	const int G = S.lanes_per_qp;
+	if (G == 64) return launch_qp_wave(S, a, stream); // explicitly ask for the wave-per-QP kernel
 	// shapes of the filter classes at the configs' sizes (C2 2x4, C3 3x41, C4 2x18)
 	if (a.nv == 2 && a.nc == 4) {
 		if (G == 0 || G == 1) return launch_policy<2, 4, 1>(S, p, stream);
@@ -59,7 +63,24 @@ int launch_qp_small(const asif_hip_solver &S, const QpArgs &a, hipStream_t strea
 		if (G == 16) return launch_policy<3, 41, 16>(S, p, stream);
 		return ASIF_HIP_EINVAL;
 	}
-	return ASIF_HIP_EUNSUPPORTED;
+	return launch_qp_wave(S, a, stream);
+}
+
+template <int NVMAX>
+static int launch_wave(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
+{
+	hipLaunchKernelGGL((qp_wave_kernel<NVMAX>), dim3((unsigned)a.B), dim3(64), 0, stream, S, a);
+	return (int)hipGetLastError();
+}
+
+// any shape with nv <= 32 and nc + nv <= 64: one wavefront per QP, factor and iterates in LDS
+int launch_qp_wave(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
+{
+	if (a.B <= 0) return 0;
+	if (a.nv < 1 || a.nv > 32 || a.nc + a.nv > 64 || a.B > 0x7fffffffLL) return ASIF_HIP_EUNSUPPORTED;
+	if (a.nv <= 8) return launch_wave<8>(S, a, stream);
+	if (a.nv <= 16) return launch_wave<16>(S, a, stream);
+	return launch_wave<32>(S, a, stream);
 }
 
 } // namespace asif
