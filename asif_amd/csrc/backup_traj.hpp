@@ -24,9 +24,9 @@ struct BackupLoop {
 	{
 		const double r = o.satSharpness;
 		const double mi = o.lb[0], ma = o.ub[0];
-		const double range = ma - mi;
-		const double middle = (ma + mi) / 2;
-		const double uc = 2 * (u - middle) / range;
+		const double range = o.satRange;
+		const double middle = o.satMiddle;
+		const double uc = (u - middle) * o.twoOverRange;
 		const double xc = o.bevelStop;
 		const double yc = 1 - r;
 		uSat = u;

@@ -158,6 +158,9 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 	dev.bevelL = o.satSharpness * std::tan(M_PI / 8);
 	dev.bevelStart = 1 - std::cos(M_PI / 4) * dev.bevelL;
 	dev.bevelStop = 1 + dev.bevelL;
+	dev.satRange = o.ub[0] - o.lb[0];
+	dev.satMiddle = (o.ub[0] + o.lb[0]) / 2;
+	dev.twoOverRange = 2.0 / dev.satRange;
 
 	if (model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR && variant == ASIF_HIP_EXPLICIT) {
 		d.nx = 2; d.nu = 1; d.npSS = 4;

@@ -51,10 +51,15 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 		double xs[NX];
 #pragma unroll
 		for (int k = 0; k < NX; k++) xs[k] = z[k];
-		const int slot = top.insert(M::safetyMin(o, xs), s);
-		if (slot >= 0) {
+		// insertions are rare after the first K samples: keep them behind a wave-uniform branch so the
+		// K-entry shift network is not if-converted into every step
+		const double hm = M::safetyMin(o, xs);
+		if (__any(hm < top.key[K - 1])) {
+			const int slot = top.insert(hm, s);
+			if (slot >= 0) {
 #pragma unroll
-			for (int k = 0; k < NZ; k++) pay[(slot * NZ + k) * 64 + lane] = z[k];
+				for (int k = 0; k < NZ; k++) pay[(slot * NZ + k) * 64 + lane] = z[k];
+			}
 		}
 	}
 	if (!live) return;

@@ -62,10 +62,13 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o, FilterArgs a)
 			double xs[NX];
 #pragma unroll
 			for (int k = 0; k < NX; k++) xs[k] = z[k];
-			const int slot = top.insert(M::safetyMin(o, xs), s);
-			if (slot >= 0) {
+			const double hm = M::safetyMin(o, xs);
+			if (hm < top.key[K - 1]) { // rare after the first K samples
+				const int slot = top.insert(hm, s);
+				if (slot >= 0) {
 #pragma unroll
-				for (int k = 0; k < NZ; k++) pay[(slot * NZ + k) * 64 + lane] = z[k];
+					for (int k = 0; k < NZ; k++) pay[(slot * NZ + k) * 64 + lane] = z[k];
+				}
 			}
 			if (M::backupSetValue(o, xs) >= 0.0) {
 				hit = true;

@@ -24,7 +24,41 @@ struct DevOptions {
 	// soft-saturation bevel constants, evaluated ONCE on the host with libm exactly as the reference
 	// evaluates them per call (src/asif_implicit.cpp:689-703): r*tan(pi/8), 1-cos(pi/4)*bevelL, 1+bevelL
 	double bevelL, bevelStart, bevelStop;
+	// input range of the soft saturation, host-evaluated: ub-lb, (ub+lb)/2 and 2/(ub-lb).  The kernel
+	// forms uc = (u - middle) * twoOverRange where the reference divides, 2*(u-middle)/range
+	// (src/asif_implicit.cpp:696): one rounding of difference, no FP64 divide in the 5000-step loop.
+	double satRange, satMiddle, twoOverRange;
 };
+
+// sin and cos together for the trajectory loops (|x| <= 1e5; beyond that ocml's sincos takes over):
+// two-term Cody-Waite reduction by pi/2 carried by FMAs, then the fdlibm minimax kernels on
+// [-pi/4, pi/4]; within 2 ulp of the correctly rounded values the oracle's glibc returns.  ocml's
+// general sincos costs about twice the instructions (Payne-Hanek path, extra branches) and this call
+// sits inside a 5000-step dependent loop.
+__device__ __forceinline__ void sincos_fast(double x, double &s, double &c)
+{
+	if (!(fabs(x) <= 1e5)) {
+		sincos(x, &s, &c);
+		return;
+	}
+	const double n = rint(x * 6.36619772367581382433e-01);
+	double r = fma(-n, 1.57079632679489655800e+00, x);
+	r = fma(-n, 6.12323399573676603587e-17, r);
+	const double z = r * r;
+	const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+	                                   2.75573137070700676789e-06), -1.98412698298579493134e-04),
+	                      8.33333333332248946124e-03);
+	const double sr = fma(z * r, fma(z, ps, -1.66666666666666324348e-01), r);
+	const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+	                                          -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+	                             -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+	const double cr = 1.0 - (0.5 * z - z * (z * pc));
+	const int q = (int)n & 3;
+	s = (q & 1) ? cr : sr;
+	c = (q & 1) ? sr : cr;
+	if (q & 2) s = -s;
+	if ((q + 1) & 2) c = -c;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Double integrator, examples/DoubleIntegrator.cpp:12-61.  x = (position, velocity).
@@ -100,7 +134,7 @@ struct InvertedPendulum {
 	                                            double (&g)[NX * NU], double (&Df)[NX * NX], double (&Dg)[NX * NU * NX])
 	{
 		double s, c;
-		sincos(x[0], &s, &c);
+		sincos_fast(x[0], s, c);
 		f[0] = x[1];
 		f[1] = s;
 		g[0] = 0.0;
@@ -184,8 +218,8 @@ struct Segway {
 	__device__ static Trig trig(double pitch)
 	{
 		Trig t;
-		sincos(pitch, &t.s1, &t.c1);
-		sincos(2.0 * pitch, &t.s2, &t.c2);
+		sincos_fast(pitch, t.s1, t.c1);
+		sincos_fast(2.0 * pitch, t.s2, t.c2);
 		return t;
 	}
 	// :70-111

@@ -92,10 +92,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    grp = dist.Group(backend="nccl")
+    # ASIF_BENCH_REHEARSAL=1: rehearse the N>1 code path on a one-GPU box (gloo rendezvous, every rank
+    # on cuda:0); never set by the driver.
+    rehearsal = os.environ.get("ASIF_BENCH_REHEARSAL") == "1"
+    grp = dist.Group(backend="gloo" if rehearsal else "nccl")
     if grp.world == 1:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", grp.local_rank if grp.world > 1 else 0)
+    dev = torch.device("cuda", grp.local_rank if (grp.world > 1 and not rehearsal) else 0)
 
     cfg = args.config
     model, variant, default_b = capi.CONFIGS[cfg]
@@ -149,7 +152,7 @@ def main():
         step()
     hip.hipEventRecord(ev[1], sptr)
     grp.barrier()
-    elapsed = grp.max_over_ranks(time.perf_counter() - t0, device=dev if grp.world > 1 else None)
+    elapsed = grp.max_over_ranks(time.perf_counter() - t0, device=dev if (grp.world > 1 and not rehearsal) else None)
     ms = C.c_float()
     assert hip.hipEventElapsedTime(C.byref(ms), ev[0], ev[1]) == 0
     for e in ev:
