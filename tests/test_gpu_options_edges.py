@@ -1,0 +1,143 @@
+"""Edge cases across the four filters: ragged batches (not a multiple of the wave size), padded leading
+dimension (ld > B), non-default options checked against the oracle, updateOptions() semantics (including
+the TB horizon quirk), special states, and argument validation at the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import gpu_util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cfg,B", [(2, 1), (2, 65), (3, 33), (4, 129), (5, 7)])
+def test_ragged_batches(hip, oracle, cfg, B):
+    out = gpu_util.run_filter(cfg, B, uact_init=3.0)
+    ua, rl, rc = gpu_util.oracle_filter(oracle, cfg, out["x"], out["udes"], uact_init=3.0)
+    assert np.array_equal(out["rc"], rc)
+    assert np.abs(out["uact"] - ua).max() <= 1e-6
+
+
+@pytest.mark.parametrize("cfg", [2, 3, 4, 5])
+def test_padded_leading_dimension(hip, cfg):
+    """Arrays with ld > B: instances beyond B must not be touched, results equal the dense call."""
+    from asif_amd import workloads
+    model, variant, _ = hip.CONFIGS[cfg]
+    B, ld = 100, 160
+    x, u = workloads.make_batch(cfg, B)
+    dense = gpu_util.run_filter(cfg, B)
+    flt = hip.Filter(model, variant)
+    d = flt.dims
+    dev = torch.device("cuda:0")
+    tx = torch.full((d.nx, ld), 1e9, dtype=torch.float64, device=dev)
+    tu = torch.full((d.nu, ld), 1e9, dtype=torch.float64, device=dev)
+    tx[:, :B] = torch.from_numpy(x).to(dev)
+    tu[:, :B] = torch.from_numpy(u).to(dev)
+    uact = torch.full((d.nu, ld), -5.0, dtype=torch.float64, device=dev)
+    relax = torch.full((d.nrelax, ld), -5.0, dtype=torch.float64, device=dev)
+    rc = torch.full((ld,), 77, dtype=torch.int32, device=dev)
+    hip.check(flt.lib.asif_hip_filter_batch(flt.handle, B, ld, C.c_void_p(tx.data_ptr()), C.c_void_p(tu.data_ptr()),
+                                            C.c_void_p(uact.data_ptr()), C.c_void_p(relax.data_ptr()),
+                                            C.c_void_p(rc.data_ptr()), None, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(rc[:B].cpu().numpy(), dense["rc"])
+    ok = np.isin(dense["rc"], (1, 2))
+    assert np.array_equal(uact[:, :B].cpu().numpy()[:, ok], dense["uact"][:, ok])
+    assert torch.all(rc[B:] == 77) and torch.all(uact[:, B:] == -5.0) and torch.all(relax[:, B:] == -5.0)
+
+
+def _with_options(hip, oracle, cfg, **kw):
+    model, variant, _ = hip.CONFIGS[cfg]
+    o = hip.default_options(model, variant)
+    oo = oracle.default_options(*oracle.CONFIGS[cfg])
+    for k, v in kw.items():
+        if k in ("lb", "ub"):
+            getattr(o, k)[0] = v
+            getattr(oo, k)[0] = v
+        else:
+            setattr(o, k, v)
+            setattr(oo, k, v)
+    return o, oo
+
+
+@pytest.mark.parametrize("cfg,B,kw", [
+    (2, 2048, dict(relaxLb=2.0, relaxCost=5.0, lb=-0.4, ub=0.7)),
+    (3, 96, dict(relaxLb=3.0, relaxReachLb=1.0, backTrajHorizon=0.75, backTrajDt=0.005, satSharpness=0.4, lb=-2.0, ub=1.0)),
+    (4, 1024, dict(relaxTTS=5.0, relaxMinOrtho=10.0, backTrajHorizon=1.5, backTrajMinOrtho=0.01, relaxCost=25.0)),
+    (5, 1024, dict(pMin=0.5, pMax=1.5, relaxLb=1.0, relaxCost=3.0)),
+])
+def test_non_default_options(hip, oracle, cfg, B, kw):
+    o, oo = _with_options(hip, oracle, cfg, **kw)
+    out = gpu_util.run_filter(cfg, B, options=o, uact_init=2.5)
+    model, variant = oracle.CONFIGS[cfg]
+    d = oracle.dims(model, variant, oo)
+    ua, rl, rc = oracle.filter_batch(model, variant, oo, np.ascontiguousarray(out["x"].T),
+                                     np.ascontiguousarray(out["udes"].T), oracle.SOLVER_EXACT,
+                                     uact_init=np.full((B, d.nu), 2.5))
+    assert np.array_equal(out["rc"], rc), f"{(out['rc'] != rc).sum()} rc mismatches"
+    assert np.abs(out["uact"].T - ua).max() <= 1e-6
+
+
+def test_update_options_and_tb_horizon_quirk(hip, oracle):
+    """initialize() sizes the TB trajectory with (1+backTrajExtend), updateOptions() without it
+    (src/asif_implicit_tb.cpp:177 vs :377): 316 samples before, 301 after, for the same options."""
+    flt = hip.Filter(hip.MODEL_SEGWAY, hip.IMPLICIT_TB)
+    assert flt.dims.npBT == 316
+    flt.update_options(flt.options)
+    assert flt.dims.npBT == 301
+    flt.close()
+    # explicit filter: updateOptions moves relaxLb in cost and LOWER bound; the batched handle applies the
+    # options as a fresh initialize() would (delta pinned at the new relaxLb)
+    f2 = hip.Filter(hip.MODEL_DOUBLE_INTEGRATOR, hip.EXPLICIT)
+    o = hip.default_options(hip.MODEL_DOUBLE_INTEGRATOR, hip.EXPLICIT)
+    o.relaxLb = 2.0
+    f2.update_options(o)
+    dev = torch.device("cuda:0")
+    x = torch.tensor([[0.2], [0.1]], dtype=torch.float64, device=dev)
+    u = torch.tensor([[0.5]], dtype=torch.float64, device=dev)
+    ua = torch.zeros((1, 1), dtype=torch.float64, device=dev)
+    rl = torch.zeros((1, 1), dtype=torch.float64, device=dev)
+    rc = torch.zeros(1, dtype=torch.int32, device=dev)
+    f2.filter(x, u, ua, rl, rc)
+    torch.cuda.synchronize()
+    assert rc.item() == 1 and abs(rl.item() - 2.0) < 1e-12 and abs(ua.item() - 0.5) < 1e-12
+
+
+def test_special_states(hip, oracle):
+    # pendulum: origin, on the safety boundary, outside it; segway: origin (inside the backup set)
+    x = np.array([[0.0, np.pi, -np.pi, 3.5, 0.1], [0.0, 0.0, 0.5, 0.0, -np.pi]])
+    u = np.array([[0.0, 1.0, -1.0, 0.3, 1.5]])
+    out = gpu_util.run_filter(3, 5, x=x, udes=u, uact_init=4.0)
+    ua, rl, rc = gpu_util.oracle_filter(oracle, 3, x, u, uact_init=4.0)
+    assert np.array_equal(out["rc"], rc) and np.abs(out["uact"] - ua).max() <= 1e-6
+    xs = np.zeros((4, 3))
+    xs[:, 1] = [0.1, 0.0, 0.0, 0.0]
+    xs[:, 2] = [0.0, 0.0, 0.3, 0.0]
+    us = np.array([[0.0, 25.0, -25.0]])
+    out = gpu_util.run_filter(4, 3, x=xs, udes=us, uact_init=4.0)
+    ua, rl, rc = gpu_util.oracle_filter(oracle, 4, xs, us, uact_init=4.0)
+    assert np.array_equal(out["rc"], rc) and np.abs(out["uact"] - ua).max() <= 1e-6
+    assert out["rc"][0] == 2 and abs(out["uact"][0, 0]) == 0.0
+
+
+def test_argument_validation(hip):
+    flt = hip.Filter(hip.MODEL_DOUBLE_INTEGRATOR, hip.EXPLICIT)
+    lib = flt.lib
+    p = C.c_void_p(64)
+    assert lib.asif_hip_filter_batch(flt.handle, -1, 4, p, p, p, p, p, None, None) == -1
+    assert lib.asif_hip_filter_batch(flt.handle, 8, 4, p, p, p, p, p, None, None) == -1   # ld < B
+    assert lib.asif_hip_filter_batch(flt.handle, 8, 8, None, p, p, p, p, None, None) == -1
+    assert lib.asif_hip_filter_batch(None, 8, 8, p, p, p, p, p, None, None) == -1
+    assert lib.asif_hip_filter_batch(flt.handle, 0, 0, None, None, None, None, None, None, None) == 0  # empty batch
+    o = hip.default_options(hip.MODEL_INVERTED_PENDULUM_ROBUST, hip.ROBUST)
+    o.nHalfPlanes = 9
+    with pytest.raises(hip.AsifHipError):
+        hip.Filter(hip.MODEL_INVERTED_PENDULUM_ROBUST, hip.ROBUST, options=o)
+    s = hip.default_solver(lanes_per_qp=3)
+    bad = hip.Filter(hip.MODEL_DOUBLE_INTEGRATOR, hip.EXPLICIT, solver=s)
+    dev = torch.device("cuda:0")
+    t = torch.zeros((2, 4), dtype=torch.float64, device=dev)
+    with pytest.raises(hip.AsifHipError):
+        bad.filter(t, t[:1], t[:1].clone(), t[:1].clone(), torch.zeros(4, dtype=torch.int32, device=dev))
