@@ -45,3 +45,39 @@ def test_double_integrator_closed_loop(hip, oracle):
         assert np.abs(rows[k, 1:3] - x).max() <= 1e-9
     # the filter must have intervened: uDes = 1 drives the agent towards the x = 1 wall
     assert rows[:, 4].min() < 0.0 and rows[:, 1].max() < 1.0 + 1e-6
+
+
+def _run_backup(kind, n):
+    exe = os.path.join(HOST, "backup_filters")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HOST, "-s"])
+    out = subprocess.run([exe, kind, str(n)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return np.array([[float(v) for v in line.split(",")] for line in out.stdout.strip().split("\n")[1:]])
+
+
+def test_implicit_class_single_agent_and_batch(hip, oracle):
+    """ASIF::ASIFimplicit with host std::function callbacks (trajectory + rows on the host, QP on the GPU)
+    and filterBatch() (all on the GPU) against the oracle's exact answer on the C3 states."""
+    n = 24
+    rows = _run_backup("implicit", n)
+    x, u = oracle.make_batch(3, n)
+    model, variant = oracle.CONFIGS[3]
+    ua, rl, rc = oracle.filter_batch(model, variant, oracle.default_options(model, variant), x, u, oracle.SOLVER_EXACT)
+    assert np.array_equal(rows[:, 4].astype(int), rc) and np.array_equal(rows[:, 6].astype(int), rc)
+    assert np.abs(rows[:, 1] - ua[:, 0]).max() <= 1e-6      # single agent
+    assert np.abs(rows[:, 5] - ua[:, 0]).max() <= 1e-6      # batch
+    ok = rc == 1
+    assert np.abs(rows[ok, 2] - rl[ok, 0]).max() <= 1e-5 and np.abs(rows[ok, 3] - rl[ok, 1]).max() <= 1e-5
+
+
+def test_tb_class_single_agent_and_batch(hip, oracle):
+    n = 300
+    rows = _run_backup("tb", n)
+    x, u = oracle.make_batch(4, n)
+    model, variant = oracle.CONFIGS[4]
+    ua, rl, rc = oracle.filter_batch(model, variant, oracle.default_options(model, variant), x, u, oracle.SOLVER_EXACT)
+    assert np.array_equal(rows[:, 4].astype(int), rc) and np.array_equal(rows[:, 6].astype(int), rc)
+    assert {1, 2, -3} <= set(rc.tolist())
+    assert np.abs(rows[:, 1] - ua[:, 0]).max() <= 1e-6
+    assert np.abs(rows[:, 5] - ua[:, 0]).max() <= 1e-6
