@@ -107,6 +107,13 @@ __device__ __forceinline__ double pow2_floor(double v)
 	(void)frexp(v, &e);
 	return ldexp(1.0, e - 1);
 }
+// largest power of two <= 1/v, without the division: v = f*2^e, f in [0.5,1) -> 2^-e, or 2^(1-e) when f == 0.5
+__device__ __forceinline__ double pow2_floor_inv(double v)
+{
+	int e;
+	const double f = frexp(v, &e);
+	return ldexp(1.0, (f == 0.5 ? 1 : 0) - e);
+}
 // exact reciprocal of a power of two
 __device__ __forceinline__ double pow2_inv(double p)
 {
@@ -138,7 +145,11 @@ __device__ __forceinline__ bool ldl_factor(double (&M)[NV][NV], double (&Dinv)[N
 		for (int k = 0; k < j; k++) dj -= M[j][k] * M[j][k] * d[k];
 		ok = ok && (dj > 0.0);
 		d[j] = dj;
-		const double di = 1.0 / dj;
+		// pivots are positive and far from the denormal range: hardware reciprocal seed + two Newton
+		// steps instead of the full IEEE division sequence (scale / fixup handling not needed)
+		double di = __builtin_amdgcn_rcp(dj);
+		di = fma(fma(-dj, di, 1.0), di, di);
+		di = fma(fma(-dj, di, 1.0), di, di);
 		Dinv[j] = di;
 #pragma unroll
 		for (int i = j + 1; i < NV; i++) {
@@ -236,7 +247,7 @@ struct AdmmSmall {
 			}
 			cm *= (1.0 / NV);
 			qn = limit_scaling(qn);
-			const double ct = pow2_floor(1.0 / limit_scaling(fmax(cm, qn)));
+			const double ct = pow2_floor_inv(limit_scaling(fmax(cm, qn)));
 #pragma unroll
 			for (int j = 0; j < NV; j++) {
 				P[j] *= ct;

@@ -122,7 +122,7 @@ extern "C" int asif_hip_default_solver(asif_hip_solver *s)
 	s->adaptive_rho_tolerance = 5.0;
 	s->max_iter = 4000;
 	s->check_interval = 2;
-	s->scaling_iters = 4;
+	s->scaling_iters = 2; // power-of-two Ruiz: two passes equilibrate these problems as well as OSQP's ten
 	s->polish = 1;
 	s->active_set_rounds = 12;
 	s->refine_steps = 2;

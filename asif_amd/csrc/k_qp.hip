@@ -67,8 +67,12 @@ int launch_qp_small(const asif_hip_solver &S, const QpArgs &a, hipStream_t strea
 }
 
 template <int NVMAX>
-static int launch_wave(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
+static int launch_wave(const asif_hip_solver &S0, const QpArgs &a, hipStream_t stream)
 {
+	// plain ADMM (no active-set finish) leans on the equilibration for its convergence rate and for what
+	// the unscaled tolerances mean: never fewer than four Ruiz passes here
+	asif_hip_solver S = S0;
+	if (S.scaling_iters < 4) S.scaling_iters = 4;
 	hipLaunchKernelGGL((qp_wave_kernel<NVMAX>), dim3((unsigned)a.B), dim3(64), 0, stream, S, a);
 	return (int)hipGetLastError();
 }
