@@ -1,0 +1,73 @@
+// robust_pendulum.cpp -- ASIF::ASIFrobust on the model of examples/InvertedPendulum_Robust.cpp:53-70
+// (ROBUST flavour: g[1] in [0.8, 1.2]) with the box half-planes of SURVEY 8(d): single-agent filter()
+// (affine-arithmetic rows on the host, the full 18-variable QP on the GPU's wave-per-QP kernel) next to
+// filterBatch() on the same seeded states.
+//   usage: robust_pendulum N    prints  i,uAct,relax,rc,uActBatch,rcBatch, then "A,<i>,<216 row entries>" lines
+#include <asif++.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+static const double pMin = 0.8, pMax = 1.2;
+static std::vector<std::vector<double>> SafetySetData;
+
+static void safetySet(const double *x, double *h, double *Dh)
+{
+	for (uint32_t i = 0; i < SafetySetData.size(); i++) {
+		h[i] = 1. - SafetySetData[i][0] * x[0] - SafetySetData[i][1] * x[1];
+		Dh[i] = -SafetySetData[i][0];
+		Dh[i + SafetySetData.size()] = -SafetySetData[i][1];
+	}
+}
+static void dynamics(const interval_t *x, interval_t *f, interval_t *g)
+{
+	f[0] = x[1];
+	f[1] = sin(x[0]);
+	g[0] = 0.;
+	g[1] = interval(pMin, pMax);
+}
+static double rng(uint64_t seed, uint64_t i, uint64_t j)
+{
+	uint64_t z = (seed << 32) + (i * 16 + j);
+	z += 0x9e3779b97f4a7c15ULL;
+	z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+	z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+	z = z ^ (z >> 31);
+	return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+int main(int argc, char **argv)
+{
+	const long N = argc > 1 ? std::atol(argv[1]) : 16;
+	const double a = 1.0 / M_PI;
+	SafetySetData = {{a, 0}, {-a, 0}, {0, a}, {0, -a}};
+	const double lb[1] = {-1.5}, ub[1] = {1.5};
+	ASIF::ASIFrobust::Options opts; // examples/InvertedPendulum_Robust.cpp:120-121
+	opts.relaxCost = 50.0;
+	opts.relaxLb = 5.0;
+	ASIF::ASIFrobust flt(2, 1, (uint32_t)SafetySetData.size(), safetySet, dynamics);
+	if (flt.initialize(lb, ub, opts) != 1) return 3;
+	asif_hip_options md;
+	asif_hip_default_options(ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST, ASIF_HIP_ROBUST, &md); // same half-planes, pMin, pMax
+	if (flt.bindDeviceModel(ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST, md) != 0) return 3;
+	std::vector<double> bx(2 * N), bu(N), ba(N, 0.0), br(N, 0.0);
+	std::vector<int32_t> brc(N, 0);
+	for (long i = 0; i < N; i++) {
+		bx[i] = -3.0 + 6.0 * rng(4, i, 0);
+		bx[N + i] = -3.0 + 6.0 * rng(4, i, 1);
+		bu[i] = -1.5 + 3.0 * rng(4, i, 2);
+	}
+	if (flt.filterBatch(N, bx.data(), bu.data(), ba.data(), br.data(), brc.data()) != 0) return 4;
+	std::printf("i,uAct,relax,rc,uActBatch,rcBatch\n");
+	for (long i = 0; i < N; i++) {
+		const double x[2] = {bx[i], bx[N + i]}, ud[1] = {bu[i]};
+		double ua[1] = {0.0}, rl = 0.0;
+		const int32_t rc = flt.filter(x, ud, ua, rl);
+		std::printf("%ld,%.17g,%.17g,%d,%.17g,%d\n", i, ua[0], rl, rc, ba[i], brc[i]);
+		std::printf("A,%ld", i);
+		for (uint32_t e = 0; e < flt.nc() * flt.nv(); e++) std::printf(",%.17g", flt.rowsA()[e]);
+		std::printf("\n");
+	}
+	return 0;
+}

@@ -81,3 +81,28 @@ def test_tb_class_single_agent_and_batch(hip, oracle):
     assert {1, 2, -3} <= set(rc.tolist())
     assert np.abs(rows[:, 1] - ua[:, 0]).max() <= 1e-6
     assert np.abs(rows[:, 5] - ua[:, 0]).max() <= 1e-6
+
+
+def test_robust_class_single_agent_and_batch(hip, oracle):
+    """ASIF::ASIFrobust: host affine arithmetic (asif_affine.h) must reproduce the oracle's rows bit for bit
+    (the oracle is pinned against the reference's libaffa); single-agent filter() solves the FULL 18-variable
+    QP on the wave-per-QP kernel (plain ADMM, 1e-5), filterBatch() the eliminated one (1e-6)."""
+    exe = os.path.join(HOST, "robust_pendulum")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HOST, "-s"])
+    n = 48
+    out = subprocess.run([exe, str(n)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().split("\n")[1:]
+    res = np.array([[float(v) for v in l.split(",")] for l in lines if not l.startswith("A,")])
+    rowsA = np.array([[float(v) for v in l.split(",")[2:]] for l in lines if l.startswith("A,")])
+    x, u = oracle.make_batch(5, n)
+    model, variant = oracle.CONFIGS[5]
+    o = oracle.default_options(model, variant)
+    A, b, code, _ = oracle.assemble_batch(model, variant, o, x)
+    assert np.array_equal(rowsA, A)
+    ua, rl, rc = oracle.filter_batch(model, variant, o, x, u, oracle.SOLVER_EXACT)
+    assert np.array_equal(res[:, 3].astype(int), rc) and np.array_equal(res[:, 5].astype(int), rc)
+    assert np.abs(res[:, 1] - ua[:, 0]).max() <= 1e-5
+    assert np.abs(res[:, 2] - rl[:, 0]).max() <= 1e-5
+    assert np.abs(res[:, 4] - ua[:, 0]).max() <= 1e-6
