@@ -189,6 +189,39 @@ int64_t or_qp_solve_batch(int nv, int nc, int solver, const or_admm_settings *s,
                           const double *lb, const double *ub, const uint8_t *be,
                           double *sol, int32_t *status, int32_t *iters);
 
+/* ------------------------------------------------------------ realizable */
+/* ASIFrealizable (src/asif_realizable.cpp) on a polytopic kernel (include/asif_realizable.h:14-36) with
+ * the sampled double integrator of examples/DoubleIntegrator_RealizableSampled.cpp; or_realizable.c. */
+typedef struct {
+	int32_t nx, nu, nVertices, nFacets, maxCriticalFacets, maxActiveConstraints, npSSmax;
+	const double *vertices;       /* [nVertices][nx] */
+	const int32_t *facetVertices; /* [nFacets][nx]   */
+	const double *facetNormals;   /* [nFacets][nx]   */
+	const int32_t *facetActive;   /* [nFacets][maxActiveConstraints] */
+	double uncertaintyBounds[OR_MAX_NX];
+	double relaxDes, relaxOffset, relaxCost, inf; /* include/asif_realizable.h:14-20 */
+	double lb[OR_MAX_NU], ub[OR_MAX_NU];
+	double mMin, mMax, Klo, Khi, Flo, Fhi;        /* interval parameters of the example's dynamics */
+} or_rz_desc;
+typedef struct or_rz or_rz;
+
+void or_rz_default(or_rz_desc *d); /* everything but the kernel arrays, as the example's main() sets it */
+or_rz *or_rz_create(const or_rz_desc *d);
+void or_rz_destroy(or_rz *z);
+void or_rz_dims(const or_rz *z, int *nv, int *nc, int *npSS, int *npSSmax);
+/* table[nFacets][maxActive][4] = lo(Lgh), hi(Lgh), lo(Lfh), hi(Lfh) over the facet; bbox[nFacets][nx][2] */
+void or_rz_table(const or_rz *z, double *table, double *bbox);
+/* returns updateConstraints()'s code (1, or -1 = outside the kernel with no critical facet) */
+int or_rz_assemble(const or_rz *z, const double *x, double *A, double *b, int32_t *info);
+void or_rz_qp_static(const or_rz *z, const double *uDes, double *Hd, double *c, double *lb, double *ub, uint8_t *be);
+/* rc 1, -1 (QP failed), -2 (assembly refused); relax[2] = {solutionFull[nu], solutionFull[nv-1]} */
+int or_rz_filter(const or_rz *z, int solver, const or_admm_settings *s, const double *x, const double *uDes,
+                 double *uAct, double *relax, double *sol_full);
+int64_t or_rz_filter_batch(const or_rz *z, int solver, const or_admm_settings *s, int64_t B, const double *x,
+                           const double *uDes, double *uAct, double *relax, int32_t *rc);
+int64_t or_rz_assemble_batch(const or_rz *z, int64_t B, const double *x, double *A, double *b, int32_t *code,
+                             int32_t *info, int info_stride);
+
 /* SURVEY 8(d) RNG: splitmix64(seed*2^32 + k) -> r=(z>>11)*2^-53, k = i*16+j */
 double or_rng_uniform(uint64_t seed, uint64_t i, uint64_t j);
 /* Seeded synthetic batch of config cfg (2..5): fills x[B][nx], uDes[B][nu] */

@@ -180,8 +180,8 @@ found:
 #define RHO_MAX 1e+06
 #define RHO_EQ_OVER_RHO_INEQ 1e+03
 #define RHO_TOL 1e-04
-#define MAXN 40
-#define MAXM 120
+#define MAXN 96  /* realizable filter on the 10 Hz kernel: n = 86, m = 65 + 86 */
+#define MAXM 160
 
 void or_admm_default_settings(or_admm_settings *s)
 {

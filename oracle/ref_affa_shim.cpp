@@ -103,4 +103,67 @@ int ref_ip_robust_lie(const double *x, double pMin, double pMax, const double *h
 	return 0;
 }
 
+/* Interval Lie derivatives over the facets of a realizable kernel exactly as the reference computes
+ * them: xFaceInt of ASIFrealizable::initialize (src/asif_realizable.cpp:137-157), the interval dynamics
+ * of examples/DoubleIntegrator_RealizableSampled.cpp:33-54 (globals m, K, F constructed first), and
+ * Lfh/Lgh of updateConstraints (:465-506) for every (facet, active constraint) pair.  nx = 2, nu = 1.
+ * out[(i*nA + j)*4 ..] = lo(Lgh), hi(Lgh), lo(Lfh), hi(Lfh). */
+int ref_rz_facet_lie(int nFacets, int nA, const double *vertices, const int *facetVertices,
+                     const double *facetNormals, const int *facetActive, double mMin, double mMax, double Klo,
+                     double Khi, double Flo, double Fhi, double *out)
+{
+	const int nx = 2, nu = 1;
+	AAF::set_default(0);
+	const AAF mInt = interval(mMin, mMax), KInt = interval(Klo, Khi), FInt = interval(Flo, Fhi);
+	std::vector<std::vector<AAF>> xFace(nFacets, std::vector<AAF>(nx));
+	for (int i = 0; i < nFacets; i++) {
+		for (int j = 0; j < nx; j++) xFace[i][j] = vertices[facetVertices[i * nx + 0] * nx + j];
+		for (int j = 1; j <= nx - 1; j++) {
+			AAF lam = AAF(0., 1.);
+			const double *vertex = &vertices[facetVertices[i * nx + j] * nx];
+			for (int k = 0; k < nx; k++) xFace[i][k] = lam * xFace[i][k] + (1. - lam) * vertex[k];
+		}
+	}
+	for (int i = 0; i < nFacets; i++)
+		for (int j = 0; j < nA; j++) {
+			const double *normal = &facetNormals[facetActive[i * nA + j] * nx];
+			AAF Dh[nx], f[nx], g[nx * nu];
+			for (int k = 0; k < nx; k++) Dh[k] = interval(-normal[k]);
+			const AAF *x = xFace[i].data();
+			f[0] = x[1];
+			f[1] = -FInt * x[1] / mInt;
+			g[0] = 0.;
+			g[1] = KInt / mInt;
+			AAF Lfh = 0., Lgh = 0.;
+			for (int k = 0; k < nx; k++) Lfh = Lfh + f[k] * Dh[k];
+			for (int k = 0; k < nx; k++) Lgh = Lgh + g[k] * Dh[k];
+			const interval a = Lgh.convert(), b = Lfh.convert();
+			double *o = &out[(i * nA + j) * 4];
+			o[0] = a.left();
+			o[1] = a.right();
+			o[2] = b.left();
+			o[3] = b.right();
+		}
+	return 0;
+}
+
+/* f, g midpoints of the same dynamics at a point state (src/asif_realizable.cpp:533-553) */
+int ref_rz_point_dynamics(const double *x, double mMin, double mMax, double Klo, double Khi, double Flo,
+                          double Fhi, double *f, double *g)
+{
+	AAF::set_default(0);
+	const AAF mInt = interval(mMin, mMax), KInt = interval(Klo, Khi), FInt = interval(Flo, Fhi);
+	AAF xI[2], fI[2], gI[2];
+	for (int i = 0; i < 2; i++) xI[i] = interval(x[i]);
+	fI[0] = xI[1];
+	fI[1] = -FInt * xI[1] / mInt;
+	gI[0] = 0.;
+	gI[1] = KInt / mInt;
+	for (int i = 0; i < 2; i++) {
+		f[i] = fI[i].convert().mid();
+		g[i] = gI[i].convert().mid();
+	}
+	return 0;
+}
+
 } /* extern "C" */

@@ -196,3 +196,130 @@ def af_run_reference(prog, nreg, cap=48):
     rl = ref_lib()
     assert rl is not None
     return _run_program(rl.ref_affa_run, prog, nreg, cap)
+
+
+# ------------------------------------------------------------------ realizable (oracle/or_realizable.c)
+class RzDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("nx", "nu", "nVertices", "nFacets", "maxCriticalFacets",
+                                         "maxActiveConstraints", "npSSmax")] + [
+        ("vertices", C.POINTER(C.c_double)), ("facetVertices", C.POINTER(C.c_int32)),
+        ("facetNormals", C.POINTER(C.c_double)), ("facetActive", C.POINTER(C.c_int32)),
+        ("uncertaintyBounds", C.c_double * 4)] + [
+        (n, C.c_double) for n in ("relaxDes", "relaxOffset", "relaxCost", "inf")] + [
+        ("lb", C.c_double * 1), ("ub", C.c_double * 1)] + [
+        (n, C.c_double) for n in ("mMin", "mMax", "Klo", "Khi", "Flo", "Fhi")]
+
+
+def load_kernel(name):
+    """Kernel polytope data of include/RealizableKernelData_<name>.h, from tests/golden/realizable_kernels.json."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "realizable_kernels.json")) as f:
+        k = json.load(f)["kernels"][name]
+    return dict(vertices=np.array(k["vertices"], dtype=np.float64),
+                facetVertices=np.array(k["facetVertices"], dtype=np.int32),
+                facetNormals=np.array(k["facetNormals"], dtype=np.float64),
+                facetActive=np.array(k["facetActive"], dtype=np.int32),
+                maxCriticalFacets=int(k["maxCriticalFacets"]), maxActiveConstraints=int(k["maxActiveConstraints"]))
+
+
+class Realizable:
+    """or_rz handle for one kernel + the example's options (overridable through **kw)."""
+
+    def __init__(self, kernel, **kw):
+        L = lib()
+        L.or_rz_create.restype = C.c_void_p
+        for f in ("or_rz_filter_batch", "or_rz_assemble_batch"):
+            getattr(L, f).restype = C.c_int64
+        d = RzDesc()
+        L.or_rz_default(C.byref(d))
+        self._keep = {k: np.ascontiguousarray(kernel[k]) for k in ("vertices", "facetVertices", "facetNormals",
+                                                                    "facetActive")}
+        d.nVertices = self._keep["vertices"].shape[0]
+        d.nFacets = self._keep["facetVertices"].shape[0]
+        d.maxCriticalFacets = kernel["maxCriticalFacets"]
+        d.maxActiveConstraints = kernel["maxActiveConstraints"]
+        d.vertices = _p(self._keep["vertices"])
+        d.facetVertices = _p(self._keep["facetVertices"], C.c_int32)
+        d.facetNormals = _p(self._keep["facetNormals"])
+        d.facetActive = _p(self._keep["facetActive"], C.c_int32)
+        for k, v in kw.items():
+            if k in ("uncertaintyBounds", "lb", "ub"):
+                for i, vi in enumerate(v):
+                    getattr(d, k)[i] = vi
+            else:
+                setattr(d, k, v)
+        self.desc = d
+        self.h = C.c_void_p(L.or_rz_create(C.byref(d)))
+        assert self.h.value, "or_rz_create failed"
+        nv, nc, npSS, npSSmax = (C.c_int() for _ in range(4))
+        L.or_rz_dims(self.h, C.byref(nv), C.byref(nc), C.byref(npSS), C.byref(npSSmax))
+        self.nv, self.nc, self.npSS, self.npSSmax = nv.value, nc.value, npSS.value, npSSmax.value
+        self.nFacets, self.nA, self.maxCrit = d.nFacets, d.maxActiveConstraints, d.maxCriticalFacets
+
+    def __del__(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            lib().or_rz_destroy(self.h)
+            self.h = None
+
+    def table(self):
+        t = np.zeros((self.nFacets, self.nA, 4))
+        bb = np.zeros((self.nFacets, 2, 2))
+        lib().or_rz_table(self.h, _p(t), _p(bb))
+        return t, bb
+
+    def assemble(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        B = x.shape[0]
+        A = np.zeros((B, self.nc * self.nv))
+        b = np.zeros((B, self.nc))
+        code = np.zeros(B, dtype=np.int32)
+        stride = 1 + self.maxCrit + self.npSSmax
+        info = np.zeros((B, stride), dtype=np.int32)
+        n = lib().or_rz_assemble_batch(self.h, C.c_int64(B), _p(x), _p(A), _p(b), _p(code, C.c_int32),
+                                       _p(info, C.c_int32), stride)
+        assert n == B
+        return A, b, code, info
+
+    def qp_static(self, udes):
+        Hd, c, lb, ub = (np.zeros(self.nv) for _ in range(4))
+        be = np.zeros(self.nc, dtype=np.uint8)
+        ud = np.ascontiguousarray(np.atleast_1d(udes), dtype=np.float64)
+        lib().or_rz_qp_static(self.h, _p(ud), _p(Hd), _p(c), _p(lb), _p(ub), _p(be, C.c_uint8))
+        return Hd, c, lb, ub, be
+
+    def filter(self, x, udes, solver=SOLVER_EXACT, settings=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        B = x.shape[0]
+        udes = np.ascontiguousarray(udes, dtype=np.float64).reshape(B, 1)
+        uact = np.full((B, 1), np.nan)
+        relax = np.full((B, 2), np.nan)
+        rc = np.zeros(B, dtype=np.int32)
+        sp = C.byref(settings) if settings is not None else None
+        n = lib().or_rz_filter_batch(self.h, solver, sp, C.c_int64(B), _p(x), _p(udes), _p(uact), _p(relax),
+                                     _p(rc, C.c_int32))
+        assert n == B
+        return uact, relax, rc
+
+
+def make_batch_realizable(kernel, B, first=0, seed=6):
+    """Config 6 workload: half the states uniform over 1.05 x the kernel's bounding box, half within
+    +-2 % (radially) of a random point of a random facet, so that the critical-facet rows are exercised;
+    uDes uniform in [-20, 20].  AoS x [B,2], uDes [B,1]."""
+    V, FV = kernel["vertices"], kernel["facetVertices"]
+    vmax = np.abs(V).max(axis=0)
+    nF = FV.shape[0]
+    x = np.zeros((B, 2))
+    u = np.zeros((B, 1))
+    r = lib().or_rng_uniform
+    for k in range(B):
+        i = first + k
+        if r(seed, i, 3) < 0.5:
+            fi = min(int(r(seed, i, 4) * nF), nF - 1)
+            t = r(seed, i, 5)
+            s = 1.0 + 0.02 * (2.0 * r(seed, i, 0) - 1.0)
+            x[k] = s * (t * V[FV[fi, 0]] + (1.0 - t) * V[FV[fi, 1]])
+        else:
+            x[k, 0] = 1.05 * vmax[0] * (2.0 * r(seed, i, 0) - 1.0)
+            x[k, 1] = 1.05 * vmax[1] * (2.0 * r(seed, i, 1) - 1.0)
+        u[k, 0] = -20.0 + 40.0 * r(seed, i, 2)
+    return x, u
