@@ -26,8 +26,25 @@ EXPORTS = [
     "asif_hip_version", "asif_hip_error_string", "asif_hip_device_count", "asif_hip_default_options",
     "asif_hip_default_solver", "asif_hip_create", "asif_hip_destroy", "asif_hip_get_dims",
     "asif_hip_update_options", "asif_hip_filter_batch", "asif_hip_assemble_batch", "asif_hip_qp_solve_batch",
-    "asif_hip_filter_batch_host",
+    "asif_hip_filter_batch_host", "asif_hip_default_realizable_options", "asif_hip_create_realizable",
+    "asif_hip_update_realizable_options", "asif_hip_realizable_tables",
 ]
+
+MODEL_DOUBLE_INTEGRATOR_SAMPLED = 4
+REALIZABLE = 4
+
+
+class KernelData(C.Structure):
+    """asif_hip_kernel_data: ASIFrealizable::kernel_t flattened (host arrays)."""
+    _fields_ = [(n, C.c_int32) for n in ("nx", "nVertices", "nFacets", "maxCriticalFacets", "maxActiveConstraints")] + [
+        ("vertices", C.POINTER(C.c_double)), ("facetVertices", C.POINTER(C.c_int32)),
+        ("facetNormals", C.POINTER(C.c_double)), ("facetActive", C.POINTER(C.c_int32))]
+
+
+class RealizableOptions(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("relaxDes", "relaxOffset", "relaxCost", "inf")] + [
+        ("lb", C.c_double * 1), ("ub", C.c_double * 1), ("uncertaintyBounds", C.c_double * 4),
+        ("npSSmax", C.c_int32)] + [(n, C.c_double) for n in ("mMin", "mMax", "Klo", "Khi", "Flo", "Fhi")]
 
 
 class Options(C.Structure):
@@ -63,6 +80,9 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise AsifHipError(f"{LIB_PATH} is missing: run `make -C asif_amd/csrc` (there is no CPU fallback)")
+        # torch brings its own libamdhip64; it must be the one already in the process when this library's
+        # HIP symbols are resolved, otherwise two HIP runtimes fight over the device (create -> ENODEVICE)
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         lib.asif_hip_error_string.restype = C.c_char_p
         lib.asif_hip_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(Options),
@@ -76,6 +96,11 @@ def load():
         lib.asif_hip_qp_solve_batch.argtypes = [C.c_int, C.POINTER(Solver), i64, i64, C.c_int32, C.c_int32, vp, vp,
                                                 vp, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.asif_hip_filter_batch_host.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+        lib.asif_hip_default_realizable_options.argtypes = [C.c_int, C.POINTER(RealizableOptions)]
+        lib.asif_hip_create_realizable.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(KernelData),
+                                                   C.POINTER(RealizableOptions), C.POINTER(Solver), C.c_int]
+        lib.asif_hip_update_realizable_options.argtypes = [vp, C.POINTER(RealizableOptions)]
+        lib.asif_hip_realizable_tables.argtypes = [vp, vp, vp]
         _lib = lib
     return _lib
 
@@ -151,6 +176,60 @@ class Filter:
         B = x.shape[1]
         check(self.lib.asif_hip_assemble_batch(self.handle, B, x.stride(0), _ptr(x), _ptr(A), _ptr(b), _ptr(code),
                                                _ptr(diag), _stream()))
+
+
+def default_realizable_options(model=MODEL_DOUBLE_INTEGRATOR_SAMPLED, **overrides):
+    o = RealizableOptions()
+    check(load().asif_hip_default_realizable_options(model, C.byref(o)))
+    for k, v in overrides.items():
+        if k in ("lb", "ub", "uncertaintyBounds"):
+            for i, vi in enumerate(v):
+                getattr(o, k)[i] = vi
+        else:
+            setattr(o, k, v)
+    return o
+
+
+class RealizableFilter(Filter):
+    """ASIFrealizable on a polytopic kernel: `kernel` is a dict of numpy arrays vertices [nV,2] f64,
+    facetVertices [nF,2] i32, facetNormals [nF,2] f64, facetActive [nF,nA] i32 plus the two limits
+    maxCriticalFacets, maxActiveConstraints (ASIFrealizable::kernel_t)."""
+
+    def __init__(self, kernel, options=None, solver=None, device=0, model=MODEL_DOUBLE_INTEGRATOR_SAMPLED):
+        import numpy as np
+        self.lib = load()
+        self.model, self.variant, self.device = model, REALIZABLE, device
+        self.options = options if options is not None else default_realizable_options(model)
+        self.solver = solver if solver is not None else default_solver()
+        v = np.ascontiguousarray(kernel["vertices"], dtype=np.float64)
+        fv = np.ascontiguousarray(kernel["facetVertices"], dtype=np.int32)
+        fn = np.ascontiguousarray(kernel["facetNormals"], dtype=np.float64)
+        fa = np.ascontiguousarray(kernel["facetActive"], dtype=np.int32)
+        k = KernelData(v.shape[1], v.shape[0], fv.shape[0], int(kernel["maxCriticalFacets"]),
+                       int(kernel["maxActiveConstraints"]), v.ctypes.data_as(C.POINTER(C.c_double)),
+                       fv.ctypes.data_as(C.POINTER(C.c_int32)), fn.ctypes.data_as(C.POINTER(C.c_double)),
+                       fa.ctypes.data_as(C.POINTER(C.c_int32)))
+        h = C.c_void_p()
+        check(self.lib.asif_hip_create_realizable(C.byref(h), model, C.byref(k), C.byref(self.options),
+                                                  C.byref(self.solver), device))
+        self.handle = h
+        self.nFacets, self.nActive, self.maxCrit = fv.shape[0], fa.shape[1], int(kernel["maxCriticalFacets"])
+        d = Dims()
+        check(self.lib.asif_hip_get_dims(self.handle, C.byref(d)))
+        self.dims = d
+
+    def update_options(self, options):
+        check(self.lib.asif_hip_update_realizable_options(self.handle, C.byref(options)))
+        self.options = options
+        check(self.lib.asif_hip_get_dims(self.handle, C.byref(self.dims)))
+
+    def tables(self):
+        """(table [nF,nA,4], bbox [nF,2,2]) as built on the device."""
+        import numpy as np
+        t = np.zeros((self.nFacets, self.nActive, 4))
+        bb = np.zeros((self.nFacets, 2, 2))
+        check(self.lib.asif_hip_realizable_tables(self.handle, C.c_void_p(t.ctypes.data), C.c_void_p(bb.ctypes.data)))
+        return t, bb
 
 
 def qp_solve_batch(Hd, c, A, b, lb, ub, sol, status, iters=None, be=None, solver=None, device=0):

@@ -14,8 +14,11 @@
 // aa_interval.cpp:85-93).  No heap and no global state: the symbol counter (AAF::last in the
 // reference, aa_aafcommon.cpp:32) is a per-lane register; only the relative order of symbols matters.
 // Forms live in per-lane private memory; this path is assembly-only work of a few hundred flops.
+// Every product and sum is rounded separately (no FMA contraction inside this header), as in the
+// reference built for baseline x86-64: the results are bit-identical to libaffa's wherever libm agrees.
 #pragma once
 #include <hip/hip_runtime.h>
+#pragma clang fp contract(off)
 
 namespace asif {
 
@@ -232,3 +235,4 @@ __device__ inline void af_sin(AfCtx &cx, const Af &p, Af &r)
 }
 
 } // namespace asif
+#pragma clang fp contract(fast)

@@ -25,6 +25,13 @@ struct asif_hip_ctx {
 	int64_t s_cap;
 	int32_t *s_code;
 	int64_t s_code_cap;
+	// realizable filter: kernel polytope + device-built tables (nullptr for the other variants)
+	struct Realizable {
+		asif_hip_realizable_options opts;
+		RzDev dev;
+		double *d_vertices, *d_normals, *d_facetRec, *d_table;
+		int32_t *d_fverts, *d_factive, *d_overflow;
+	} *rz;
 };
 
 extern "C" int asif_hip_version(void) { return ASIF_HIP_VERSION; }
@@ -265,13 +272,199 @@ extern "C" int asif_hip_create(asif_hip_ctx **out, int model, int variant, const
 	c->s_cap = 0;
 	c->s_code = nullptr;
 	c->s_code_cap = 0;
+	c->rz = nullptr;
 	*out = c;
+	return ASIF_HIP_OK;
+}
+
+// ---- realizable filter -------------------------------------------------------------------------
+// examples/DoubleIntegrator_RealizableSampled.cpp:19-43,88-94; include/asif_realizable.h:14-20
+extern "C" int asif_hip_default_realizable_options(int model, asif_hip_realizable_options *o)
+{
+	if (!o || model != ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_SAMPLED) return ASIF_HIP_EINVAL;
+	std::memset(o, 0, sizeof(*o));
+	o->relaxDes = 10.0;
+	o->relaxOffset = 0.0;
+	o->relaxCost = 100.0;
+	o->inf = 1e20;
+	o->lb[0] = -20.;
+	o->ub[0] = 20.;
+	o->uncertaintyBounds[0] = 0.031;
+	o->uncertaintyBounds[1] = 0.028;
+	o->npSSmax = 2;
+	o->mMin = 70.;
+	o->mMax = 75.;
+	o->Klo = 5.7 - 0.1;
+	o->Khi = 5.7 + 0.1;
+	o->Flo = 23 - 2; // FInt = interval(F-DF, F-DF), :43
+	o->Fhi = 23 - 2;
+	return ASIF_HIP_OK;
+}
+
+static void rz_free(asif_hip_ctx::Realizable *r)
+{
+	if (!r) return;
+	(void)hipFree(r->d_vertices);
+	(void)hipFree(r->d_normals);
+	(void)hipFree(r->d_facetRec);
+	(void)hipFree(r->d_table);
+	(void)hipFree(r->d_fverts);
+	(void)hipFree(r->d_factive);
+	(void)hipFree(r->d_overflow);
+	delete r;
+}
+
+// options -> kernel-side struct + dimensions (src/asif_realizable.cpp:19-22), then the table kernel
+static int rz_configure(asif_hip_ctx *c, const asif_hip_realizable_options &o)
+{
+	asif_hip_ctx::Realizable *r = c->rz;
+	RzDev &z = r->dev;
+	if (o.npSSmax < 0 || o.npSSmax > 4 || o.npSSmax >= z.nF) return ASIF_HIP_EUNSUPPORTED;
+	r->opts = o;
+	z.npSSmax = o.npSSmax;
+	z.npSS = z.maxCrit * z.nA;
+	z.nv = (z.npSSmax > 0) ? (1 + z.npSS * 2 * 2 + 1) : (1 + z.npSS * 2 * 2);
+	z.nc = z.npSS * 3 + z.npSSmax;
+	z.unc[0] = o.uncertaintyBounds[0];
+	z.unc[1] = o.uncertaintyBounds[1];
+	z.relaxDes = o.relaxDes;
+	z.relaxOffset = o.relaxOffset;
+	z.relaxCost = o.relaxCost;
+	z.inf = o.inf;
+	z.lb = o.lb[0];
+	z.ub = o.ub[0];
+	z.mMin = o.mMin;
+	z.mMax = o.mMax;
+	z.Klo = o.Klo;
+	z.Khi = o.Khi;
+	z.Flo = o.Flo;
+	z.Fhi = o.Fhi;
+	asif_hip_dims &d = c->dims;
+	std::memset(&d, 0, sizeof(d));
+	d.nx = 2;
+	d.nu = 1;
+	d.npSS = z.npSS;
+	d.nv = z.nv;
+	d.nc = z.nc;
+	d.nrelax = 2;
+	d.ndiag = 1 + z.maxCrit + z.npSSmax + 1;
+	hipError_t e = hipMemset(r->d_overflow, 0, sizeof(int32_t));
+	if (e != hipSuccess) return (int)e;
+	int rc = launch_realizable_tables(z, r->d_vertices, r->d_fverts, r->d_normals, r->d_factive, r->d_facetRec,
+	                                  r->d_table, r->d_overflow, nullptr);
+	if (rc) return rc;
+	int32_t ovf = 0;
+	e = hipMemcpy(&ovf, r->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost);
+	if (e != hipSuccess) return (int)e;
+	return ovf ? ASIF_HIP_EUNSUPPORTED : ASIF_HIP_OK; // affine-form capacity exceeded
+}
+
+extern "C" int asif_hip_create_realizable(asif_hip_ctx **out, int model, const asif_hip_kernel_data *k,
+                                          const asif_hip_realizable_options *opts, const asif_hip_solver *solver,
+                                          int device)
+{
+	if (!out) return ASIF_HIP_EINVAL;
+	*out = nullptr;
+	if (model != ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_SAMPLED || !k) return ASIF_HIP_EINVAL;
+	if (k->nx != 2) return ASIF_HIP_EUNSUPPORTED;
+	if (k->nVertices < 2 || k->nFacets < 1 || k->maxCriticalFacets < 1 || k->maxCriticalFacets > 8 ||
+	    k->maxActiveConstraints < 1 || !k->vertices || !k->facetVertices || !k->facetNormals || !k->facetActive)
+		return ASIF_HIP_EINVAL;
+	for (int i = 0; i < k->nFacets * 2; i++)
+		if (k->facetVertices[i] < 0 || k->facetVertices[i] >= k->nVertices) return ASIF_HIP_EINVAL;
+	for (int i = 0; i < k->nFacets * k->maxActiveConstraints; i++)
+		if (k->facetActive[i] < 0 || k->facetActive[i] >= k->nFacets) return ASIF_HIP_EINVAL;
+	asif_hip_realizable_options o;
+	if (opts) o = *opts;
+	else asif_hip_default_realizable_options(model, &o);
+	int r = check_device(device);
+	if (r) return r;
+	hipError_t e = hipSetDevice(device);
+	if (e != hipSuccess) return (int)e;
+	asif_hip_ctx *c = new (std::nothrow) asif_hip_ctx();
+	if (!c) return ASIF_HIP_EINVAL;
+	std::memset(c, 0, sizeof(*c));
+	c->model = model;
+	c->variant = ASIF_HIP_REALIZABLE;
+	c->device = device;
+	if (solver) c->solver = *solver;
+	else asif_hip_default_solver(&c->solver);
+	c->rz = new (std::nothrow) asif_hip_ctx::Realizable();
+	if (!c->rz) {
+		delete c;
+		return ASIF_HIP_EINVAL;
+	}
+	std::memset(c->rz, 0, sizeof(*c->rz));
+	asif_hip_ctx::Realizable *z = c->rz;
+	const int nF = k->nFacets, nA = k->maxActiveConstraints, nV = k->nVertices;
+	z->dev.nF = nF;
+	z->dev.nA = nA;
+	z->dev.maxCrit = k->maxCriticalFacets;
+	e = hipMalloc((void **)&z->d_vertices, sizeof(double) * nV * 2);
+	if (e == hipSuccess) e = hipMalloc((void **)&z->d_normals, sizeof(double) * nF * 2);
+	if (e == hipSuccess) e = hipMalloc((void **)&z->d_fverts, sizeof(int32_t) * nF * 2);
+	if (e == hipSuccess) e = hipMalloc((void **)&z->d_factive, sizeof(int32_t) * nF * nA);
+	if (e == hipSuccess) e = hipMalloc((void **)&z->d_facetRec, sizeof(double) * nF * kRzRec);
+	if (e == hipSuccess) e = hipMalloc((void **)&z->d_table, sizeof(double) * nF * nA * 4);
+	if (e == hipSuccess) e = hipMalloc((void **)&z->d_overflow, sizeof(int32_t));
+	if (e == hipSuccess) e = hipMemcpy(z->d_vertices, k->vertices, sizeof(double) * nV * 2, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(z->d_normals, k->facetNormals, sizeof(double) * nF * 2, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(z->d_fverts, k->facetVertices, sizeof(int32_t) * nF * 2, hipMemcpyHostToDevice);
+	if (e == hipSuccess)
+		e = hipMemcpy(z->d_factive, k->facetActive, sizeof(int32_t) * nF * nA, hipMemcpyHostToDevice);
+	r = (e == hipSuccess) ? ASIF_HIP_OK : (int)e;
+	z->dev.facetRec = z->d_facetRec;
+	z->dev.table = z->d_table;
+	if (r == ASIF_HIP_OK) r = rz_configure(c, o);
+	if (r != ASIF_HIP_OK) {
+		rz_free(c->rz);
+		delete c;
+		return r;
+	}
+	*out = c;
+	return ASIF_HIP_OK;
+}
+
+extern "C" int asif_hip_update_realizable_options(asif_hip_ctx *ctx, const asif_hip_realizable_options *opts)
+{
+	if (!ctx || !opts || !ctx->rz) return ASIF_HIP_EINVAL;
+	hipError_t e = hipSetDevice(ctx->device);
+	if (e != hipSuccess) return (int)e;
+	const asif_hip_realizable_options keep = ctx->rz->opts;
+	int r = rz_configure(ctx, *opts);
+	if (r) (void)rz_configure(ctx, keep);
+	return r;
+}
+
+extern "C" int asif_hip_realizable_tables(asif_hip_ctx *ctx, double *table, double *bbox)
+{
+	if (!ctx || !ctx->rz) return ASIF_HIP_EINVAL;
+	hipError_t e = hipSetDevice(ctx->device);
+	if (e != hipSuccess) return (int)e;
+	const RzDev &z = ctx->rz->dev;
+	if (table) {
+		e = hipMemcpy(table, ctx->rz->d_table, sizeof(double) * z.nF * z.nA * 4, hipMemcpyDeviceToHost);
+		if (e != hipSuccess) return (int)e;
+	}
+	if (bbox) {
+		double *rec = new (std::nothrow) double[(size_t)z.nF * kRzRec];
+		if (!rec) return ASIF_HIP_EINVAL;
+		e = hipMemcpy(rec, ctx->rz->d_facetRec, sizeof(double) * z.nF * kRzRec, hipMemcpyDeviceToHost);
+		for (int i = 0; i < z.nF && e == hipSuccess; i++)
+			for (int q = 0; q < 4; q++) bbox[i * 4 + q] = rec[i * kRzRec + 4 + q];
+		delete[] rec;
+		if (e != hipSuccess) return (int)e;
+	}
 	return ASIF_HIP_OK;
 }
 
 extern "C" int asif_hip_destroy(asif_hip_ctx *ctx)
 {
 	if (!ctx) return ASIF_HIP_EINVAL;
+	if (ctx->rz) {
+		(void)hipSetDevice(ctx->device);
+		rz_free(ctx->rz);
+	}
 	if (ctx->s_rows) {
 		(void)hipSetDevice(ctx->device);
 		(void)hipFree(ctx->s_rows);
@@ -346,6 +539,8 @@ static int stage_rows(asif_hip_ctx *ctx, FilterArgs &a)
 
 static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipStream_t stream)
 {
+	if (ctx->variant == ASIF_HIP_REALIZABLE)
+		return ctx->rz ? launch_realizable(ctx->rz->dev, ctx->solver, a, assemble_only, stream) : ASIF_HIP_EINVAL;
 	if (ctx->model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR && ctx->variant == ASIF_HIP_EXPLICIT)
 		return launch_explicit_di(ctx->dev, ctx->solver, a, assemble_only, stream);
 	if (ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM && ctx->variant == ASIF_HIP_IMPLICIT) {

@@ -37,6 +37,22 @@ int launch_tb_segway(const DevOptions &o, const asif_hip_solver &S, const Filter
 int launch_robust_ip(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                      hipStream_t stream);
 
+// realizable filter (class ASIFrealizable), model = DoubleIntegratorSampled; k_realizable.hip
+constexpr int kRzRec = 10; // facet record: v0[2], v1[2], bounding box {lo,hi}[2], normal[2]
+struct RzDev {
+	const double *facetRec; // [nF][kRzRec], device
+	const double *table;    // [nF][nA][4] = lo(Lgh), hi(Lgh), lo(Lfh), hi(Lfh), device
+	int nF, nA, maxCrit, npSSmax, npSS, nv, nc;
+	double unc[2];
+	double relaxDes, relaxOffset, relaxCost, inf, lb, ub;
+	double mMin, mMax, Klo, Khi, Flo, Fhi;
+};
+int launch_realizable_tables(const RzDev &z, const double *vertices, const int32_t *fverts, const double *normals,
+                             const int32_t *factive, double *facetRec, double *table, int32_t *overflow,
+                             hipStream_t stream);
+int launch_realizable(const RzDev &z, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                      hipStream_t stream);
+
 struct QpArgs {
 	int64_t B, ld;
 	int nv, nc;

@@ -38,3 +38,39 @@ def make_batch(cfg, B, first=0):
     else:
         raise ValueError(f"unknown config {cfg}")
     return np.ascontiguousarray(x), np.ascontiguousarray(u)
+
+
+def load_kernel(name="100Hz", path=None):
+    """Polytope data of the reference's include/RealizableKernelData_<name>.h (numbers only, kept as a JSON
+    fixture under tests/golden/realizable_kernels.json) as the dict asif_amd.capi.RealizableFilter takes."""
+    import json
+    import os
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                            "realizable_kernels.json")
+    with open(path) as f:
+        k = json.load(f)["kernels"][name]
+    return dict(vertices=np.array(k["vertices"], dtype=np.float64),
+                facetVertices=np.array(k["facetVertices"], dtype=np.int32),
+                facetNormals=np.array(k["facetNormals"], dtype=np.float64),
+                facetActive=np.array(k["facetActive"], dtype=np.int32),
+                maxCriticalFacets=int(k["maxCriticalFacets"]), maxActiveConstraints=int(k["maxActiveConstraints"]))
+
+
+def make_batch_realizable(kernel, B, first=0, seed=6):
+    """Config 6 (realizable filter, sampled double integrator): half the states uniform over 1.05 x the
+    kernel's bounding box (some start outside -> rc -2), half within +-2 % radially of a random point of a random
+    facet (critical-facet rows active); uDes uniform in [-20, 20].  SoA x [2,B], udes [1,B]."""
+    i = np.arange(first, first + B, dtype=np.uint64)
+    V, FV = kernel["vertices"], kernel["facetVertices"]
+    vmax = np.abs(V).max(axis=0)
+    nF = FV.shape[0]
+    r0, r1, r3 = uniform(seed, i, 0), uniform(seed, i, 1), uniform(seed, i, 3)
+    fi = np.minimum((uniform(seed, i, 4) * nF).astype(np.int64), nF - 1)
+    t = uniform(seed, i, 5)
+    s = 1.0 + 0.02 * (2.0 * r0 - 1.0)
+    near = s[:, None] * (t[:, None] * V[FV[fi, 0]] + (1.0 - t)[:, None] * V[FV[fi, 1]])
+    wide = np.stack([1.05 * vmax[0] * (2.0 * r0 - 1.0), 1.05 * vmax[1] * (2.0 * r1 - 1.0)], axis=1)
+    x = np.where((r3 < 0.5)[:, None], near, wide).T
+    u = (-20.0 + 40.0 * uniform(seed, i, 2))[None, :]
+    return np.ascontiguousarray(x), np.ascontiguousarray(u)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- QP solves/s of the batched CBF-QP filter() hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5|6] [--batch B] [--kernel 100Hz]
 
 One "step" = one pass of the filter (constraint assembly + in-kernel ADMM solve + saturation + return
 code) over one batch of synthetic states that is already resident in HBM when the timed region starts.
@@ -29,13 +29,15 @@ from asif_amd import capi, dist, workloads  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 # algorithmic HBM bytes per instance of the state->input path: read 8(nx+nu), write 8(nu+nrelax)+4
-ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44}
+ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44, 6: 52}
+REALIZABLE_CFG = 6  # ASIFrealizable on the sampled double integrator; not a BASELINE.json config
 PMC_SUMMARY = {2: "r01/c2_v1_pmc_summary.json"}
 WORKLOAD = {
     2: "C2 DoubleIntegrator explicit CBF (ASIF::filter), seeded x in U[-1.2,1.2]^2, uDes in U[-1.5,1.5]",
     3: "C3 InvertedPendulum_Implicit (ASIFimplicit::filter, 5001-step backup trajectory)",
     4: "C4 segway_implicit_tb (ASIFimplicitTB::filter, 316-step backup trajectory), one GPU's share",
     5: "C5 InvertedPendulum_Robust (ASIFrobust::filter, affine-arithmetic rows, nv=18 nc=12)",
+    6: "C6 DoubleIntegrator_RealizableSampled (ASIFrealizable::filter, polytopic kernel, facet search + interval rows)",
 }
 
 
@@ -45,6 +47,39 @@ def host_cores():
     except AttributeError:
         n = os.cpu_count() or 1
     return max(1, min(n, 16))  # the GPU box's CPU share for one GPU is 16
+
+
+def cpu_baseline_realizable(kernel_name, gpu_uact, gpu_rc, x, udes):
+    """cpu_baseline() for config 6: the oracle's ASIFrealizable restatement with its OSQP-style ADMM on the
+    full nv x nc problem (the QP the reference hands to OSQP), python threads over ctypes calls (GIL released)."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    O.build()
+    k = O.load_kernel(kernel_name)
+    z = O.Realizable(k)
+    cores = host_cores()
+    xa, ua = np.ascontiguousarray(x.T), np.ascontiguousarray(udes.T)
+    probe = min(2000, xa.shape[0])
+    t = time.perf_counter()
+    z.filter(xa[:probe], ua[:probe], solver=O.SOLVER_ADMM)
+    per = (time.perf_counter() - t) / probe
+    n = int(max(cores * 16, min(15.0 / per * cores, xa.shape[0])))
+    cuts = [n * j // cores for j in range(cores + 1)]
+    t = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda j: z.filter(xa[cuts[j]:cuts[j + 1]], ua[cuts[j]:cuts[j + 1]], solver=O.SOLVER_ADMM),
+                    range(cores)))
+    dt = time.perf_counter() - t
+    m = min(xa.shape[0], 65536)
+    ue, _, rc = z.filter(xa[:m], ua[:m])
+    ok = rc == 1
+    err = float(np.abs(gpu_uact[0, :m][ok] - ue[ok, 0]).max()) if ok.any() else 0.0
+    return ({"value": n / dt, "unit": "QP solves/s", "cores": cores, "kind": "port",
+             "sample": f"{n} instances of the same seeded workload, ASIFrealizable restatement + OSQP-style ADMM on "
+                       f"the full {z.nv}x{z.nc} QP (eps 1e-3, max_iter 2000, cold start, {per * 1e6:.1f} us per "
+                       f"filter() on one core) over {cores} host threads"},
+            {"max_abs_u_err_vs_exact": err, "rc_mismatches": int((rc != gpu_rc[:m]).sum()), "checked_instances": m})
 
 
 def cpu_baseline(cfg, gpu_uact, gpu_rc, x, udes):
@@ -89,6 +124,7 @@ def main():
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--kernel", default="100Hz", help="config 6: RealizableKernelData_<name> polytope")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -101,13 +137,21 @@ def main():
     dev = torch.device("cuda", grp.local_rank if (grp.world > 1 and not rehearsal) else 0)
 
     cfg = args.config
-    model, variant, default_b = capi.CONFIGS[cfg]
-    B = args.batch or default_b
     solver = capi.default_solver(lanes_per_qp=args.lanes)
-    flt = capi.Filter(model, variant, solver=solver, device=dev.index)
+    if cfg == REALIZABLE_CFG:
+        default_b = 65536
+        kernel = workloads.load_kernel(args.kernel)
+        flt = capi.RealizableFilter(kernel, solver=solver, device=dev.index)
+    else:
+        model, variant, default_b = capi.CONFIGS[cfg]
+        flt = capi.Filter(model, variant, solver=solver, device=dev.index)
+    B = args.batch or default_b
     d = flt.dims
     first, count = grp.shard(B)  # this rank's own slice of the seeded instance stream
-    x, udes = workloads.make_batch(cfg, count, first=first)
+    if cfg == REALIZABLE_CFG:
+        x, udes = workloads.make_batch_realizable(kernel, count, first=first)
+    else:
+        x, udes = workloads.make_batch(cfg, count, first=first)
     tx = torch.from_numpy(x).to(dev)
     tu = torch.from_numpy(udes).to(dev)
     uact = torch.zeros((d.nu, B), dtype=torch.float64, device=dev)
@@ -160,7 +204,7 @@ def main():
     step_ms = ms.value / max(args.steps, 1)
 
     rc_host = rc.cpu().numpy()
-    solved = int(np.isin(rc_host, (1, 2, -1)).sum())
+    solved = int(np.isin(rc_host, (1, 2, -1)).sum())  # instances whose QP was solved (or found infeasible)
     value = B * grp.world * args.steps / elapsed
     alg_bytes = ALG_BYTES[cfg] * B
     achieved = alg_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
@@ -193,7 +237,10 @@ def main():
                      "note": "FP64-VALU/latency bound by design (44-60 algorithmic bytes per instance); see DESIGN.md"},
     }
     if grp.rank == 0 and grp.world == 1 and not args.no_cpu_baseline:
-        base, parity = cpu_baseline(cfg, uact.cpu().numpy(), rc_host, x, udes)
+        if cfg == REALIZABLE_CFG:
+            base, parity = cpu_baseline_realizable(args.kernel, uact.cpu().numpy(), rc_host, x, udes)
+        else:
+            base, parity = cpu_baseline(cfg, uact.cpu().numpy(), rc_host, x, udes)
         out["cpu_baseline"] = base
         out["parity"] = parity
     elif grp.rank == 0:

@@ -10,6 +10,10 @@
  *                                         src/asif_implicit_tb.cpp:261-363, src/asif_robust.cpp:218-252)
  *                                        = updateConstraints + QPWrapperAbstract::{updateCost,updateA,updateb,
  *                                          solve,getSolution} + inputSaturate, fused in one launch.
+ *   asif_hip_create_realizable + asif_hip_filter_batch
+ *                              replaces  ASIFrealizable::ASIFrealizable / initialize / filter
+ *                                        (src/asif_realizable.cpp:5-75,100-267,284-352): facet search incl. the
+ *                                        per-facet feasibility QP (:381-441), interval rows, barrier rows, solve.
  *   asif_hip_assemble_batch    replaces  updateConstraints alone (src/asif.cpp:233-312,
  *                                        src/asif_implicit.cpp:403-651, src/asif_implicit_tb.cpp:407-733,
  *                                        src/asif_robust.cpp:275-367): rows A, b as handed to updateA/updateb.
@@ -52,14 +56,16 @@ enum asif_hip_model {
 	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR = 0,       /* examples/DoubleIntegrator.cpp:12-61          */
 	ASIF_HIP_MODEL_INVERTED_PENDULUM = 1,       /* examples/InvertedPendulum_Implicit.cpp:13-80 */
 	ASIF_HIP_MODEL_SEGWAY = 2,                  /* examples/segway_implicit_tb.cpp:13-212       */
-	ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST = 3 /* examples/InvertedPendulum_Robust.cpp:20-79   */
+	ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST = 3,/* examples/InvertedPendulum_Robust.cpp:20-79   */
+	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_SAMPLED = 4 /* examples/DoubleIntegrator_RealizableSampled.cpp:16-62 (interval dynamics) */
 };
 
 enum asif_hip_variant {
 	ASIF_HIP_EXPLICIT = 0,    /* class ASIF,           include/asif.h:8-101             */
 	ASIF_HIP_IMPLICIT = 1,    /* class ASIFimplicit,   include/asif_implicit.h:17-216   */
 	ASIF_HIP_IMPLICIT_TB = 2, /* class ASIFimplicitTB, include/asif_implicit_tb.h:17-208 */
-	ASIF_HIP_ROBUST = 3       /* class ASIFrobust,     include/asif_robust.h:11-89      */
+	ASIF_HIP_ROBUST = 3,      /* class ASIFrobust,     include/asif_robust.h:11-89      */
+	ASIF_HIP_REALIZABLE = 4   /* class ASIFrealizable, include/asif_realizable.h:9-123 (asif_hip_create_realizable) */
 };
 
 #define ASIF_HIP_MAX_NU 1
@@ -114,6 +120,7 @@ typedef struct asif_hip_dims {
 #define ASIF_HIP_RC_QP_FAILED (-1)       /* src/asif.cpp:209, src/asif_implicit.cpp:354 */
 #define ASIF_HIP_RC_IN_BACKUP_SET 2      /* src/asif_implicit_tb.cpp:307 */
 #define ASIF_HIP_RC_BACKUP_UNREACHED (-3)/* src/asif_implicit_tb.cpp:360 */
+#define ASIF_HIP_RC_OUTSIDE_KERNEL (-2)  /* src/asif_realizable.cpp:324-326: no critical facet and some h < 0 */
 
 /* Solver status values written by asif_hip_qp_solve_batch = QPWrapperOsqp::solve()'s contract
  * (src/qpwrapper_osqp.cpp:225-238): 1 (FEASIBLE) when solved, otherwise the OSQP-style raw status. */
@@ -140,6 +147,46 @@ int asif_hip_destroy(asif_hip_ctx *ctx);
 int asif_hip_get_dims(const asif_hip_ctx *ctx, asif_hip_dims *d);
 /* updateOptions(options) of the reference classes (src/asif.cpp:213-231 etc.) */
 int asif_hip_update_options(asif_hip_ctx *ctx, const asif_hip_options *opts);
+
+/* ---- realizable filter (class ASIFrealizable) ------------------------------------------------------------
+ * ASIFrealizable::kernel_t (include/asif_realizable.h:22-36) flattened; HOST arrays, copied by create.
+ * nx == 2 (facets are segments), the only dimension the reference ships kernel data for. */
+typedef struct asif_hip_kernel_data {
+	int32_t nx, nVertices, nFacets;
+	int32_t maxCriticalFacets, maxActiveConstraints;
+	const double *vertices;       /* [nVertices][nx]                       kernel_t::vertices            */
+	const int32_t *facetVertices; /* [nFacets][nx]                         facet_t::verticesIdx          */
+	const double *facetNormals;   /* [nFacets][nx]                         facet_t::normal               */
+	const int32_t *facetActive;   /* [nFacets][maxActiveConstraints]       facet_t::activeConstraintsSet */
+} asif_hip_kernel_data;
+
+/* ASIFrealizable::Options (include/asif_realizable.h:14-20), the constructor's uncertaintyBounds / npSSmax
+ * (:40-50), initialize()'s input bounds, and the interval parameters of the device model's dynamics
+ * (examples/DoubleIntegrator_RealizableSampled.cpp:27-43: m, K, F as [lo, hi]). */
+typedef struct asif_hip_realizable_options {
+	double relaxDes, relaxOffset, relaxCost, inf;
+	double lb[ASIF_HIP_MAX_NU], ub[ASIF_HIP_MAX_NU];
+	double uncertaintyBounds[4];
+	int32_t npSSmax; /* barrier rows kept (0..4) */
+	double mMin, mMax, Klo, Khi, Flo, Fhi;
+} asif_hip_realizable_options;
+
+/* what examples/DoubleIntegrator_RealizableSampled.cpp:19-43,88-94 passes */
+int asif_hip_default_realizable_options(int model, asif_hip_realizable_options *o);
+/* = new ASIFrealizable(nx,nu,uncertaintyBounds,kernel,dynamics,npSSmax) + initialize(lb,ub,opts).  Uploads the
+ * kernel, builds bounding boxes and facet intervals (:137-175) and -- because dynamics_(xFaceInt) does not
+ * depend on the state -- the interval Lie derivatives of every (facet, active constraint) pair (:465-506),
+ * on the device.  The handle then works with asif_hip_filter_batch / _assemble_batch / _filter_batch_host /
+ * _get_dims / _destroy.  filter: relax[2][ld] = {solutionFull[nu], solutionFull[nv-1]} (:346-347), rc 1/-1/-2;
+ * diag[ndiag][ld] = {nCriticalFacets, critical facets (maxCriticalFacets, -1 padded), barrier facets (npSSmax),
+ * ADMM iterations}. */
+int asif_hip_create_realizable(asif_hip_ctx **out, int model, const asif_hip_kernel_data *kernel,
+                               const asif_hip_realizable_options *opts, const asif_hip_solver *solver, int device);
+/* updateOptions(options), src/asif_realizable.cpp:355-373 (also re-reads bounds and model parameters) */
+int asif_hip_update_realizable_options(asif_hip_ctx *ctx, const asif_hip_realizable_options *opts);
+/* Copies the device-built tables to HOST arrays (either may be NULL): table[nFacets][maxActive][4] =
+ * {lo(Lgh), hi(Lgh), lo(Lfh), hi(Lfh)}, bbox[nFacets][nx][2].  Synchronises the device. */
+int asif_hip_realizable_tables(asif_hip_ctx *ctx, double *table, double *bbox);
 
 /* B independent filter() calls.  x[nx][ldx], udes[nu][ldx] in; uact[nu][ldx], relax[nrelax][ldx], rc[B] out.
  * Where the reference leaves uAct/relax untouched (QP failed in ASIF/ASIFrobust, relax on any failure)
