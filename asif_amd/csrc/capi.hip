@@ -29,7 +29,7 @@ struct asif_hip_ctx {
 	struct Realizable {
 		asif_hip_realizable_options opts;
 		RzDev dev;
-		double *d_vertices, *d_normals, *d_facetRec, *d_table;
+		double *d_vertices, *d_normals, *d_facetRec, *d_table, *d_pointC;
 		int32_t *d_fverts, *d_factive, *d_overflow;
 	} *rz;
 };
@@ -308,6 +308,7 @@ static void rz_free(asif_hip_ctx::Realizable *r)
 	(void)hipFree(r->d_normals);
 	(void)hipFree(r->d_facetRec);
 	(void)hipFree(r->d_table);
+	(void)hipFree(r->d_pointC);
 	(void)hipFree(r->d_fverts);
 	(void)hipFree(r->d_factive);
 	(void)hipFree(r->d_overflow);
@@ -351,7 +352,7 @@ static int rz_configure(asif_hip_ctx *c, const asif_hip_realizable_options &o)
 	hipError_t e = hipMemset(r->d_overflow, 0, sizeof(int32_t));
 	if (e != hipSuccess) return (int)e;
 	int rc = launch_realizable_tables(z, r->d_vertices, r->d_fverts, r->d_normals, r->d_factive, r->d_facetRec,
-	                                  r->d_table, r->d_overflow, nullptr);
+	                                  r->d_table, r->d_pointC, r->d_overflow, nullptr);
 	if (rc) return rc;
 	int32_t ovf = 0;
 	e = hipMemcpy(&ovf, r->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost);
@@ -367,6 +368,7 @@ extern "C" int asif_hip_create_realizable(asif_hip_ctx **out, int model, const a
 	*out = nullptr;
 	if (model != ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_SAMPLED || !k) return ASIF_HIP_EINVAL;
 	if (k->nx != 2) return ASIF_HIP_EUNSUPPORTED;
+	if (k->nFacets > 65535) return ASIF_HIP_EUNSUPPORTED; // critical facets are kept as 16-bit indexes
 	if (k->nVertices < 2 || k->nFacets < 1 || k->maxCriticalFacets < 1 || k->maxCriticalFacets > 8 ||
 	    k->maxActiveConstraints < 1 || !k->vertices || !k->facetVertices || !k->facetNormals || !k->facetActive)
 		return ASIF_HIP_EINVAL;
@@ -406,6 +408,7 @@ extern "C" int asif_hip_create_realizable(asif_hip_ctx **out, int model, const a
 	if (e == hipSuccess) e = hipMalloc((void **)&z->d_factive, sizeof(int32_t) * nF * nA);
 	if (e == hipSuccess) e = hipMalloc((void **)&z->d_facetRec, sizeof(double) * nF * kRzRec);
 	if (e == hipSuccess) e = hipMalloc((void **)&z->d_table, sizeof(double) * nF * nA * 4);
+	if (e == hipSuccess) e = hipMalloc((void **)&z->d_pointC, sizeof(double) * kRzPoint);
 	if (e == hipSuccess) e = hipMalloc((void **)&z->d_overflow, sizeof(int32_t));
 	if (e == hipSuccess) e = hipMemcpy(z->d_vertices, k->vertices, sizeof(double) * nV * 2, hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(z->d_normals, k->facetNormals, sizeof(double) * nF * 2, hipMemcpyHostToDevice);
@@ -415,6 +418,7 @@ extern "C" int asif_hip_create_realizable(asif_hip_ctx **out, int model, const a
 	r = (e == hipSuccess) ? ASIF_HIP_OK : (int)e;
 	z->dev.facetRec = z->d_facetRec;
 	z->dev.table = z->d_table;
+	z->dev.pointC = z->d_pointC;
 	if (r == ASIF_HIP_OK) r = rz_configure(c, o);
 	if (r != ASIF_HIP_OK) {
 		rz_free(c->rz);
@@ -451,7 +455,7 @@ extern "C" int asif_hip_realizable_tables(asif_hip_ctx *ctx, double *table, doub
 		if (!rec) return ASIF_HIP_EINVAL;
 		e = hipMemcpy(rec, ctx->rz->d_facetRec, sizeof(double) * z.nF * kRzRec, hipMemcpyDeviceToHost);
 		for (int i = 0; i < z.nF && e == hipSuccess; i++)
-			for (int q = 0; q < 4; q++) bbox[i * 4 + q] = rec[i * kRzRec + 4 + q];
+			for (int q = 0; q < 4; q++) bbox[i * 4 + q] = rec[i * kRzRec + 8 + q];
 		delete[] rec;
 		if (e != hipSuccess) return (int)e;
 	}

@@ -8,6 +8,7 @@
 //   bounding box (:160-175), dynamics_(xFaceInt) and  Lfh = sum f_k*DhInt_k,  Lgh = sum g_k*DhInt_k  with
 //   Dh = -normal of the active constraint (:465-506), converted to intervals.  Symbols are created in the
 //   reference's order (globals m, K, F; facet; per-call), so the table is bit-identical to libaffa's.
+//   Thread 0 also evaluates the state-independent pieces of the point-state dynamics (inv(m), K/m).
 //
 // realizable_filter_kernel (per batch, fused, one instance per lane):
 //   1. facet scan (:386-442), facet data read through wave-uniform (scalar) loads: h_i = 1 - n_i.x, the
@@ -18,11 +19,12 @@
 //      are eliminated exactly (nu == 1, same argument as k_robust.hip): group s is satisfiable for a given
 //      u iff  lo(Lgh) u + lo(Lfh) >= 0  and  hi(Lgh) u + lo(Lfh) >= 0,  so the 3*npSS rows and 4*npSS
 //      multipliers collapse into an interval [uLo, uHi] for u.
-//   3. barrier rows (:530-600): point-state dynamics in affine arithmetic, midpoints, Lfh/Lgh, right-hand side.
+//   3. barrier rows (:530-600): midpoints of the point-state interval dynamics, Lfh/Lgh, right-hand side.
 //   4. QP in (u, delta):  min (u-uDes)^2 + relaxCost delta^2  s.t.  Lgh_i u + delta >= b_i,
 //      max(lb,uLo) <= u <= min(ub,uHi), 0 <= delta <= inf;  in-register ADMM + active-set finish.
 //   5. inputSaturate, relax = {l+_0 of group 0, delta}, rc 1 / -1 / -2 (:324-351).
 //   asif_hip_assemble_batch writes the full nc x nv rows the reference hands to updateA/updateb instead.
+// The assembly arithmetic is compiled without FMA contraction: rows are bit-identical to the oracle's.
 #include "admm_small.hpp"
 #include "affine_dev.hpp"
 #include "launchers.hpp"
@@ -42,11 +44,59 @@ struct DoubleIntegratorSampled {
 		af_const(g[0], 0.);
 		af_div(cx, K, m, g[1]);
 	}
+
+	// State-independent pieces of dynamicsAffine at a POINT state x = ([x0,x0], [x1,x1]), written to
+	// pc[kRzPoint] by one thread at table-build time:  inv(m) = ci + am*eps_m + de*eps_new,  -F = nFc + nFr*eps_F,
+	// mid(K/m).
+	__device__ static void pointConstants(AfCtx &cx, const Af &m, const Af &K, const Af &F, double *pc)
+	{
+		Af im, nF, g1;
+		af_inv(cx, m, im); // {eps_m, new}
+		af_neg(F, nF);
+		af_div(cx, K, m, g1);
+		double lo, hi;
+		af_convert(g1, lo, hi);
+		pc[0] = im.c;
+		pc[1] = im.v[0];
+		pc[2] = im.v[1];
+		pc[3] = af_rad(im);
+		pc[4] = nF.c;
+		pc[5] = nF.v[0];
+		pc[6] = lo * 0.5 + hi * 0.5;
+		pc[7] = 0.0;
+	}
+
+	// Midpoints (interval::mid() = lo*0.5 + hi*0.5) of dynamicsAffine at a point state, :533-553.  This is
+	// the same sequence of roundings the affine forms go through (symbols in index order m, F, x1, new(-F*x1),
+	// new(inv m), new(product); coefficient rules of aa_aafapprox.cpp:34-101), with the zero terms kept.
+	__device__ __forceinline__ static void pointDynamicsMid(const double *pc, double x1, double (&f)[2], double (&g)[2])
+	{
+#pragma clang fp contract(off)
+		const double ci = pc[0], am = pc[1], de = pc[2], ri = pc[3], nFc = pc[4], nFr = pc[5];
+		const double cu = nFc * x1;  // centre of -F*x1
+		const double uF = x1 * nFr;  // its coefficient on eps_F; eps_x1 gets nFc*0, the new symbol rad*0
+		const double ux = nFc * 0.0;
+		const double radu = ((0.0 + fabs(uF)) + fabs(ux)) + fabs(fabs(nFr) * 0.0);
+		const double c = cu * ci;
+		double r = 0.0;
+		r += fabs(cu * am);
+		r += fabs(ci * uF);
+		r += fabs(ci * ux);
+		r += fabs(ci * (fabs(nFr) * 0.0));
+		r += fabs(cu * de);
+		r += fabs(radu * ri);
+		const double lo = c - r, hi = c + r;
+		f[0] = x1 * 0.5 + x1 * 0.5;
+		f[1] = lo * 0.5 + hi * 0.5;
+		g[0] = 0.0;
+		g[1] = pc[6];
+	}
 };
 
 __global__ __launch_bounds__(64) void realizable_table_kernel(RzDev z, const double *vertices, const int32_t *fverts,
                                                               const double *normals, const int32_t *factive,
-                                                              double *facetRec, double *table, int32_t *overflow)
+                                                              double *facetRec, double *table, double *pointC,
+                                                              int32_t *overflow)
 {
 	const int t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= z.nF * z.nA) return;
@@ -56,6 +106,10 @@ __global__ __launch_bounds__(64) void realizable_table_kernel(RzDev z, const dou
 	af_interval(cx, m, z.mMin, z.mMax);
 	af_interval(cx, K, z.Klo, z.Khi);
 	af_interval(cx, F, z.Flo, z.Fhi);
+	if (t == 0) {
+		AfCtx c2 = cx;
+		DoubleIntegratorSampled::pointConstants(c2, m, K, F, pointC);
+	}
 	const double *v0 = &vertices[fverts[i * 2 + 0] * 2], *v1 = &vertices[fverts[i * 2 + 1] * 2];
 	Af xf[2], lam, one, oml, a, b2;
 	af_const(xf[0], v0[0]);
@@ -90,22 +144,26 @@ __global__ __launch_bounds__(64) void realizable_table_kernel(RzDev z, const dou
 	af_convert(Lfh, o[2], o[3]);
 	if (cx.overflow) atomicAdd(overflow, 1);
 	if (j == 0) {
+		// segment stored from its end with the smaller first coordinate: p(t) = va + t*(a0, s1*a1), t in [0,1]
 		double *r = &facetRec[(size_t)i * kRzRec];
-		r[0] = v0[0];
-		r[1] = v0[1];
-		r[2] = v1[0];
-		r[3] = v1[1];
-		r[4] = fmin(v0[0], v1[0]);
-		r[5] = fmax(v0[0], v1[0]);
-		r[6] = fmin(v0[1], v1[1]);
-		r[7] = fmax(v0[1], v1[1]);
-		r[8] = normals[i * 2 + 0];
-		r[9] = normals[i * 2 + 1];
+		const bool swap = v1[0] < v0[0];
+		const double *va = swap ? v1 : v0, *vb = swap ? v0 : v1;
+		r[0] = va[0];
+		r[1] = va[1];
+		r[2] = vb[0] - va[0];
+		r[3] = fabs(vb[1] - va[1]);
+		r[4] = (vb[1] >= va[1]) ? 1.0 : -1.0;
+		r[5] = normals[i * 2 + 0];
+		r[6] = normals[i * 2 + 1];
+		r[7] = 0.0;
+		r[8] = fmin(v0[0], v1[0]); // bounding box, :160-175
+		r[9] = fmax(v0[0], v1[0]);
+		r[10] = fmin(v0[1], v1[1]);
+		r[11] = fmax(v0[1], v1[1]);
 	}
 }
 
-constexpr int kRzMaxCrit = 8;  // critical facets kept per instance (kernel_t::maxCriticalFacets <= 8)
-constexpr int kRzMaxBarrier = 4; // barrier rows (npSSmax <= 4) = rows of the in-register QP
+constexpr int kRzMaxCrit = 8; // critical facets kept per instance (kernel_t::maxCriticalFacets <= 8)
 
 // one row  a*u + c >= 0  folded into [lo, hi]
 __device__ __forceinline__ void fold_row(double a, double c, double &lo, double &hi, bool &feasible)
@@ -115,10 +173,12 @@ __device__ __forceinline__ void fold_row(double a, double c, double &lo, double 
 	else if (c < 0.0) feasible = false;
 }
 
+// KB = barrier rows carried in registers (>= npSSmax) = rows of the in-register QP
+template <int KB>
 __global__ __launch_bounds__(64) void realizable_filter_kernel(RzDev z, asif_hip_solver S, FilterArgs a,
                                                                bool assemble_only)
 {
-	constexpr int NV = 2, RPL = kRzMaxBarrier;
+	constexpr int NV = 2, RPL = KB;
 	const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int64_t i = tid;
 	const bool live = i < a.B;
@@ -127,101 +187,106 @@ __global__ __launch_bounds__(64) void realizable_filter_kernel(RzDev z, asif_hip
 	const double x0 = a.x[i], x1 = a.x[ld + i];
 
 	// ---- 1. facet scan
-	double hmin[kRzMaxBarrier];
-	int hidx[kRzMaxBarrier], crit[kRzMaxCrit];
+	double hmin[KB];
+	int hidx[KB];
+	unsigned long long critLo = 0ull, critHi = 0ull; // critical facet indexes, 16 bits each, in facet order
 	int nCrit = 0;
 	bool anyNeg = false;
 #pragma unroll
-	for (int q = 0; q < kRzMaxBarrier; q++) {
+	for (int q = 0; q < KB; q++) {
 		hmin[q] = __builtin_huge_val();
 		hidx[q] = -1;
 	}
-#pragma unroll
-	for (int q = 0; q < kRzMaxCrit; q++) crit[q] = -1;
 	{
 #pragma clang fp contract(off)
-		for (int fi = 0; fi < z.nF; fi++) {
-			const double *r = z.facetRec + (size_t)fi * kRzRec; // wave-uniform address
+		const double xm0 = x0 - z.unc[0], xp0 = x0 + z.unc[0], xm1 = x1 - z.unc[1], xp1 = x1 + z.unc[1];
+		// One facet, branch-free.  `valid` is wave-uniform (false only for the padding slot of an odd facet count).
+		auto facet = [&](const double (&r)[7], const int fi, const bool valid) {
 			double h = 1.;
-			h -= r[8] * x0;
-			h -= r[9] * x1;
-			anyNeg = anyNeg || (h < 0.);
-			double hv = h;
-			int hi_ = fi;
+			h -= r[5] * x0;
+			h -= r[6] * x1;
+			h = valid ? h : __builtin_huge_val();
+			anyNeg = anyNeg | (h < 0.);
+			if constexpr (KB == 2) {
+				// two smallest, strict < keeps the lower facet index on ties
+				const bool c1 = h < hmin[0], c2 = h < hmin[1];
+				hidx[1] = c1 ? hidx[0] : (c2 ? fi : hidx[1]);
+				hidx[0] = c1 ? fi : hidx[0];
+				hmin[1] = fmin(hmin[1], fmax(hmin[0], h));
+				hmin[0] = fmin(hmin[0], h);
+			} else {
+				double hv = h;
+				int hi_ = fi;
 #pragma unroll
-			for (int q = 0; q < kRzMaxBarrier; q++) // sorted insert; strict < keeps the lower facet index on ties
-				if (hv < hmin[q]) {
+				for (int q = 0; q < KB; q++) { // sorted insert
+					const bool lt = hv < hmin[q];
 					const double tv = hmin[q];
 					const int ti = hidx[q];
-					hmin[q] = hv;
-					hidx[q] = hi_;
-					hv = tv;
-					hi_ = ti;
-				}
-			if (nCrit < z.maxCrit) {
-				const bool potential = !(x0 < r[4] - z.unc[0] || x0 > r[5] + z.unc[0] || x1 < r[6] - z.unc[1] ||
-				                         x1 > r[7] + z.unc[1]);
-				if (potential) {
-					// exists t in [0,1]: | t v0 + (1-t) v1 - x | <= unc  (componentwise)
-					double tlo = 0.0, thi = 1.0;
-					bool ok = true;
-#pragma unroll
-					for (int k = 0; k < 2; k++) {
-						const double xk = k ? x1 : x0;
-						const double d = r[k] - r[2 + k];
-						const double lo = xk - z.unc[k] - r[2 + k], hi = xk + z.unc[k] - r[2 + k];
-						if (d > 0.0) {
-							tlo = fmax(tlo, lo / d);
-							thi = fmin(thi, hi / d);
-						} else if (d < 0.0) {
-							tlo = fmax(tlo, hi / d);
-							thi = fmin(thi, lo / d);
-						} else if (lo > 0.0 || hi < 0.0) ok = false;
-					}
-					if (ok && tlo <= thi) {
-#pragma unroll
-						for (int q = 0; q < kRzMaxCrit; q++)
-							if (q == nCrit) crit[q] = fi;
-						nCrit++;
-					}
+					hmin[q] = lt ? hv : tv;
+					hidx[q] = lt ? hi_ : ti;
+					hv = lt ? tv : hv;
+					hi_ = lt ? ti : hi_;
 				}
 			}
+			// Does the facet touch the box [x-unc, x+unc]?  With p(t) = va + t*(a0, s1*a1): exists t in [0,1] with
+			// A0 <= t*a0 <= B0 and L1 <= t*a1 <= H1.  Lower bounds {0, A0/a0, L1/a1} against upper bounds
+			// {1, B0/a0, H1/a1}, cross-multiplied (a0, a1 >= 0; a zero extent degenerates correctly): no divide,
+			// no branch.  The first four comparisons are the reference's bounding-box prefilter (:400-409).
+			const double A0 = xm0 - r[0], B0 = xp0 - r[0], A1 = xm1 - r[1], B1 = xp1 - r[1];
+			const bool up = r[4] > 0.0; // wave-uniform
+			const double L1 = up ? A1 : -B1, H1 = up ? B1 : -A1;
+			const bool touch = (A0 <= r[2]) & (B0 >= 0.0) & (L1 <= r[3]) & (H1 >= 0.0) & (A0 * r[3] <= H1 * r[2]) &
+			                   (L1 * r[2] <= B0 * r[3]);
+			// first maxCriticalFacets in facet order (:436-438), appended as 16-bit fields
+			const bool app = touch & (nCrit < z.maxCrit) & valid;
+			const unsigned long long v = app ? ((unsigned long long)fi << (16 * (nCrit & 3))) : 0ull;
+			critLo |= (nCrit < 4) ? v : 0ull;
+			critHi |= (nCrit < 4) ? 0ull : v;
+			nCrit += app ? 1 : 0;
+		};
+		// Records come through scalar loads (wave-uniform addresses).  Scalar loads return out of order, so a
+		// wait covers everything outstanding; four records are requested per wait to amortise the latency.
+		const int nF4 = z.nF & ~3;
+		for (int fi = 0; fi < nF4; fi += 4) {
+			double r[4][7];
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+#pragma unroll
+				for (int k = 0; k < 7; k++) r[u][k] = z.facetRec[(size_t)(fi + u) * kRzRec + k];
+#pragma unroll
+			for (int u = 0; u < 4; u++) facet(r[u], fi + u, true);
+		}
+		for (int fi = nF4; fi < z.nF; fi++) {
+			double r[7];
+#pragma unroll
+			for (int k = 0; k < 7; k++) r[k] = z.facetRec[(size_t)fi * kRzRec + k];
+			facet(r, fi, true);
 		}
 	}
+	int crit[kRzMaxCrit];
+#pragma unroll
+	for (int q = 0; q < kRzMaxCrit; q++)
+		crit[q] = (q < nCrit) ? (int)(((q < 4 ? critLo : critHi) >> (16 * (q & 3))) & 0xFFFFull) : -1;
 	const int code = (nCrit == 0 && anyNeg) ? -1 : 1; // :602-605
 
-	// ---- 3. barrier rows: point-state dynamics in affine arithmetic, midpoints (:533-553)
-	double Lgh[kRzMaxBarrier], bb[kRzMaxBarrier];
+	// ---- 3. barrier rows (:533-599)
+	double Lgh[KB], bb[KB];
 	{
 #pragma clang fp contract(off)
-		AfCtx cx = {0u, false};
-		Af m, K, F, xI[2], fI[2], gI[2];
-		af_interval(cx, m, z.mMin, z.mMax);
-		af_interval(cx, K, z.Klo, z.Khi);
-		af_interval(cx, F, z.Flo, z.Fhi);
-		af_interval(cx, xI[0], x0, x0);
-		af_interval(cx, xI[1], x1, x1);
-		DoubleIntegratorSampled::dynamicsAffine(cx, m, K, F, xI, fI, gI);
-		double f[2], g[2], lo, hi;
+		double f[2], g[2];
+		DoubleIntegratorSampled::pointDynamicsMid(z.pointC, x1, f, g);
 #pragma unroll
-		for (int k = 0; k < 2; k++) {
-			af_convert(fI[k], lo, hi);
-			f[k] = lo * 0.5 + hi * 0.5;
-			af_convert(gI[k], lo, hi);
-			g[k] = lo * 0.5 + hi * 0.5;
-		}
-#pragma unroll
-		for (int q = 0; q < kRzMaxBarrier; q++) {
+		for (int q = 0; q < KB; q++) {
 			const int fi = (q < z.npSSmax) ? hidx[q] : 0;
 			const double *r = z.facetRec + (size_t)fi * kRzRec;
-			const double hq = hmin[q];
+			const double n0 = r[5], n1 = r[6];
 			double lf = 0.0, lg = 0.0;
-			lf += -r[8] * f[0];
-			lf += -r[9] * f[1];
-			lg += -r[8] * g[0];
-			lg += -r[9] * g[1];
+			lf += -n0 * f[0];
+			lf += -n1 * f[1];
+			lg += -n0 * g[0];
+			lg += -n1 * g[1];
 			Lgh[q] = lg;
-			bb[q] = -lf - z.relaxDes * (hq - z.relaxOffset);
+			bb[q] = -lf - z.relaxDes * (hmin[q] - z.relaxOffset);
 		}
 	}
 
@@ -257,7 +322,7 @@ __global__ __launch_bounds__(64) void realizable_filter_kernel(RzDev z, asif_hip
 			a.b[(int64_t)(iRow + 2) * ld + i] = 1.0;
 		}
 #pragma unroll
-		for (int q = 0; q < kRzMaxBarrier; q++)
+		for (int q = 0; q < KB; q++)
 			if (q < z.npSSmax) {
 				const int row = 3 * z.npSS + q;
 				a.A[(int64_t)(row + 0 * nc) * ld + i] = Lgh[q];
@@ -330,18 +395,18 @@ __global__ __launch_bounds__(64) void realizable_filter_kernel(RzDev z, asif_hip
 		for (int q = 0; q < kRzMaxCrit; q++)
 			if (q < z.maxCrit) a.diag[(int64_t)(1 + q) * ld + i] = (double)crit[q];
 #pragma unroll
-		for (int q = 0; q < kRzMaxBarrier; q++)
+		for (int q = 0; q < KB; q++)
 			if (q < z.npSSmax) a.diag[(int64_t)(1 + z.maxCrit + q) * ld + i] = (double)hidx[q];
 	}
 }
 
 int launch_realizable_tables(const RzDev &z, const double *vertices, const int32_t *fverts, const double *normals,
-                             const int32_t *factive, double *facetRec, double *table, int32_t *overflow,
-                             hipStream_t stream)
+                             const int32_t *factive, double *facetRec, double *table, double *pointC,
+                             int32_t *overflow, hipStream_t stream)
 {
 	const int n = z.nF * z.nA;
 	hipLaunchKernelGGL(realizable_table_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, z, vertices, fverts, normals,
-	                   factive, facetRec, table, overflow);
+	                   factive, facetRec, table, pointC, overflow);
 	return (int)hipGetLastError();
 }
 
@@ -349,9 +414,10 @@ int launch_realizable(const RzDev &z, const asif_hip_solver &S, const FilterArgs
                       hipStream_t stream)
 {
 	if (a.B <= 0) return 0;
-	if (z.maxCrit > kRzMaxCrit || z.npSSmax > kRzMaxBarrier) return ASIF_HIP_EUNSUPPORTED;
-	hipLaunchKernelGGL(realizable_filter_kernel, dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, z, S, a,
-	                   assemble_only);
+	if (z.maxCrit > kRzMaxCrit || z.npSSmax > 4) return ASIF_HIP_EUNSUPPORTED;
+	const dim3 grid(grid_for(a.B, 1, 64)), block(64);
+	if (z.npSSmax <= 2) hipLaunchKernelGGL(realizable_filter_kernel<2>, grid, block, 0, stream, z, S, a, assemble_only);
+	else hipLaunchKernelGGL(realizable_filter_kernel<4>, grid, block, 0, stream, z, S, a, assemble_only);
 	return (int)hipGetLastError();
 }
 

@@ -38,18 +38,22 @@ int launch_robust_ip(const DevOptions &o, const asif_hip_solver &S, const Filter
                      hipStream_t stream);
 
 // realizable filter (class ASIFrealizable), model = DoubleIntegratorSampled; k_realizable.hip
-constexpr int kRzRec = 10; // facet record: v0[2], v1[2], bounding box {lo,hi}[2], normal[2]
+// facet record: va[2] (segment end with the smaller first coordinate), extents a0, |a1|, sign of a1, pad,
+// normal[2], bounding box {lo,hi}[2]
+constexpr int kRzRec = 12;
+constexpr int kRzPoint = 8; // state-independent constants of the model's point-state dynamics
 struct RzDev {
 	const double *facetRec; // [nF][kRzRec], device
 	const double *table;    // [nF][nA][4] = lo(Lgh), hi(Lgh), lo(Lfh), hi(Lfh), device
+	const double *pointC;   // [kRzPoint], device
 	int nF, nA, maxCrit, npSSmax, npSS, nv, nc;
 	double unc[2];
 	double relaxDes, relaxOffset, relaxCost, inf, lb, ub;
 	double mMin, mMax, Klo, Khi, Flo, Fhi;
 };
 int launch_realizable_tables(const RzDev &z, const double *vertices, const int32_t *fverts, const double *normals,
-                             const int32_t *factive, double *facetRec, double *table, int32_t *overflow,
-                             hipStream_t stream);
+                             const int32_t *factive, double *facetRec, double *table, double *pointC,
+                             int32_t *overflow, hipStream_t stream);
 int launch_realizable(const RzDev &z, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                       hipStream_t stream);
 
