@@ -38,6 +38,38 @@ struct GenericQpPolicy {
 	}
 };
 
+// Same, for a shape padded up to a compiled one: rows nc..NC-1 are inert (0.x >= -big).
+struct PaddedQpPolicy : GenericQpPolicy {
+	int nc;
+
+	template <int NV, int NC, int G>
+	__device__ __forceinline__ void load(int64_t i, int g, QpLaneData<NV, (NC + G - 1) / G> &qp) const
+	{
+		constexpr int RPL = (NC + G - 1) / G;
+#pragma unroll
+		for (int j = 0; j < NV; j++) {
+			qp.Hd[j] = Hd[j * ld + i];
+			qp.c[j] = c[j * ld + i];
+			qp.lb[j] = lb[j * ld + i];
+			qp.ub[j] = ub[j * ld + i];
+		}
+#pragma unroll
+		for (int k = 0; k < RPL; k++) {
+			const int r = g + k * G;
+			const bool valid = r < nc;
+			const int rr = valid ? r : 0;
+#pragma unroll
+			for (int j = 0; j < NV; j++) {
+				const double v = A[(int64_t)(rr + j * nc) * ld + i];
+				qp.A[k][j] = valid ? v : 0.0;
+			}
+			const double bv = b[(int64_t)rr * ld + i];
+			qp.b[k] = valid ? bv : -1e20;
+			qp.eq[k] = valid && ((be_mask >> rr) & 1ull);
+		}
+	}
+};
+
 int launch_qp_small(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
 {
 	if (a.B <= 0) return 0;
@@ -62,6 +94,15 @@ int launch_qp_small(const asif_hip_solver &S, const QpArgs &a, hipStream_t strea
 		if (G == 8) return launch_policy<3, 41, 8>(S, p, stream);
 		if (G == 16) return launch_policy<3, 41, 16>(S, p, stream);
 		return ASIF_HIP_EINVAL;
+	}
+	// other two-variable shapes (the realizable filter's facet problem 2x5 and its eliminated QP, 2x20..2x44)
+	// ride on a padded in-register kernel, so that they get the active-set finish as well
+	if (a.nv == 2 && a.nc >= 1 && a.nc <= 48 && G == 0) {
+		PaddedQpPolicy pp;
+		static_cast<GenericQpPolicy &>(pp) = p;
+		pp.nc = a.nc;
+		if (a.nc <= 8) return launch_policy<2, 8, 1>(S, pp, stream);
+		return launch_policy<2, 48, 4>(S, pp, stream);
 	}
 	return launch_qp_wave(S, a, stream);
 }

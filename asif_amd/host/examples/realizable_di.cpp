@@ -1,0 +1,96 @@
+// realizable_di.cpp -- ASIF::ASIFrealizable on the model of examples/DoubleIntegrator_RealizableSampled.cpp:16-54
+// (interval mass, gain and friction) over a polytopic kernel read from a text file (the numbers of
+// include/RealizableKernelData_*.h; tests write it from tests/golden/realizable_kernels.json):
+//     nVertices nFacets maxCriticalFacets maxActiveConstraints
+//     nVertices lines  x y
+//     nFacets lines    v0 v1  n0 n1  a_0 .. a_{maxActive-1}
+// Single-agent filter() (facet QPs and the eliminated QP on the GPU through QPWrapperHip, affine arithmetic on
+// the host) next to filterBatch() on the same states, which are read from stdin as "x0 x1 uDes" lines.
+//   usage: realizable_di kernel.txt < states.txt
+//   prints  i,uAct,relax0,relax1,rc,nCrit,uActBatch,relax1Batch,rcBatch  and  "A,<i>,<nc*nv row entries>" / "b,<i>,..."
+#include <asif++.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+static const double m_min = 70., m_max = 75., K = 5.7, dK = 0.1, F = 23, DF = 2;
+static interval_t mInt, KInt, FInt;
+
+static void dynamics(const interval_t *x, interval_t *f, interval_t *g)
+{
+	f[0] = x[1];
+	f[1] = -FInt * x[1] / mInt;
+	g[0] = 0.;
+	g[1] = KInt / mInt;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 2) return 2;
+	FILE *fp = std::fopen(argv[1], "r");
+	if (!fp) return 2;
+	int nV, nF, maxCrit, maxAct;
+	if (std::fscanf(fp, "%d %d %d %d", &nV, &nF, &maxCrit, &maxAct) != 4) return 2;
+	ASIF::ASIFrealizable::kernel_t kernel;
+	kernel.vertices.assign(nV, std::vector<double>(2));
+	for (int i = 0; i < nV; i++)
+		if (std::fscanf(fp, "%lf %lf", &kernel.vertices[i][0], &kernel.vertices[i][1]) != 2) return 2;
+	kernel.facets.resize(nF);
+	for (int i = 0; i < nF; i++) {
+		ASIF::ASIFrealizable::facet_t &f = kernel.facets[i];
+		f.verticesIdx.resize(2);
+		f.normal.resize(2);
+		f.activeConstraintsSet.resize(maxAct);
+		if (std::fscanf(fp, "%u %u %lf %lf", &f.verticesIdx[0], &f.verticesIdx[1], &f.normal[0], &f.normal[1]) != 4) return 2;
+		for (int j = 0; j < maxAct; j++)
+			if (std::fscanf(fp, "%u", &f.activeConstraintsSet[j]) != 1) return 2;
+	}
+	std::fclose(fp);
+	kernel.maxCriticalFacets = maxCrit;
+	kernel.maxActiveConstraints = maxAct;
+
+	// the example's globals, constructed in its order (m, K, F) before anything else creates a symbol
+	mInt = interval(m_min, m_max);
+	KInt = interval(K - dK, K + dK);
+	FInt = interval(F - DF, F - DF);
+	const double lb[1] = {-20.}, ub[1] = {20.}, xUncertainty[2] = {0.031, 0.028};
+	ASIF::ASIFrealizable::Options opts;
+	opts.relaxCost = 100.0;
+	opts.relaxOffset = 0.0;
+	opts.relaxDes = 10.0;
+	ASIF::ASIFrealizable flt(2, 1, xUncertainty, kernel, dynamics, 2);
+	if (flt.initialize(lb, ub, opts) != 1) return 3;
+	asif_hip_realizable_options md;
+	asif_hip_default_realizable_options(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_SAMPLED, &md); // same m, K, F intervals
+	if (flt.bindDeviceModel(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_SAMPLED, md) != 0) return 3;
+
+	std::vector<double> xs, us;
+	double a, b, c;
+	while (std::scanf("%lf %lf %lf", &a, &b, &c) == 3) {
+		xs.push_back(a);
+		xs.push_back(b);
+		us.push_back(c);
+	}
+	const long N = (long)us.size();
+	std::vector<double> bx(2 * N), ba(N, 0.0), br(2 * N, 0.0);
+	std::vector<int32_t> brc(N, 0);
+	for (long i = 0; i < N; i++) {
+		bx[i] = xs[2 * i];
+		bx[N + i] = xs[2 * i + 1];
+	}
+	if (flt.filterBatch(N, bx.data(), us.data(), ba.data(), br.data(), brc.data()) != 0) return 4;
+	std::printf("i,uAct,relax0,relax1,rc,nCrit,uActBatch,relax1Batch,rcBatch\n");
+	for (long i = 0; i < N; i++) {
+		const double x[2] = {xs[2 * i], xs[2 * i + 1]}, ud[1] = {us[i]};
+		double ua[1] = {0.0}, rl[2] = {0.0, 0.0};
+		const int32_t rc = flt.filter(x, ud, ua, rl);
+		std::printf("%ld,%.17g,%.17g,%.17g,%d,%u,%.17g,%.17g,%d\n", i, ua[0], rl[0], rl[1], rc, flt.nCriticalFacets_, ba[i],
+		            br[N + i], brc[i]);
+		std::printf("A,%ld", i);
+		for (uint32_t e = 0; e < flt.nc() * flt.nv(); e++) std::printf(",%.17g", flt.rowsA()[e]);
+		std::printf("\nb,%ld", i);
+		for (uint32_t e = 0; e < flt.nc(); e++) std::printf(",%.17g", flt.rowsb()[e]);
+		std::printf("\n");
+	}
+	return 0;
+}

@@ -106,3 +106,44 @@ def test_robust_class_single_agent_and_batch(hip, oracle):
     assert np.abs(res[:, 1] - ua[:, 0]).max() <= 1e-5
     assert np.abs(res[:, 2] - rl[:, 0]).max() <= 1e-5
     assert np.abs(res[:, 4] - ua[:, 0]).max() <= 1e-6
+
+
+def test_realizable_class_single_agent_and_batch(hip, oracle, tmp_path):
+    """ASIF::ASIFrealizable: facet search through facetSolver_ (2 x 5 QPs on the GPU), host affine arithmetic and
+    the full 29 x 38 rows must reproduce the oracle's rows bit for bit; single-agent filter() and filterBatch()
+    against the oracle's exact optimum; rc 1 / -2 identical."""
+    exe = os.path.join(HOST, "realizable_di")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HOST, "-s"])
+    k = oracle.load_kernel("100Hz")
+    kfile = tmp_path / "kernel.txt"
+    with open(kfile, "w") as f:
+        nF, nA = k["facetVertices"].shape[0], k["maxActiveConstraints"]
+        f.write(f"{k['vertices'].shape[0]} {nF} {k['maxCriticalFacets']} {nA}\n")
+        for v in k["vertices"]:
+            f.write(f"{float(v[0])!r} {float(v[1])!r}\n")
+        for i in range(nF):
+            f.write(" ".join([str(int(t)) for t in k["facetVertices"][i]] + [repr(float(t)) for t in k["facetNormals"][i]] +
+                             [str(int(t)) for t in k["facetActive"][i]]) + "\n")
+    n = 96
+    x, u = oracle.make_batch_realizable(k, n)
+    stdin = "".join(f"{float(x[i, 0])!r} {float(x[i, 1])!r} {float(u[i, 0])!r}\n" for i in range(n))
+    out = subprocess.run([exe, str(kfile)], input=stdin, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().split("\n")[1:]
+    res = np.array([[float(v) for v in l.split(",")] for l in lines if l[0] not in "Ab"])
+    rowsA = np.array([[float(v) for v in l.split(",")[2:]] for l in lines if l.startswith("A,")])
+    rowsb = np.array([[float(v) for v in l.split(",")[2:]] for l in lines if l.startswith("b,")])
+    z = oracle.Realizable(k)
+    A, b, code, info = z.assemble(x)
+    assert np.array_equal(res[:, 5].astype(int), info[:, 0])  # critical-facet counts found through the facet QPs
+    assert np.array_equal(rowsA, A) and np.array_equal(rowsb, b)
+    ua, rl, rc = z.filter(x, u)
+    assert np.array_equal(res[:, 4].astype(int), rc) and np.array_equal(res[:, 8].astype(int), rc)
+    assert {1, -2} <= set(rc.tolist()) and (info[:, 0] > 0).sum() > 10
+    ok = rc == 1
+    assert np.abs(res[ok, 1] - ua[ok, 0]).max() <= 1e-5      # single agent (wave-per-QP kernel, plain ADMM)
+    assert np.abs(res[ok, 3] - rl[ok, 1]).max() <= 1e-5
+    assert np.abs(res[ok, 2] - rl[ok, 0]).max() <= 1e-5
+    assert np.abs(res[ok, 6] - ua[ok, 0]).max() <= 1e-6      # batch
+    assert np.abs(res[ok, 7] - rl[ok, 1]).max() <= 1e-6
