@@ -135,6 +135,7 @@ extern "C" int asif_hip_default_solver(asif_hip_solver *s)
 	s->refine_steps = 2;
 	s->adaptive_rho = 1;
 	s->lanes_per_qp = 0;
+	s->presolve = 0;
 	return ASIF_HIP_OK;
 }
 

@@ -11,8 +11,10 @@
 
 namespace asif {
 
-template <class M, int G>
-__global__ __launch_bounds__(64) void explicit_filter_kernel(DevOptions o, asif_hip_solver S, FilterArgs a,
+// PRE = asif_hip_solver::presolve: its own instantiation, so that the closed-form path does not carry the
+// solver's register footprint.
+template <class M, int G, bool PRE>
+__global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_filter_kernel(DevOptions o, asif_hip_solver S, FilterArgs a,
                                                              bool assemble_only)
 {
 	constexpr int NX = M::NX, NU = M::NU, NP = M::NPSS, NV = NU + 1, NC = NP;
@@ -57,6 +59,37 @@ __global__ __launch_bounds__(64) void explicit_filter_kernel(DevOptions o, asif_
 				a.b[r * a.ld + i] = -Lfh[r];
 			}
 			a.code[i] = 1;
+		}
+		return;
+	}
+
+	if constexpr (PRE) {
+		static_assert(NU == 1, "closed form needs a single input");
+		// The explicit class pins its relaxation variable (lb = ub = relaxLb, src/asif.cpp:88-91), so with one
+		// input the QP is  min (u - uDes)^2  s.t.  Lgh_r u >= -Lfh_r - h_r relaxLb,  lb <= u <= ub:  a clip.
+		double lo = o.lb[0], hi = o.ub[0];
+		bool feasible = true;
+#pragma unroll
+		for (int r = 0; r < NC; r++) {
+			const double a_ = Lgh[r], rhs = -Lfh[r] - h[r] * o.relaxLb;
+			if (a_ > 0.0) lo = fmax(lo, rhs / a_);
+			else if (a_ < 0.0) hi = fmin(hi, rhs / a_);
+			else if (rhs > 0.0) feasible = false;
+		}
+		feasible = feasible && (lo <= hi);
+		if (live && g == 0) {
+			if (feasible) {
+				a.uact[i] = fmin(fmax(fmin(fmax(uDes[0], lo), hi), o.lb[0]), o.ub[0]);
+				a.relax[i] = o.relaxLb;
+				a.rc[i] = ASIF_HIP_RC_OK;
+			} else {
+				a.rc[i] = ASIF_HIP_RC_QP_FAILED;
+			}
+			if (a.diag) {
+				a.diag[0 * a.ld + i] = 0.0;
+				a.diag[1 * a.ld + i] = 0.0;
+				a.diag[(a.ndiag - 1) * a.ld + i] = 0.0;
+			}
 		}
 		return;
 	}
@@ -116,8 +149,8 @@ static int launch_g(const DevOptions &o, const asif_hip_solver &S, const FilterA
                     hipStream_t stream)
 {
 	const int block = 64;
-	hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, G>), dim3(grid_for(a.B, G, block)), dim3(block), 0,
-	                   stream, o, S, a, assemble_only);
+	hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, G, false>), dim3(grid_for(a.B, G, block)), dim3(block),
+	                   0, stream, o, S, a, assemble_only);
 	return (int)hipGetLastError();
 }
 
@@ -125,6 +158,12 @@ int launch_explicit_di(const DevOptions &o, const asif_hip_solver &S, const Filt
                        hipStream_t stream)
 {
 	if (a.B <= 0) return 0;
+	if (S.presolve && !assemble_only) { // closed form, one instance per lane, larger blocks (tiny register footprint)
+		const int block = 256;
+		hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, 1, true>), dim3(grid_for(a.B, 1, block)), dim3(block),
+		                   0, stream, o, S, a, false);
+		return (int)hipGetLastError();
+	}
 	switch (S.lanes_per_qp) {
 	case 2: return launch_g<2>(o, S, a, assemble_only, stream);
 	case 4: return launch_g<4>(o, S, a, assemble_only, stream);

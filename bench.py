@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--kernel", default="100Hz", help="config 6: RealizableKernelData_<name> polytope")
+    ap.add_argument("--presolve", type=int, default=0,
+                    help="asif_hip_solver.presolve (config 2: closed-form clip instead of the in-kernel ADMM; default 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -137,7 +139,7 @@ def main():
     dev = torch.device("cuda", grp.local_rank if (grp.world > 1 and not rehearsal) else 0)
 
     cfg = args.config
-    solver = capi.default_solver(lanes_per_qp=args.lanes)
+    solver = capi.default_solver(lanes_per_qp=args.lanes, presolve=args.presolve)
     if cfg == REALIZABLE_CFG:
         default_b = 65536
         kernel = workloads.load_kernel(args.kernel)
@@ -229,6 +231,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": WORKLOAD[cfg], "batch_per_gpu": B, "sharding": "instances, no collective",
                    "lanes_per_qp": args.lanes or "default",
+                   "presolve": args.presolve,
                    "rc_histogram": {str(int(k)): int(v) for k, v in zip(*np.unique(rc_host, return_counts=True))},
                    "qp_solved_fraction": solved / B},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -109,6 +109,11 @@ typedef struct asif_hip_solver {
 	int32_t refine_steps;      /* refinement steps of each regularised working-set solve */
 	int32_t adaptive_rho;
 	int32_t lanes_per_qp;   /* 0 = library default for the shape */
+	/* 1: eliminate variables whose bounds pin them (lb == ub) before the solve and, when one free variable is left,
+	 * take the closed-form optimum (a clip) instead of iterating.  Applies to the explicit class ASIF, whose
+	 * relaxation variable is pinned by construction (src/asif.cpp:88-91).  Same optimum, same return codes.
+	 * Default 0: every QP goes through the in-kernel ADMM the way the reference sends every QP through OSQP. */
+	int32_t presolve;
 } asif_hip_solver;
 
 typedef struct asif_hip_dims {

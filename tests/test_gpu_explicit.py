@@ -78,3 +78,18 @@ def test_edge_cases(hip, oracle):
     ua, rl, rc = gpu_util.oracle_filter(oracle, 2, x, ud, uact_init=9.0)
     assert np.array_equal(out["rc"], rc)
     assert np.abs(out["uact"] - ua).max() <= U_TOL
+
+
+def test_presolve_closed_form_equals_admm_path(hip, oracle):
+    """asif_hip_solver.presolve = 1: the pinned relaxation variable is eliminated and the one-variable QP is a
+    clip.  Same optimum (to rounding) and the same return codes as the exact solver and as the ADMM path."""
+    B = 65536
+    pre = gpu_util.run_filter(2, B, solver=hip.default_solver(presolve=1), uact_init=7.0, relax_init=-7.0)
+    adm = gpu_util.run_filter(2, B, uact_init=7.0, relax_init=-7.0)
+    ua, rl, rc = gpu_util.oracle_filter(oracle, 2, pre["x"], pre["udes"], uact_init=7.0, relax_init=-7.0)
+    assert np.array_equal(pre["rc"], rc) and np.array_equal(adm["rc"], rc)
+    assert np.abs(pre["uact"] - ua).max() <= 1e-12
+    assert np.abs(pre["uact"] - adm["uact"]).max() <= 1e-12
+    ok = rc == 1
+    assert np.all(pre["relax"][0, ok] == 5.0) and np.all(pre["relax"][0, ~ok] == -7.0)
+    assert np.all(pre["uact"][0, ~ok] == 7.0)
