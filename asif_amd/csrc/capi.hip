@@ -512,13 +512,7 @@ extern "C" int asif_hip_update_options(asif_hip_ctx *ctx, const asif_hip_options
 // allocation a filter call can make; size it once with a first call before capturing a graph).
 static int stage_rows(asif_hip_ctx *ctx, FilterArgs &a)
 {
-	// the robust filter stages its reduced 2-variable rows (2 x 16 + 16 per instance), which can be
-	// more than nc*nv + nc when there are few half-planes
-	int64_t nA = (int64_t)ctx->dims.nc * ctx->dims.nv, nb = ctx->dims.nc;
-	if (ctx->variant == ASIF_HIP_ROBUST) {
-		if (nA < 2 * 2 * ASIF_HIP_MAX_HALFPLANES) nA = 2 * 2 * ASIF_HIP_MAX_HALFPLANES;
-		if (nb < 2 * ASIF_HIP_MAX_HALFPLANES) nb = 2 * ASIF_HIP_MAX_HALFPLANES;
-	}
+	const int64_t nA = (int64_t)ctx->dims.nc * ctx->dims.nv, nb = ctx->dims.nc;
 	const int64_t need = (nA + nb) * a.ld;
 	if (need > ctx->s_cap) {
 		if (ctx->s_rows) (void)hipFree(ctx->s_rows);
@@ -562,13 +556,8 @@ static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipSt
 		}
 		return launch_tb_segway(ctx->dev, ctx->solver, a, assemble_only, stream);
 	}
-	if (ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST && ctx->variant == ASIF_HIP_ROBUST) {
-		if (!assemble_only) {
-			int r = stage_rows(ctx, a);
-			if (r) return r;
-		}
-		return launch_robust_ip(ctx->dev, ctx->solver, a, assemble_only, stream);
-	}
+	if (ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST && ctx->variant == ASIF_HIP_ROBUST)
+		return launch_robust_ip(ctx->dev, ctx->solver, a, assemble_only, stream); // fused, nothing staged
 	return ASIF_HIP_EINVAL;
 }
 

@@ -1,10 +1,11 @@
 // k_robust.hip -- robust explicit filter: ASIFrobust::filter, src/asif_robust.cpp:218-252.
 //
 // Stage 1  robust_rows_kernel, one instance per lane: ASIFrobust::updateConstraints (:275-367).
-//   State and safety-set gradient are lifted to affine forms (:282-284,322-324), the model dynamics
-//   run in affine arithmetic, Lfh = Dh f and Lgh = Dh g are formed with the reference's matmul order
-//   (include/asif_utils.h:22-62 instantiated on AAF), converted to intervals and scattered into the
-//   fixed sparsity pattern initialize() lays down (:103-133): per safety row s
+//   The reference lifts state and safety-set gradient to affine forms (:282-284,322-324), runs the model
+//   dynamics in affine arithmetic and forms Lfh = Dh f, Lgh = Dh g with its matmul (include/asif_utils.h:22-62
+//   instantiated on AAF); pendulum_point_lie() below is that computation at a point state with the zero terms
+//   dropped.  The intervals are scattered into the fixed sparsity pattern initialize() lays down (:103-133):
+//   per safety row s
 //       ineq  h_s d + lo(Lgh) l+_0 - hi(Lgh) l-_0 + lo(Lfh) l+_1 - hi(Lfh) l-_1 >= 0
 //       eq    -u + l+_0 - l-_0 = 0
 //       eq    l+_1 - l-_1 = 1 ,   l >= 0.
@@ -15,24 +16,53 @@
 //   the reference hands to OSQP is the optimum of this 2-variable, 2N-row QP -- H is zero on every
 //   multiplier (:89-90) and (u, d) is all filter() reads back (:243-248).  The reduced rows are what
 //   stage 1 stages in filter mode; qp_policy_kernel<2,16,2> solves them (rows beyond 2N are inert).
-#include "affine_dev.hpp"
 #include "qp_kernel.hpp"
 
 namespace asif {
 
-// examples/InvertedPendulum_Robust.cpp:62-69: f = (x1, sin x0), g = (0, [pMin,pMax]).
-// Symbol creation order is the statement order: sin's symbol, then g[1]'s.
-__device__ static void pendulum_dynamics_affine(const DevOptions &o, AfCtx &cx, const Af (&x)[2], Af (&f)[2], Af (&g)[2])
+// Interval Lie derivatives of the robust pendulum at a POINT state, src/asif_robust.cpp:282-337 on
+// examples/InvertedPendulum_Robust.cpp:62-69 (f = (x1, sin x0), g = (0, [pMin,pMax])).
+//
+// The reference lifts x and every entry of Dh to affine forms with ZERO radius, so along the whole
+// computation the only noise symbol with a non-zero coefficient is the one of g[1]; every other
+// coefficient libaffa carries is an exact zero (a.c*0, 0*rad, rad*0) that contributes |0| to the radius.
+// Written out with the same roundings (affine_dev.hpp evaluates the identical expressions generically and
+// is what the realizable filter's table kernel still uses):
+//   f[0] = AAF(interval(x1))             centre (x1+x1)/2 = x1
+//   f[1] = sin(AAF(interval(x0)))        width 0 < 1e-10 -> AAF(interval(t,t)), t = sin(x0*0.5 + x0*0.5)
+//   Lfh_s = (0 + Dh_s0*f0) + Dh_s1*f1    radius 0                      -> lo = hi
+//   Lgh_s = (0 + Dh_s0*0) + Dh_s1*gc     radius |Dh_s1*gr|, gc = (pMax+pMin)/2, gr = (pMax-pMin)/2
+// The affine forms of the previous implementation lived in per-lane scratch memory (5x the algorithmic HBM
+// traffic by the PMC counters); this needs a dozen flops and no memory.
+__device__ __forceinline__ static void pendulum_point_lie(const DevOptions &o, const double (&x)[2],
+                                                          const double (&Dh)[ASIF_HIP_MAX_HALFPLANES * 2], int N,
+                                                          double (&fl)[ASIF_HIP_MAX_HALFPLANES],
+                                                          double (&fh)[ASIF_HIP_MAX_HALFPLANES],
+                                                          double (&gl)[ASIF_HIP_MAX_HALFPLANES],
+                                                          double (&gh)[ASIF_HIP_MAX_HALFPLANES])
 {
-	f[0] = x[1];
-	af_sin(cx, x[0], f[1]);
-	af_const(g[0], 0.);
-	af_interval(cx, g[1], o.pMin, o.pMax);
+#pragma clang fp contract(off)
+	const double f0 = (x[1] + x[1]) / 2;
+	const double xs = x[0] * 0.5 + x[0] * 0.5;
+	const double t = sin(xs);
+	const double f1 = (t + t) / 2;
+	const double gc = (o.pMax + o.pMin) / 2, gr = (o.pMax - o.pMin) / 2;
+	for (int s = 0; s < N; s++) {
+		const double d0 = (Dh[s] + Dh[s]) / 2, d1 = (Dh[s + N] + Dh[s + N]) / 2; // centres of AAF(interval(Dh))
+		const double cf = (0.0 + d0 * f0) + d1 * f1;
+		fl[s] = cf - 0.0;
+		fh[s] = cf + 0.0;
+		const double cg = (0.0 + d0 * 0.0) + d1 * gc;
+		const double r = fabs(d1 * gr);
+		gl[s] = cg - r;
+		gh[s] = cg + r;
+	}
 }
 
 constexpr int kRobustRedRows = 2 * ASIF_HIP_MAX_HALFPLANES; // reduced QP: 2 rows per half-plane
 
-__global__ __launch_bounds__(64) void robust_rows_kernel(DevOptions o, FilterArgs a, bool reduced)
+// asif_hip_assemble_batch: the full rows the reference hands to updateA/updateb
+__global__ __launch_bounds__(64) void robust_rows_kernel(DevOptions o, FilterArgs a)
 {
 	using M = InvertedPendulumRobust;
 	constexpr int NX = M::NX, NU = M::NU, MAXNP = M::MAXNP;
@@ -46,49 +76,9 @@ __global__ __launch_bounds__(64) void robust_rows_kernel(DevOptions o, FilterArg
 #pragma unroll
 	for (int k = 0; k < NX; k++) x[k] = a.x[k * ld + i];
 	M::safetySet(o, x, h, Dh);
-
-	AfCtx cx = {0u, false};
-	Af xI[NX], f[NX], g[NX * NU];
-	for (int k = 0; k < NX; k++) af_interval(cx, xI[k], x[k], x[k]);
-	for (int k = 0; k < NX; k++) af_const(f[k], 0.0);
-	for (int k = 0; k < NX * NU; k++) af_const(g[k], 0.0);
-	pendulum_dynamics_affine(o, cx, xI, f, g);
-	Af DhI[MAXNP * NX];
-	for (int e = 0; e < N * NX; e++) af_interval(cx, DhI[e], Dh[e], Dh[e]);
 	double fl[MAXNP], fh[MAXNP], gl[MAXNP], gh[MAXNP];
-	for (int s = 0; s < N; s++) { // Lfh, include/asif_utils.h:46-62 on AAF
-		Af acc, t;
-		af_const(acc, 0.0);
-		for (int k = 0; k < NX; k++) {
-			af_mul(cx, DhI[s + k * N], f[k], t);
-			af_add(cx, acc, t, acc);
-		}
-		af_convert(acc, fl[s], fh[s]);
-	}
-	for (int s = 0; s < N; s++) { // Lgh (nu == 1), include/asif_utils.h:22-44 on AAF
-		Af acc, t;
-		af_const(acc, 0.0);
-		for (int k = 0; k < NX; k++) {
-			af_mul(cx, DhI[s + k * N], g[k], t);
-			af_add(cx, acc, t, acc);
-		}
-		af_convert(acc, gl[s], gh[s]);
-	}
-	if (cx.overflow) { // capacity exceeded: poison the rows so that nothing downstream can look valid
-		for (int s = 0; s < N; s++) fl[s] = fh[s] = gl[s] = gh[s] = __builtin_nan("");
-	}
-	if (reduced) {
-		for (int r = 0; r < kRobustRedRows; r++) {
-			const int s = r >> 1;
-			const bool valid = s < N;
-			const double lg = valid ? ((r & 1) ? gh[s] : gl[s]) : 0.0;
-			a.A[(int64_t)(r + 0 * kRobustRedRows) * ld + i] = lg;
-			a.A[(int64_t)(r + 1 * kRobustRedRows) * ld + i] = valid ? h[s] : 0.0;
-			a.b[(int64_t)r * ld + i] = valid ? -fl[s] : -1e20;
-		}
-		return;
-	}
-	// full rows: fixed structure (src/asif_robust.cpp:103-133) + interval entries (:340-358)
+	pendulum_point_lie(o, x, Dh, N, fl, fh, gl, gh);
+	// fixed structure (src/asif_robust.cpp:103-133) + interval entries (:340-358)
 	for (int e = 0; e < nc * nv; e++) a.A[(int64_t)e * ld + i] = 0.0;
 	for (int r = 0; r < nc; r++) a.b[(int64_t)r * ld + i] = 0.0;
 	int iCol = NU + 1;
@@ -107,18 +97,49 @@ __global__ __launch_bounds__(64) void robust_rows_kernel(DevOptions o, FilterArg
 		a.b[(int64_t)(iRow + NU + 1) * ld + i] = 1.0;
 		iCol += 2 * (NU + 1);
 	}
-	if (a.code) a.code[i] = cx.overflow ? -100 : 1;
+	if (a.code) a.code[i] = 1;
 }
 
 struct RobustPolicy {
 	int64_t B;
 	DevOptions o;
-	FilterArgs a; // a.A / a.b = staged reduced rows
+	FilterArgs a;
 
+	// Fused: every lane of the group assembles the rows of its instance from the state (a dozen flops per
+	// half-plane, cheaper than staging them through HBM) and keeps its share.  Reduced row r = 2s + p is
+	// [p ? hi(Lgh_s) : lo(Lgh_s), h_s] >= -lo(Lfh_s); lane g owns rows g, g+G, ...: s = (G/2) k + (g >> 1), p = g & 1.
 	template <int NV, int NC, int G>
 	__device__ __forceinline__ void load(int64_t i, int g, QpLaneData<NV, (NC + G - 1) / G> &qp) const
 	{
-		static_assert(NV == 2 && NC == kRobustRedRows, "reduced robust QP");
+		static_assert(NV == 2 && NC == kRobustRedRows && (G == 2 || G == 4 || G == 8), "reduced robust QP");
+		using M = InvertedPendulumRobust;
+		constexpr int MAXNP = M::MAXNP, RPL = (NC + G - 1) / G, H = G / 2;
+		const int N = o.nHalfPlanes;
+		double x[2], h[MAXNP], Dh[MAXNP * 2], fl[MAXNP], fh[MAXNP], gl[MAXNP], gh[MAXNP];
+		x[0] = a.x[i];
+		x[1] = a.x[a.ld + i];
+		M::safetySet(o, x, h, Dh);
+		pendulum_point_lie(o, x, Dh, N, fl, fh, gl, gh);
+		const bool hiRow = (g & 1) != 0;
+		const int sub = g >> 1;
+#pragma unroll
+		for (int k = 0; k < RPL; k++) {
+			double lg = 0.0, hs = 0.0, rhs = -1e20;
+#pragma unroll
+			for (int q = 0; q < H; q++) {
+				const int s = H * k + q; // compile-time
+				if (s < MAXNP) {
+					const bool pick = (q == sub) && (s < N);
+					lg = pick ? (hiRow ? gh[s] : gl[s]) : lg;
+					hs = pick ? h[s] : hs;
+					rhs = pick ? -fl[s] : rhs;
+				}
+			}
+			qp.A[k][0] = lg;
+			qp.A[k][1] = hs;
+			qp.b[k] = rhs;
+			qp.eq[k] = false;
+		}
 		// src/asif_robust.cpp:89-101,140-142 restricted to (u, delta)
 		qp.Hd[0] = 1.0;
 		qp.Hd[1] = o.relaxCost;
@@ -128,7 +149,6 @@ struct RobustPolicy {
 		qp.lb[1] = o.relaxLb;
 		qp.ub[0] = o.ub[0];
 		qp.ub[1] = o.inf;
-		load_rows<NV, NC, G>(a.A, a.b, a.ld, i, g, 0ull, qp);
 	}
 	template <int NV>
 	__device__ __forceinline__ void store(int64_t i, const double (&sol)[NV], int st, int it) const
@@ -148,14 +168,17 @@ int launch_robust_ip(const DevOptions &o, const asif_hip_solver &S, const Filter
                      hipStream_t stream)
 {
 	if (a.B <= 0) return 0;
-	hipLaunchKernelGGL(robust_rows_kernel, dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a, !assemble_only);
-	int e = (int)hipGetLastError();
-	if (e || assemble_only) return e;
+	if (assemble_only) {
+		hipLaunchKernelGGL(robust_rows_kernel, dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
+		return (int)hipGetLastError();
+	}
 	const RobustPolicy p = {a.B, o, a};
-	switch (S.lanes_per_qp) {
-	case 0:
+	int G = S.lanes_per_qp;
+	if (G == 0) G = a.B >= 32768 ? 2 : (a.B >= 16384 ? 4 : 8); // enough lane groups for one wave on every SIMD
+	switch (G) {
 	case 2: return launch_policy<2, kRobustRedRows, 2>(S, p, stream);
 	case 4: return launch_policy<2, kRobustRedRows, 4>(S, p, stream);
+	case 8: return launch_policy<2, kRobustRedRows, 8>(S, p, stream);
 	default: return ASIF_HIP_EINVAL;
 	}
 }

@@ -31,7 +31,6 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # algorithmic HBM bytes per instance of the state->input path: read 8(nx+nu), write 8(nu+nrelax)+4
 ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44, 6: 52}
 REALIZABLE_CFG = 6  # ASIFrealizable on the sampled double integrator; not a BASELINE.json config
-PMC_SUMMARY = {2: "r01/c2_v1_pmc_summary.json"}
 WORKLOAD = {
     2: "C2 DoubleIntegrator explicit CBF (ASIF::filter), seeded x in U[-1.2,1.2]^2, uDes in U[-1.5,1.5]",
     3: "C3 InvertedPendulum_Implicit (ASIFimplicit::filter, 5001-step backup trajectory)",
@@ -213,9 +212,12 @@ def main():
     # HBM traffic per launch: rocprofv3 PMC passes cannot run inside this process; the number comes from
     # the committed summary of the same command (profiles/, FETCH_SIZE x2 + WRITE_SIZE, in bytes)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY.get(cfg, ""))
-    if B == default_b and os.path.isfile(pmc):
-        traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+    tag = f"c{cfg}"
+    if cfg == 2 and args.presolve:
+        tag, default_b = "c2pre", 4194304  # the closed-form path was profiled at the HBM-bound batch size
+    pmc = os.path.join(ROOT, "profiles", "r01", f"{tag}_pmc_summary.json")
+    if B == default_b and os.path.isfile(pmc) and (cfg != REALIZABLE_CFG or args.kernel == "100Hz"):
+        traffic = json.load(open(pmc)).get("traffic_bytes_per_step")  # all kernels of one step
     out = {
         "metric": "QP solves/sec (batched filter())",
         "value": value,

@@ -44,7 +44,7 @@ def test_rows_match_reference_libaffa_golden(hip):
         np.testing.assert_allclose(A[col + 3, row], [-c["Lfh_hi"][s] for c in g["cases"]], rtol=1e-12, atol=1e-15)
 
 
-@pytest.mark.parametrize("lanes", [2, 4])
+@pytest.mark.parametrize("lanes", [2, 4, 8])
 def test_filter_matches_exact_optimum(hip, oracle, lanes):
     B = 8192
     s = hip.default_solver(lanes_per_qp=lanes)
