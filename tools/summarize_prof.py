@@ -20,7 +20,7 @@ def pmc(tag, name):
     files = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", f"pmc_{name}", "**", "*counter_collection.csv"),
                       recursive=True)
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
         agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return agg
 
