@@ -222,6 +222,30 @@ int64_t or_rz_filter_batch(const or_rz *z, int solver, const or_admm_settings *s
 int64_t or_rz_assemble_batch(const or_rz *z, int64_t B, const double *x, double *A, double *b, int32_t *code,
                              int32_t *info, int info_stride);
 
+/* ------------------------------------------------- robust filter on shipped half-plane data */
+/* ASIFrobust on examples/DoubleIntegrator_Robust.cpp + include/KernelData_*.h; or_robust_data.c. */
+typedef struct {
+	int32_t N, npSSmax;
+	const double *halfPlanes; /* [N][2]: 1 - a.x >= 0 (SafetySetData) */
+	double relaxCost, relaxLb, inf;
+	double lb[OR_MAX_NU], ub[OR_MAX_NU];
+	double mMin, mMax, Klo, Khi, Flo, Fhi;
+} or_rb_desc;
+typedef struct or_rb or_rb;
+
+void or_rb_default(or_rb_desc *d);
+or_rb *or_rb_create(const or_rb_desc *d);
+void or_rb_destroy(or_rb *z);
+void or_rb_dims(const or_rb *z, int *nv, int *nc, int *npSSmax);
+int or_rb_assemble(const or_rb *z, const double *x, double *A, double *b, int32_t *sel);
+void or_rb_qp_static(const or_rb *z, const double *uDes, double *Hd, double *c, double *lb, double *ub, uint8_t *be);
+int or_rb_filter(const or_rb *z, int solver, const or_admm_settings *s, const double *x, const double *uDes,
+                 double *uAct, double *relax);
+int64_t or_rb_filter_batch(const or_rb *z, int solver, const or_admm_settings *s, int64_t B, const double *x,
+                           const double *uDes, double *uAct, double *relax, int32_t *rc);
+int64_t or_rb_assemble_batch(const or_rb *z, int64_t B, const double *x, double *A, double *b, int32_t *code,
+                             int32_t *sel);
+
 /* SURVEY 8(d) RNG: splitmix64(seed*2^32 + k) -> r=(z>>11)*2^-53, k = i*16+j */
 double or_rng_uniform(uint64_t seed, uint64_t i, uint64_t j);
 /* Seeded synthetic batch of config cfg (2..5): fills x[B][nx], uDes[B][nu] */

@@ -147,6 +147,47 @@ int ref_rz_facet_lie(int nFacets, int nA, const double *vertices, const int *fac
 	return 0;
 }
 
+/* Interval Lie derivatives of examples/DoubleIntegrator_Robust.cpp exactly as ASIFrobust::updateConstraints
+ * (src/asif_robust.cpp:282-337) computes them for M selected half-planes hp[M][2] at the point state x:
+ * globals m, K, F first (:28-37), xInt, dynamics (:51-58), DhInt column-major, all Lfh, then all Lgh
+ * (include/asif_utils.h:22-62 restated on AAF).  out[s*4..] = lo(Lgh), hi(Lgh), lo(Lfh), hi(Lfh). */
+int ref_di_robust_lie(const double *x, int M, const double *hp, double mMin, double mMax, double Klo, double Khi,
+                      double Flo, double Fhi, double *out)
+{
+	const int nx = 2, nu = 1;
+	AAF::set_default(0);
+	const AAF mInt = interval(mMin, mMax), KInt = interval(Klo, Khi), FInt = interval(Flo, Fhi);
+	std::vector<AAF> xI(nx), f(nx), g(nx * nu), DhI(M * nx), Lfh(M), Lgh(M * nu);
+	for (int i = 0; i < nx; i++) xI[i] = interval(x[i]);
+	f[0] = xI[1];
+	f[1] = -FInt * xI[1] / mInt;
+	g[0] = 0.;
+	g[1] = KInt / mInt;
+	std::vector<double> Dh(M * nx);
+	for (int i = 0; i < M; i++) {
+		Dh[i] = -hp[2 * i];
+		Dh[i + M] = -hp[2 * i + 1];
+	}
+	for (int i = 0; i < M * nx; i++) DhI[i] = interval(Dh[i]);
+	for (int i = 0; i < M; i++) {
+		Lfh[i] = 0.0;
+		for (int k = 0; k < nx; k++) Lfh[i] = Lfh[i] + DhI[i + k * M] * f[k];
+	}
+	for (int i = 0; i < M; i++)
+		for (int j = 0; j < nu; j++) {
+			Lgh[i + j * M] = 0.0;
+			for (int k = 0; k < nx; k++) Lgh[i + j * M] = Lgh[i + j * M] + DhI[i + k * M] * g[k + j * nx];
+		}
+	for (int i = 0; i < M; i++) {
+		const interval a = Lgh[i].convert(), b = Lfh[i].convert();
+		out[i * 4 + 0] = a.left();
+		out[i * 4 + 1] = a.right();
+		out[i * 4 + 2] = b.left();
+		out[i * 4 + 3] = b.right();
+	}
+	return 0;
+}
+
 /* f, g midpoints of the same dynamics at a point state (src/asif_realizable.cpp:533-553) */
 int ref_rz_point_dynamics(const double *x, double mMin, double mMax, double Klo, double Khi, double Flo,
                           double Fhi, double *f, double *g)

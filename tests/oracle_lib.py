@@ -323,3 +323,95 @@ def make_batch_realizable(kernel, B, first=0, seed=6):
             x[k, 1] = 1.05 * vmax[1] * (2.0 * r(seed, i, 1) - 1.0)
         u[k, 0] = -20.0 + 40.0 * r(seed, i, 2)
     return x, u
+
+
+# ------------------------------------------- robust filter on shipped half-planes (oracle/or_robust_data.c)
+class RbDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("npSSmax", C.c_int32), ("halfPlanes", C.POINTER(C.c_double))] + [
+        (n, C.c_double) for n in ("relaxCost", "relaxLb", "inf")] + [("lb", C.c_double * 1), ("ub", C.c_double * 1)] + [
+        (n, C.c_double) for n in ("mMin", "mMax", "Klo", "Khi", "Flo", "Fhi")]
+
+
+def load_halfplanes(name="70-135kg"):
+    """SafetySetData of include/KernelData_<name>.h ([N,2]), from tests/golden/robust_halfplanes.json."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "robust_halfplanes.json")) as f:
+        return np.array(json.load(f)["sets"][name], dtype=np.float64)
+
+
+class RobustData:
+    """or_rb handle: ASIFrobust of examples/DoubleIntegrator_Robust.cpp on a half-plane set."""
+
+    def __init__(self, halfplanes, **kw):
+        L = lib()
+        L.or_rb_create.restype = C.c_void_p
+        for f in ("or_rb_filter_batch", "or_rb_assemble_batch"):
+            getattr(L, f).restype = C.c_int64
+        d = RbDesc()
+        L.or_rb_default(C.byref(d))
+        self._hp = np.ascontiguousarray(halfplanes, dtype=np.float64)
+        d.N = self._hp.shape[0]
+        d.halfPlanes = _p(self._hp)
+        for k, v in kw.items():
+            if k in ("lb", "ub"):
+                getattr(d, k)[0] = v[0]
+            else:
+                setattr(d, k, v)
+        self.desc = d
+        self.h = C.c_void_p(L.or_rb_create(C.byref(d)))
+        assert self.h.value, "or_rb_create failed"
+        nv, nc, m = (C.c_int() for _ in range(3))
+        L.or_rb_dims(self.h, C.byref(nv), C.byref(nc), C.byref(m))
+        self.nv, self.nc, self.npSSmax, self.N = nv.value, nc.value, m.value, d.N
+
+    def __del__(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            lib().or_rb_destroy(self.h)
+            self.h = None
+
+    def assemble(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        B = x.shape[0]
+        A = np.zeros((B, self.nc * self.nv))
+        b = np.zeros((B, self.nc))
+        code = np.zeros(B, dtype=np.int32)
+        sel = np.zeros((B, self.npSSmax), dtype=np.int32)
+        n = lib().or_rb_assemble_batch(self.h, C.c_int64(B), _p(x), _p(A), _p(b), _p(code, C.c_int32), _p(sel, C.c_int32))
+        assert n == B
+        return A, b, code, sel
+
+    def qp_static(self, udes):
+        Hd, c, lb, ub = (np.zeros(self.nv) for _ in range(4))
+        be = np.zeros(self.nc, dtype=np.uint8)
+        ud = np.ascontiguousarray(np.atleast_1d(udes), dtype=np.float64)
+        lib().or_rb_qp_static(self.h, _p(ud), _p(Hd), _p(c), _p(lb), _p(ub), _p(be, C.c_uint8))
+        return Hd, c, lb, ub, be
+
+    def filter(self, x, udes, solver=SOLVER_EXACT, settings=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        B = x.shape[0]
+        udes = np.ascontiguousarray(udes, dtype=np.float64).reshape(B, 1)
+        uact = np.full((B, 1), np.nan)
+        relax = np.full((B, 1), np.nan)
+        rc = np.zeros(B, dtype=np.int32)
+        sp = C.byref(settings) if settings is not None else None
+        n = lib().or_rb_filter_batch(self.h, solver, sp, C.c_int64(B), _p(x), _p(udes), _p(uact), _p(relax),
+                                     _p(rc, C.c_int32))
+        assert n == B
+        return uact, relax, rc
+
+
+def make_batch_robust_data(halfplanes, B, first=0, seed=7):
+    """Config 7 workload: states uniform over 1.1 x the bounding box of the polygon the half-planes cut out
+    (|x_k| <= 1.1 / min_i |a_ik| is too wide; the support is taken from 1/|a| per axis), uDes in [-20, 20]."""
+    a = np.abs(halfplanes)
+    ext = 1.1 * np.array([1.0 / a[:, 0].max(), 1.0 / a[:, 1].max()])
+    x = np.zeros((B, 2))
+    u = np.zeros((B, 1))
+    r = lib().or_rng_uniform
+    for k in range(B):
+        i = first + k
+        x[k, 0] = ext[0] * (2.0 * r(seed, i, 0) - 1.0)
+        x[k, 1] = ext[1] * (2.0 * r(seed, i, 1) - 1.0)
+        u[k, 0] = -20.0 + 40.0 * r(seed, i, 2)
+    return x, u
