@@ -27,11 +27,19 @@ EXPORTS = [
     "asif_hip_default_solver", "asif_hip_create", "asif_hip_destroy", "asif_hip_get_dims",
     "asif_hip_update_options", "asif_hip_filter_batch", "asif_hip_assemble_batch", "asif_hip_qp_solve_batch",
     "asif_hip_filter_batch_host", "asif_hip_default_realizable_options", "asif_hip_create_realizable",
-    "asif_hip_update_realizable_options", "asif_hip_realizable_tables",
+    "asif_hip_update_realizable_options", "asif_hip_realizable_tables", "asif_hip_default_robust_data_options",
+    "asif_hip_create_robust_data", "asif_hip_update_robust_data_options",
 ]
 
 MODEL_DOUBLE_INTEGRATOR_SAMPLED = 4
+MODEL_DOUBLE_INTEGRATOR_ROBUST = 5
 REALIZABLE = 4
+
+
+class RobustDataOptions(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("relaxCost", "relaxLb", "inf")] + [
+        ("lb", C.c_double * 1), ("ub", C.c_double * 1), ("npSSmax", C.c_int32)] + [
+        (n, C.c_double) for n in ("mMin", "mMax", "Klo", "Khi", "Flo", "Fhi")]
 
 
 class KernelData(C.Structure):
@@ -101,6 +109,10 @@ def load():
                                                    C.POINTER(RealizableOptions), C.POINTER(Solver), C.c_int]
         lib.asif_hip_update_realizable_options.argtypes = [vp, C.POINTER(RealizableOptions)]
         lib.asif_hip_realizable_tables.argtypes = [vp, vp, vp]
+        lib.asif_hip_default_robust_data_options.argtypes = [C.c_int, C.POINTER(RobustDataOptions)]
+        lib.asif_hip_create_robust_data.argtypes = [C.POINTER(C.c_void_p), C.c_int, vp, C.c_int32,
+                                                    C.POINTER(RobustDataOptions), C.POINTER(Solver), C.c_int]
+        lib.asif_hip_update_robust_data_options.argtypes = [vp, C.POINTER(RobustDataOptions)]
         _lib = lib
     return _lib
 
@@ -230,6 +242,42 @@ class RealizableFilter(Filter):
         bb = np.zeros((self.nFacets, 2, 2))
         check(self.lib.asif_hip_realizable_tables(self.handle, C.c_void_p(t.ctypes.data), C.c_void_p(bb.ctypes.data)))
         return t, bb
+
+
+def default_robust_data_options(model=MODEL_DOUBLE_INTEGRATOR_ROBUST, **overrides):
+    o = RobustDataOptions()
+    check(load().asif_hip_default_robust_data_options(model, C.byref(o)))
+    for k, v in overrides.items():
+        if k in ("lb", "ub"):
+            getattr(o, k)[0] = v[0]
+        else:
+            setattr(o, k, v)
+    return o
+
+
+class RobustDataFilter(Filter):
+    """ASIFrobust on a half-plane data set [N,2] (numpy f64), npSSmax rows kept per call:
+    the reference's examples/DoubleIntegrator_Robust.cpp."""
+
+    def __init__(self, halfplanes, options=None, solver=None, device=0, model=MODEL_DOUBLE_INTEGRATOR_ROBUST):
+        import numpy as np
+        self.lib = load()
+        self.model, self.variant, self.device = model, ROBUST, device
+        self.options = options if options is not None else default_robust_data_options(model)
+        self.solver = solver if solver is not None else default_solver()
+        hp = np.ascontiguousarray(halfplanes, dtype=np.float64)
+        h = C.c_void_p()
+        check(self.lib.asif_hip_create_robust_data(C.byref(h), model, C.c_void_p(hp.ctypes.data), hp.shape[0],
+                                                   C.byref(self.options), C.byref(self.solver), device))
+        self.handle = h
+        d = Dims()
+        check(self.lib.asif_hip_get_dims(self.handle, C.byref(d)))
+        self.dims = d
+
+    def update_options(self, options):
+        check(self.lib.asif_hip_update_robust_data_options(self.handle, C.byref(options)))
+        self.options = options
+        check(self.lib.asif_hip_get_dims(self.handle, C.byref(self.dims)))
 
 
 def qp_solve_batch(Hd, c, A, b, lb, ub, sol, status, iters=None, be=None, solver=None, device=0):

@@ -32,7 +32,8 @@ constexpr double kRhoMin = 1e-6;
 constexpr double kRhoMax = 1e6;
 constexpr double kRhoEqOverIneq = 1e3;
 constexpr double kRhoTol = 1e-4;
-constexpr double kPolishDelta = 1e-6;
+constexpr double kPolishDelta = 1e-9;     // 1/penalty of the working-set solve (see finish())
+constexpr double kPolishPrimalReg = 1e-6; // curvature lent to variables the cost does not touch
 constexpr double kPolishKktTol = 1e-9;
 
 constexpr int kStatusSolved = 1;
@@ -358,9 +359,9 @@ struct AdmmSmall {
 	//             sum r_i v_i = |v|^2 > 0): the QP is infeasible,
 	//   return 0  undecided -> ADMM keeps iterating and the next check tries again.
 	// act: 0 inactive, -1 at lower bound, +1 at upper bound, 2 equality (always in, multiplier free).
-	__device__ __forceinline__ int finish(double (&xp)[NV], int rounds, int refine)
+	// idl: penalty (1/delta) of the working-set solve; the caller raises it after an undecided attempt.
+	__device__ __forceinline__ int finish(double (&xp)[NV], int rounds, int refine, double idl)
 	{
-		const double idelta = 1.0 / kPolishDelta;
 		int act[RPL], actb[NV];
 		double nu[RPL], nub[NV], rtb[NV];
 #pragma unroll
@@ -378,6 +379,11 @@ struct AdmmSmall {
 		for (int round = 0; round <= rounds; round++) {
 			stat_rounds++;
 			// -- equality-constrained solve on the working set
+			// Method of multipliers on the working rows with penalty idl = 1/delta, `refine` steps from zero.  Its
+			// contraction factor is about delta / (delta + s^2), s the smallest singular value of the (scaled)
+			// working rows seen through P^-1/2.  With 1/delta = 1e9 two steps meet the rows unless they are parallel
+			// to ~1e-4; the corrections below usually cope with an unconverged solve (one of two parallel rows
+			// leaves); where they do not, the attempt ends undecided and solve() repeats it with 1000x the penalty.
 			double Mp[NV][NV], Mi[NV];
 #pragma unroll
 			for (int a = 0; a < NV; a++)
@@ -386,9 +392,9 @@ struct AdmmSmall {
 					double s = 0.0;
 #pragma unroll
 					for (int r = 0; r < RPL; r++) s += act[r] ? A[r][a] * A[r][b] : 0.0;
-					s = gsum<G>(s) * idelta;
+					s = gsum<G>(s) * idl;
 					// primal regularisation only where the cost has no curvature of its own
-					if (a == b) s += (P[a] > 0.0 ? P[a] : kPolishDelta) + (actb[a] ? Ab[a] * Ab[a] * idelta : 0.0);
+					if (a == b) s += (P[a] > 0.0 ? P[a] : kPolishPrimalReg) + (actb[a] ? Ab[a] * Ab[a] * idl : 0.0);
 					Mp[a][b] = s;
 				}
 			bool ok = ldl_factor<NV>(Mp, Mi);
@@ -407,7 +413,7 @@ struct AdmmSmall {
 #pragma unroll
 					for (int j = 0; j < NV; j++) ax += A[r][j] * xp[j];
 					e2[r] = l[r] - ax;
-					const double w = act[r] ? (e2[r] * idelta - nu[r]) : 0.0;
+					const double w = act[r] ? (e2[r] * idl - nu[r]) : 0.0;
 #pragma unroll
 					for (int j = 0; j < NV; j++) rhs[j] += A[r][j] * w;
 				}
@@ -415,7 +421,7 @@ struct AdmmSmall {
 				for (int j = 0; j < NV; j++) {
 					rhs[j] = gsum<G>(rhs[j]);
 					e2b[j] = rtb[j] - Ab[j] * xp[j];
-					rhs[j] += -q[j] - P[j] * xp[j] + (actb[j] ? Ab[j] * (e2b[j] * idelta - nub[j]) : 0.0);
+					rhs[j] += -q[j] - P[j] * xp[j] + (actb[j] ? Ab[j] * (e2b[j] * idl - nub[j]) : 0.0);
 				}
 				ldl_solve<NV>(Mp, Mi, rhs); // rhs = dx
 #pragma unroll
@@ -423,11 +429,11 @@ struct AdmmSmall {
 					double adx = 0.0;
 #pragma unroll
 					for (int j = 0; j < NV; j++) adx += A[r][j] * rhs[j];
-					nu[r] += act[r] ? (adx - e2[r]) * idelta : 0.0;
+					nu[r] += act[r] ? (adx - e2[r]) * idl : 0.0;
 				}
 #pragma unroll
 				for (int j = 0; j < NV; j++) {
-					nub[j] += actb[j] ? (Ab[j] * rhs[j] - e2b[j]) * idelta : 0.0;
+					nub[j] += actb[j] ? (Ab[j] * rhs[j] - e2b[j]) * idl : 0.0;
 					xp[j] += rhs[j];
 				}
 			}
@@ -614,6 +620,7 @@ struct AdmmSmall {
 		bool fact_ok = set_rho_and_factor(S_.rho, S_.sigma);
 		const double cinv = pow2_inv(cs);
 		int it = 0;
+		double penalty = 1.0 / kPolishDelta; // of the finish's working-set solves; per problem, see finish()
 		const int K = S_.check_interval > 0 ? S_.check_interval : 10;
 		while (it < S_.max_iter) {
 			if (__all(status != 0)) break; // wave-uniform: every lane has latched its result
@@ -628,13 +635,15 @@ struct AdmmSmall {
 			for (int j = 0; j < NV; j++) xs[j] = x[j];
 			if (S_.polish) {
 				double xp[NV];
-				const int v = finish(xp, S_.active_set_rounds, S_.refine_steps);
+				const int v = finish(xp, S_.active_set_rounds, S_.refine_steps, penalty);
 				if (v == 1) {
 					st = kStatusSolved;
 #pragma unroll
 					for (int j = 0; j < NV; j++) xs[j] = xp[j];
 				} else if (v == 2) {
 					st = kStatusPrimalInf;
+				} else if (status == 0 && penalty < 1e14) {
+					penalty *= 1e3; // undecided: the next attempt, K iterations on, solves its working sets more stiffly
 				}
 			}
 			// The residual tests below are only needed by lanes the finish left undecided

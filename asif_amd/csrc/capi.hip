@@ -32,6 +32,12 @@ struct asif_hip_ctx {
 		double *d_vertices, *d_normals, *d_facetRec, *d_table, *d_pointC;
 		int32_t *d_fverts, *d_factive, *d_overflow;
 	} *rz;
+	// robust filter on a half-plane data set (nullptr otherwise)
+	struct RobustData {
+		asif_hip_robust_data_options opts;
+		RbDev dev;
+		double *d_hp, *d_pointC;
+	} *rb;
 };
 
 extern "C" int asif_hip_version(void) { return ASIF_HIP_VERSION; }
@@ -463,12 +469,137 @@ extern "C" int asif_hip_realizable_tables(asif_hip_ctx *ctx, double *table, doub
 	return ASIF_HIP_OK;
 }
 
+// ---- robust filter on a half-plane data set ---------------------------------------------------------
+// examples/DoubleIntegrator_Robust.cpp:20-37,85-90
+extern "C" int asif_hip_default_robust_data_options(int model, asif_hip_robust_data_options *o)
+{
+	if (!o || model != ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_ROBUST) return ASIF_HIP_EINVAL;
+	std::memset(o, 0, sizeof(*o));
+	o->relaxCost = 50.0;
+	o->relaxLb = 5.0;
+	o->inf = 1e20;
+	o->lb[0] = -20;
+	o->ub[0] = 20;
+	o->npSSmax = 5;
+	o->mMin = 70.;
+	o->mMax = 135.;
+	o->Klo = 5.7 - 0.1;
+	o->Khi = 5.7 + 0.1;
+	o->Flo = 23 - 2; // FInt = interval(F-DF, F-DF), :37
+	o->Fhi = 23 - 2;
+	return ASIF_HIP_OK;
+}
+
+static void rb_free(asif_hip_ctx::RobustData *r)
+{
+	if (!r) return;
+	(void)hipFree(r->d_hp);
+	(void)hipFree(r->d_pointC);
+	delete r;
+}
+
+static int rb_configure(asif_hip_ctx *c, const asif_hip_robust_data_options &o)
+{
+	asif_hip_ctx::RobustData *r = c->rb;
+	RbDev &z = r->dev;
+	int M = o.npSSmax;
+	if (M < 0 || M > z.N) M = z.N; // src/asif_robust.cpp:20
+	if (M < 1 || M > 8) return ASIF_HIP_EUNSUPPORTED;
+	r->opts = o;
+	z.npSSmax = M;
+	z.relaxCost = o.relaxCost;
+	z.relaxLb = o.relaxLb;
+	z.inf = o.inf;
+	z.lb = o.lb[0];
+	z.ub = o.ub[0];
+	z.mMin = o.mMin;
+	z.mMax = o.mMax;
+	z.Klo = o.Klo;
+	z.Khi = o.Khi;
+	z.Flo = o.Flo;
+	z.Fhi = o.Fhi;
+	asif_hip_dims &d = c->dims;
+	std::memset(&d, 0, sizeof(d));
+	d.nx = 2;
+	d.nu = 1;
+	d.npSS = z.N;
+	d.nv = 2 + 4 * M; // src/asif_robust.cpp:21
+	d.nc = 3 * M;     // :22
+	d.nrelax = 1;
+	d.ndiag = M + 1;
+	int rc = launch_robust_data_point(z, r->d_pointC, nullptr);
+	if (rc) return rc;
+	double pc[kRbPoint];
+	hipError_t e = hipMemcpy(pc, r->d_pointC, sizeof(pc), hipMemcpyDeviceToHost);
+	if (e != hipSuccess) return (int)e;
+	return pc[kRbPoint - 1] != 0.0 ? ASIF_HIP_EUNSUPPORTED : ASIF_HIP_OK;
+}
+
+extern "C" int asif_hip_create_robust_data(asif_hip_ctx **out, int model, const double *halfPlanes, int32_t N,
+                                           const asif_hip_robust_data_options *opts, const asif_hip_solver *solver,
+                                           int device)
+{
+	if (!out) return ASIF_HIP_EINVAL;
+	*out = nullptr;
+	if (model != ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_ROBUST || !halfPlanes || N < 1) return ASIF_HIP_EINVAL;
+	asif_hip_robust_data_options o;
+	if (opts) o = *opts;
+	else asif_hip_default_robust_data_options(model, &o);
+	int r = check_device(device);
+	if (r) return r;
+	hipError_t e = hipSetDevice(device);
+	if (e != hipSuccess) return (int)e;
+	asif_hip_ctx *c = new (std::nothrow) asif_hip_ctx();
+	if (!c) return ASIF_HIP_EINVAL;
+	std::memset(c, 0, sizeof(*c));
+	c->model = model;
+	c->variant = ASIF_HIP_ROBUST;
+	c->device = device;
+	if (solver) c->solver = *solver;
+	else asif_hip_default_solver(&c->solver);
+	c->rb = new (std::nothrow) asif_hip_ctx::RobustData();
+	if (!c->rb) {
+		delete c;
+		return ASIF_HIP_EINVAL;
+	}
+	std::memset(c->rb, 0, sizeof(*c->rb));
+	c->rb->dev.N = N;
+	e = hipMalloc((void **)&c->rb->d_hp, sizeof(double) * 2 * N);
+	if (e == hipSuccess) e = hipMalloc((void **)&c->rb->d_pointC, sizeof(double) * kRbPoint);
+	if (e == hipSuccess) e = hipMemcpy(c->rb->d_hp, halfPlanes, sizeof(double) * 2 * N, hipMemcpyHostToDevice);
+	c->rb->dev.hp = c->rb->d_hp;
+	c->rb->dev.pointC = c->rb->d_pointC;
+	r = (e == hipSuccess) ? rb_configure(c, o) : (int)e;
+	if (r != ASIF_HIP_OK) {
+		rb_free(c->rb);
+		delete c;
+		return r;
+	}
+	*out = c;
+	return ASIF_HIP_OK;
+}
+
+extern "C" int asif_hip_update_robust_data_options(asif_hip_ctx *ctx, const asif_hip_robust_data_options *opts)
+{
+	if (!ctx || !opts || !ctx->rb) return ASIF_HIP_EINVAL;
+	hipError_t e = hipSetDevice(ctx->device);
+	if (e != hipSuccess) return (int)e;
+	const asif_hip_robust_data_options keep = ctx->rb->opts;
+	int r = rb_configure(ctx, *opts);
+	if (r) (void)rb_configure(ctx, keep);
+	return r;
+}
+
 extern "C" int asif_hip_destroy(asif_hip_ctx *ctx)
 {
 	if (!ctx) return ASIF_HIP_EINVAL;
 	if (ctx->rz) {
 		(void)hipSetDevice(ctx->device);
 		rz_free(ctx->rz);
+	}
+	if (ctx->rb) {
+		(void)hipSetDevice(ctx->device);
+		rb_free(ctx->rb);
 	}
 	if (ctx->s_rows) {
 		(void)hipSetDevice(ctx->device);
@@ -540,6 +671,7 @@ static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipSt
 {
 	if (ctx->variant == ASIF_HIP_REALIZABLE)
 		return ctx->rz ? launch_realizable(ctx->rz->dev, ctx->solver, a, assemble_only, stream) : ASIF_HIP_EINVAL;
+	if (ctx->rb) return launch_robust_data(ctx->rb->dev, ctx->solver, a, assemble_only, stream);
 	if (ctx->model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR && ctx->variant == ASIF_HIP_EXPLICIT)
 		return launch_explicit_di(ctx->dev, ctx->solver, a, assemble_only, stream);
 	if (ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM && ctx->variant == ASIF_HIP_IMPLICIT) {

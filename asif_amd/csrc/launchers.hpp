@@ -57,6 +57,19 @@ int launch_realizable_tables(const RzDev &z, const double *vertices, const int32
 int launch_realizable(const RzDev &z, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                       hipStream_t stream);
 
+// robust filter (class ASIFrobust) on a half-plane data set, model = DoubleIntegratorRobust; k_robust_data.hip
+constexpr int kRbPoint = 12; // state-independent constants of the point-state interval dynamics
+struct RbDev {
+	const double *hp;     // [N][2] half-planes 1 - a.x >= 0, device
+	const double *pointC; // [kRbPoint], device
+	int N, npSSmax;
+	double relaxCost, relaxLb, inf, lb, ub;
+	double mMin, mMax, Klo, Khi, Flo, Fhi;
+};
+int launch_robust_data_point(const RbDev &z, double *pointC, hipStream_t stream);
+int launch_robust_data(const RbDev &z, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                       hipStream_t stream);
+
 struct QpArgs {
 	int64_t B, ld;
 	int nv, nc;

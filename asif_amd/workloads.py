@@ -57,6 +57,29 @@ def load_kernel(name="100Hz", path=None):
                 maxCriticalFacets=int(k["maxCriticalFacets"]), maxActiveConstraints=int(k["maxActiveConstraints"]))
 
 
+def load_halfplanes(name="70-135kg", path=None):
+    """SafetySetData of the reference's include/KernelData_<name>.h ([N,2] float64), kept as numbers under
+    tests/golden/robust_halfplanes.json."""
+    import json
+    import os
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                            "robust_halfplanes.json")
+    with open(path) as f:
+        return np.array(json.load(f)["sets"][name], dtype=np.float64)
+
+
+def make_batch_robust_data(halfplanes, B, first=0, seed=7):
+    """Config 7 (robust filter on the shipped half-planes): states uniform over 1.1 x the extent of the polygon
+    along each axis (so part of the batch starts outside), uDes uniform in [-20, 20].  SoA x [2,B], udes [1,B]."""
+    i = np.arange(first, first + B, dtype=np.uint64)
+    a = np.abs(halfplanes)
+    ext = 1.1 * np.array([1.0 / a[:, 0].max(), 1.0 / a[:, 1].max()])
+    x = np.stack([ext[0] * (2.0 * uniform(seed, i, 0) - 1.0), ext[1] * (2.0 * uniform(seed, i, 1) - 1.0)])
+    u = (-20.0 + 40.0 * uniform(seed, i, 2))[None, :]
+    return np.ascontiguousarray(x), np.ascontiguousarray(u)
+
+
 def make_batch_realizable(kernel, B, first=0, seed=6):
     """Config 6 (realizable filter, sampled double integrator): half the states uniform over 1.05 x the
     kernel's bounding box (some start outside -> rc -2), half within +-2 % radially of a random point of a random

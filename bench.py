@@ -29,14 +29,16 @@ from asif_amd import capi, dist, workloads  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 # algorithmic HBM bytes per instance of the state->input path: read 8(nx+nu), write 8(nu+nrelax)+4
-ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44, 6: 52}
+ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44, 6: 52, 7: 44}
 REALIZABLE_CFG = 6  # ASIFrealizable on the sampled double integrator; not a BASELINE.json config
+ROBUST_DATA_CFG = 7  # ASIFrobust on the shipped data: examples/DoubleIntegrator_Robust.cpp + KernelData_70-135kg.h
 WORKLOAD = {
     2: "C2 DoubleIntegrator explicit CBF (ASIF::filter), seeded x in U[-1.2,1.2]^2, uDes in U[-1.5,1.5]",
     3: "C3 InvertedPendulum_Implicit (ASIFimplicit::filter, 5001-step backup trajectory)",
     4: "C4 segway_implicit_tb (ASIFimplicitTB::filter, 316-step backup trajectory), one GPU's share",
     5: "C5 InvertedPendulum_Robust (ASIFrobust::filter, affine-arithmetic rows, nv=18 nc=12)",
     6: "C6 DoubleIntegrator_RealizableSampled (ASIFrealizable::filter, polytopic kernel, facet search + interval rows)",
+    7: "C7 DoubleIntegrator_Robust (ASIFrobust::filter on the shipped 100 half-planes, 5 kept per call, nv=22 nc=15)",
 }
 
 
@@ -48,15 +50,18 @@ def host_cores():
     return max(1, min(n, 16))  # the GPU box's CPU share for one GPU is 16
 
 
-def cpu_baseline_realizable(kernel_name, gpu_uact, gpu_rc, x, udes):
-    """cpu_baseline() for config 6: the oracle's ASIFrealizable restatement with its OSQP-style ADMM on the
-    full nv x nc problem (the QP the reference hands to OSQP), python threads over ctypes calls (GIL released)."""
+def cpu_baseline_handle(cfg, data_name, gpu_uact, gpu_rc, x, udes):
+    """cpu_baseline() for configs 6 and 7: the oracle's ASIFrealizable / ASIFrobust-on-data restatement with its
+    OSQP-style ADMM on the full nv x nc problem (the QP the reference hands to OSQP), python threads over ctypes
+    calls (GIL released)."""
     from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     O.build()
-    k = O.load_kernel(kernel_name)
-    z = O.Realizable(k)
+    if cfg == REALIZABLE_CFG:
+        z, what = O.Realizable(O.load_kernel(data_name)), "ASIFrealizable"
+    else:
+        z, what = O.RobustData(O.load_halfplanes(data_name)), "ASIFrobust (DoubleIntegrator_Robust data)"
     cores = host_cores()
     xa, ua = np.ascontiguousarray(x.T), np.ascontiguousarray(udes.T)
     probe = min(2000, xa.shape[0])
@@ -75,7 +80,7 @@ def cpu_baseline_realizable(kernel_name, gpu_uact, gpu_rc, x, udes):
     ok = rc == 1
     err = float(np.abs(gpu_uact[0, :m][ok] - ue[ok, 0]).max()) if ok.any() else 0.0
     return ({"value": n / dt, "unit": "QP solves/s", "cores": cores, "kind": "port",
-             "sample": f"{n} instances of the same seeded workload, ASIFrealizable restatement + OSQP-style ADMM on "
+             "sample": f"{n} instances of the same seeded workload, {what} restatement + OSQP-style ADMM on "
                        f"the full {z.nv}x{z.nc} QP (eps 1e-3, max_iter 2000, cold start, {per * 1e6:.1f} us per "
                        f"filter() on one core) over {cores} host threads"},
             {"max_abs_u_err_vs_exact": err, "rc_mismatches": int((rc != gpu_rc[:m]).sum()), "checked_instances": m})
@@ -124,6 +129,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--kernel", default="100Hz", help="config 6: RealizableKernelData_<name> polytope")
+    ap.add_argument("--halfplanes", default="70-135kg", help="config 7: KernelData_<name> half-plane set")
     ap.add_argument("--presolve", type=int, default=0,
                     help="asif_hip_solver.presolve (config 2: closed-form clip instead of the in-kernel ADMM; default 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -143,6 +149,10 @@ def main():
         default_b = 65536
         kernel = workloads.load_kernel(args.kernel)
         flt = capi.RealizableFilter(kernel, solver=solver, device=dev.index)
+    elif cfg == ROBUST_DATA_CFG:
+        default_b = 8192
+        halfplanes = workloads.load_halfplanes(args.halfplanes)
+        flt = capi.RobustDataFilter(halfplanes, solver=solver, device=dev.index)
     else:
         model, variant, default_b = capi.CONFIGS[cfg]
         flt = capi.Filter(model, variant, solver=solver, device=dev.index)
@@ -151,6 +161,8 @@ def main():
     first, count = grp.shard(B)  # this rank's own slice of the seeded instance stream
     if cfg == REALIZABLE_CFG:
         x, udes = workloads.make_batch_realizable(kernel, count, first=first)
+    elif cfg == ROBUST_DATA_CFG:
+        x, udes = workloads.make_batch_robust_data(halfplanes, count, first=first)
     else:
         x, udes = workloads.make_batch(cfg, count, first=first)
     tx = torch.from_numpy(x).to(dev)
@@ -242,8 +254,9 @@ def main():
                      "note": "FP64-VALU/latency bound by design (44-60 algorithmic bytes per instance); see DESIGN.md"},
     }
     if grp.rank == 0 and grp.world == 1 and not args.no_cpu_baseline:
-        if cfg == REALIZABLE_CFG:
-            base, parity = cpu_baseline_realizable(args.kernel, uact.cpu().numpy(), rc_host, x, udes)
+        if cfg in (REALIZABLE_CFG, ROBUST_DATA_CFG):
+            base, parity = cpu_baseline_handle(cfg, args.kernel if cfg == REALIZABLE_CFG else args.halfplanes,
+                                               uact.cpu().numpy(), rc_host, x, udes)
         else:
             base, parity = cpu_baseline(cfg, uact.cpu().numpy(), rc_host, x, udes)
         out["cpu_baseline"] = base

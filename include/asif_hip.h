@@ -57,7 +57,8 @@ enum asif_hip_model {
 	ASIF_HIP_MODEL_INVERTED_PENDULUM = 1,       /* examples/InvertedPendulum_Implicit.cpp:13-80 */
 	ASIF_HIP_MODEL_SEGWAY = 2,                  /* examples/segway_implicit_tb.cpp:13-212       */
 	ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST = 3,/* examples/InvertedPendulum_Robust.cpp:20-79   */
-	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_SAMPLED = 4 /* examples/DoubleIntegrator_RealizableSampled.cpp:16-62 (interval dynamics) */
+	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_SAMPLED = 4,/* examples/DoubleIntegrator_RealizableSampled.cpp:16-62 (interval dynamics) */
+	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_ROBUST = 5  /* examples/DoubleIntegrator_Robust.cpp:17-58 (asif_hip_create_robust_data) */
 };
 
 enum asif_hip_variant {
@@ -192,6 +193,25 @@ int asif_hip_update_realizable_options(asif_hip_ctx *ctx, const asif_hip_realiza
 /* Copies the device-built tables to HOST arrays (either may be NULL): table[nFacets][maxActive][4] =
  * {lo(Lgh), hi(Lgh), lo(Lfh), hi(Lfh)}, bbox[nFacets][nx][2].  Synchronises the device. */
 int asif_hip_realizable_tables(asif_hip_ctx *ctx, double *table, double *bbox);
+
+/* ---- robust filter on a half-plane data set (class ASIFrobust with npSSmax < npSS) --------------------------
+ * = the reference's default-built driver examples/DoubleIntegrator_Robust.cpp: safety set  1 - a_i.x >= 0  for the
+ * N rows of SafetySetData (include/KernelData_*.h), the npSSmax smallest h kept per call
+ * (src/asif_robust.cpp:296-315), dynamics with interval mass, gain and friction (:28-58 of the example). */
+typedef struct asif_hip_robust_data_options {
+	double relaxCost, relaxLb, inf;            /* ASIFrobust::Options, include/asif_robust.h:14-19 */
+	double lb[ASIF_HIP_MAX_NU], ub[ASIF_HIP_MAX_NU];
+	int32_t npSSmax;                           /* constructor argument (1..8) */
+	double mMin, mMax, Klo, Khi, Flo, Fhi;     /* interval parameters of the device model */
+} asif_hip_robust_data_options;
+
+int asif_hip_default_robust_data_options(int model, asif_hip_robust_data_options *o);
+/* = new ASIFrobust(nx, nu, N, safetySet, dynamics, npSSmax) + initialize(lb, ub, opts); halfPlanes: HOST [N][2].
+ * The handle works with asif_hip_filter_batch / _assemble_batch / _filter_batch_host / _get_dims / _destroy.
+ * relax[1][ld]; rc 1 / -1; diag[ndiag][ld] = {kept half-plane indexes (npSSmax), ADMM iterations}. */
+int asif_hip_create_robust_data(asif_hip_ctx **out, int model, const double *halfPlanes, int32_t N,
+                                const asif_hip_robust_data_options *opts, const asif_hip_solver *solver, int device);
+int asif_hip_update_robust_data_options(asif_hip_ctx *ctx, const asif_hip_robust_data_options *opts);
 
 /* B independent filter() calls.  x[nx][ldx], udes[nu][ldx] in; uact[nu][ldx], relax[nrelax][ldx], rc[B] out.
  * Where the reference leaves uAct/relax untouched (QP failed in ASIF/ASIFrobust, relax on any failure)

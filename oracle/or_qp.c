@@ -432,11 +432,12 @@ static void small_ldl_solve(int n, const double *M, const double *Dg, double *v)
 static int g_as_refine = 3; /* refinement steps of the regularised solve (device default) */
 
 /* returns 1 valid KKT point; 0 otherwise with viol[i] (-1 below l, +1 above u) and wrong[i] filled */
+static __thread double g_as_delta = 1e-6; /* 1/penalty of the working-set solve; try_polish lowers it on stalls */
 static int as_solve(const ws_t *w, const int *act, const double *r, double *x, double *nu, int *viol, int *wrong,
                     double *vmag, double ktol)
 {
 	const int n = w->n, m = w->m;
-	const double delta = 1e-6;
+	const double delta = g_as_delta;
 	double M[MAXN * MAXN], Dg[MAXN], e2[MAXM], rhs[MAXN];
 	for (int a = 0; a < n; a++)
 		for (int b = 0; b <= a; b++) {
@@ -444,7 +445,7 @@ static int as_solve(const ws_t *w, const int *act, const double *r, double *x, d
 			for (int i = 0; i < m; i++)
 				if (act[i]) sacc += w->A[i * n + a] * w->A[i * n + b];
 			/* primal regularisation only where the cost has no curvature of its own */
-			M[a * n + b] = sacc / delta + (a == b ? (w->P[a] > 0 ? w->P[a] : delta) : 0.0);
+			M[a * n + b] = sacc / delta + (a == b ? (w->P[a] > 0 ? w->P[a] : 1e-6) : 0.0);
 		}
 	for (int i = 0; i < m; i++) { nu[i] = 0; viol[i] = 0; wrong[i] = 0; vmag[i] = 0; }
 	for (int j = 0; j < n; j++) x[j] = 0;
@@ -649,6 +650,7 @@ int or_qp_admm(const or_qp *qp, const or_admm_settings *s, double *xout, or_admm
 	double xp[MAXN], zp[MAXM], xt[MAXN], zt[MAXM], dx[MAXN], dy[MAXM];
 	double rhs[MAXN + MAXM], Ax[MAXM], Px[MAXN], Aty[MAXN], tmpn[MAXN], tmpm[MAXM];
 	int status = 0, iter = 0, rho_updates = 0;
+	double polish_delta = 1e-9;
 	double pri_res = 0, dua_res = 0;
 	const int ct = s->check_termination;
 
@@ -712,9 +714,13 @@ int or_qp_admm(const or_qp *qp, const or_admm_settings *s, double *xout, or_admm
 		}
 		pri_res = scaled_norm_inf(w->Einv, tmpm, m);
 		dua_res = w->cinv * scaled_norm_inf(w->Dinv, tmpn, n);
+		/* the method of multipliers inside contracts by about delta / (delta + s^2) per step (s: smallest singular
+		 * value of the working rows): an undecided attempt is repeated at the next check with 1000x the penalty */
 		if (s->polish && (do_check || last)) {
 			double xpol[MAXN];
+			g_as_delta = polish_delta;
 			const int pr = try_polish(w, z, y, xpol, 1e-9);
+			if (pr == 0 && polish_delta > 1e-14) polish_delta *= 1e-3;
 			if (pr == 1) {
 				memcpy(x, xpol, sizeof(double) * n);
 				status = OR_OSQP_SOLVED;
