@@ -5,8 +5,10 @@
 // robust_data_point_kernel (once per handle): the state-independent pieces of the point-state interval
 //   dynamics -- the affine forms of inv(m) and K/m -- evaluated generically with affine_dev.hpp.
 // Fused filter kernel = qp_policy_kernel<2,16,G> with RobustDataPolicy::load:
-//   1. scan of the half-planes (wave-uniform scalar loads): h_i = 1 - a_i.x, the npSSmax smallest kept sorted
-//      in registers (:296-315; std::sort's order of equal keys is unspecified, lowest index first here);
+//   1. scan of the half-planes, shared by the G lanes of the QP's group (lane g takes rows g, g+G, ...):
+//      h_i = 1 - a_i.x, each lane's smallest kept sorted in registers, then the group's npSSmax smallest
+//      extracted head by head with DPP minima (:296-315; std::sort's order of equal keys is unspecified,
+//      lowest index first here);
 //   2. interval Lie derivatives of the kept rows at the point state.  As in k_robust.hip the only non-zero
 //      noise coefficients come from the interval parameters; written out with libaffa's roundings:
 //        f1 = (-F*x1)/m   centre cu*ci, coefficients {cu*am, ci*uF, cu*de, radu*ri}    (cu = -Fc*x1, uF = x1*(-Fr))
@@ -49,38 +51,74 @@ struct RbRows {
 	int idx[kRbMaxRows];
 };
 
-// steps 1 and 2 for one instance
-__device__ __forceinline__ void robust_data_rows(const RbDev &z, double x0, double x1, RbRows &R)
+template <int G>
+__device__ __forceinline__ double gmin(double v)
+{
+	if (G >= 2) v = fmin(v, dpp_xchg<1>(v));
+	if (G >= 4) v = fmin(v, dpp_xchg<2>(v));
+	if (G >= 8) v = fmin(v, dpp_xchg<4>(v));
+	if (G >= 16) v = fmin(v, dpp_xchg<8>(v));
+	return v;
+}
+template <int G>
+__device__ __forceinline__ int gmin(int v)
+{
+	if (G >= 2) v = min(v, dpp_xchg<1>(v));
+	if (G >= 4) v = min(v, dpp_xchg<2>(v));
+	if (G >= 8) v = min(v, dpp_xchg<4>(v));
+	if (G >= 16) v = min(v, dpp_xchg<8>(v));
+	return v;
+}
+
+// steps 1 and 2 for one instance, by the G lanes of its group (g = this lane's place in it)
+template <int G>
+__device__ __forceinline__ void robust_data_rows(const RbDev &z, double x0, double x1, int g, RbRows &R)
 {
 #pragma clang fp contract(off)
+	// 1a. every lane keeps the smallest of its share of the half-planes (g, g+G, ...), sorted by (h, index)
+	double lh[kRbMaxRows];
+	int li[kRbMaxRows];
 #pragma unroll
 	for (int q = 0; q < kRbMaxRows; q++) {
-		R.h[q] = __builtin_huge_val();
-		R.idx[q] = 0;
+		lh[q] = __builtin_huge_val();
+		li[q] = 0x7fffffff;
 	}
-	auto visit = [&](double a0, double a1, int i) {
+	for (int i = g; i < z.N; i += G) {
+		const double a0 = z.hp[2 * i], a1 = z.hp[2 * i + 1];
 		double hv = 1. - a0 * x0 - a1 * x1; // examples/DoubleIntegrator_Robust.cpp:45
 		int hi_ = i;
 #pragma unroll
-		for (int q = 0; q < kRbMaxRows; q++) { // sorted insert, strict <
-			const bool lt = hv < R.h[q];
-			const double tv = R.h[q];
-			const int ti = R.idx[q];
-			R.h[q] = lt ? hv : tv;
-			R.idx[q] = lt ? hi_ : ti;
+		for (int q = 0; q < kRbMaxRows; q++) { // sorted insert, strict < (indexes arrive in increasing order)
+			const bool lt = hv < lh[q];
+			const double tv = lh[q];
+			const int ti = li[q];
+			lh[q] = lt ? hv : tv;
+			li[q] = lt ? hi_ : ti;
 			hv = lt ? tv : hv;
 			hi_ = lt ? ti : hi_;
 		}
-	};
-	const int N4 = z.N & ~3;
-	for (int i = 0; i < N4; i += 4) { // wave-uniform addresses: scalar loads, four half-planes per wait
-		double a[8];
-#pragma unroll
-		for (int k = 0; k < 8; k++) a[k] = z.hp[2 * i + k];
-#pragma unroll
-		for (int u = 0; u < 4; u++) visit(a[2 * u], a[2 * u + 1], i + u);
 	}
-	for (int i = N4; i < z.N; i++) visit(z.hp[2 * i], z.hp[2 * i + 1], i);
+	// 1b. the group's npSSmax smallest, extracted head by head: smallest h over the lanes' heads, lowest index on
+	//     ties (std::sort leaves equal keys unspecified), the owner pops.  All lanes end with the same list.
+#pragma unroll
+	for (int k = 0; k < kRbMaxRows; k++) {
+		R.h[k] = __builtin_huge_val();
+		R.idx[k] = 0;
+		if (k < z.npSSmax) { // wave-uniform
+			const double hm = gmin<G>(lh[0]);
+			const int im = gmin<G>(lh[0] == hm ? li[0] : 0x7fffffff);
+			R.h[k] = hm;
+			R.idx[k] = im;
+			const bool mine = (lh[0] == hm) && (li[0] == im);
+#pragma unroll
+			for (int q = 0; q + 1 < kRbMaxRows; q++) {
+				lh[q] = mine ? lh[q + 1] : lh[q];
+				li[q] = mine ? li[q + 1] : li[q];
+			}
+			lh[kRbMaxRows - 1] = mine ? __builtin_huge_val() : lh[kRbMaxRows - 1];
+			li[kRbMaxRows - 1] = mine ? 0x7fffffff : li[kRbMaxRows - 1];
+		}
+	}
 	if (z.npSSmax == z.N) { // no selection (:316-320): rows in data order
 #pragma unroll
 		for (int q = 0; q < kRbMaxRows; q++)
@@ -131,7 +169,7 @@ __global__ __launch_bounds__(64) void robust_data_rows_kernel(RbDev z, FilterArg
 	const int64_t ld = a.ld;
 	const int M = z.npSSmax, nv = 2 + 4 * M, nc = 3 * M;
 	RbRows R;
-	robust_data_rows(z, a.x[i], a.x[ld + i], R);
+	robust_data_rows<1>(z, a.x[i], a.x[ld + i], 0, R);
 	for (int e = 0; e < nc * nv; e++) a.A[(int64_t)e * ld + i] = 0.0;
 	for (int r = 0; r < nc; r++) a.b[(int64_t)r * ld + i] = 0.0;
 #pragma unroll
@@ -167,7 +205,7 @@ struct RobustDataPolicy {
 		static_assert(NV == 2 && NC == 2 * kRbMaxRows && (G == 2 || G == 4 || G == 8), "reduced robust QP");
 		constexpr int RPL = (NC + G - 1) / G, H = G / 2;
 		RbRows R;
-		robust_data_rows(z, a.x[i], a.x[a.ld + i], R);
+		robust_data_rows<G>(z, a.x[i], a.x[a.ld + i], g, R);
 		const int M = z.npSSmax;
 		const bool hiRow = (g & 1) != 0;
 		const int sub = g >> 1;
