@@ -119,7 +119,12 @@ int32_t ASIFrobust::updateOptions(void)
 	lb_[nu_] = options_.relaxLb;
 	QPsolver_->updateBounds(lb_.data(), nullptr);
 	QPsolver_->updateCost(H_.data(), c_.data());
-	if (batch_) {
+	if (batch_ && batchIsData_) {
+		batchDataOpts_.relaxCost = options_.relaxCost;
+		batchDataOpts_.relaxLb = options_.relaxLb;
+		batchDataOpts_.inf = options_.inf;
+		asif_hip_update_robust_data_options(batch_, &batchDataOpts_);
+	} else if (batch_) {
 		batchOpts_.relaxCost = options_.relaxCost;
 		batchOpts_.relaxLb = options_.relaxLb;
 		batchOpts_.inf = options_.inf;
@@ -176,6 +181,7 @@ int32_t ASIFrobust::bindDeviceModel(int model, const asif_hip_options &modelData
 {
 	if (batch_) asif_hip_destroy(batch_);
 	batch_ = nullptr;
+	batchIsData_ = false;
 	batchOpts_ = modelData;
 	batchOpts_.relaxCost = options_.relaxCost;
 	batchOpts_.relaxLb = options_.relaxLb;
@@ -186,6 +192,33 @@ int32_t ASIFrobust::bindDeviceModel(int model, const asif_hip_options &modelData
 	}
 	int r = asif_hip_create(&batch_, model, ASIF_HIP_ROBUST, &batchOpts_, nullptr, device);
 	if (r) return r;
+	asif_hip_dims d;
+	asif_hip_get_dims(batch_, &d);
+	if ((uint32_t)d.nx != nx_ || (uint32_t)d.nu != nu_ || (uint32_t)d.nc != nc_ || (uint32_t)d.nv != nv_) {
+		asif_hip_destroy(batch_);
+		batch_ = nullptr;
+		return ASIF_HIP_EINVAL;
+	}
+	return 0;
+}
+
+int32_t ASIFrobust::bindDeviceData(int model, const double halfPlanes[], int32_t N,
+                                   const asif_hip_robust_data_options &modelData, int device)
+{
+	if (batch_) asif_hip_destroy(batch_);
+	batch_ = nullptr;
+	if ((uint32_t)N != npSS_) return ASIF_HIP_EINVAL;
+	asif_hip_robust_data_options o = modelData;
+	o.relaxCost = options_.relaxCost;
+	o.relaxLb = options_.relaxLb;
+	o.inf = options_.inf;
+	o.lb[0] = lb_[0];
+	o.ub[0] = ub_[0];
+	o.npSSmax = (int32_t)npSSmax_;
+	int r = asif_hip_create_robust_data(&batch_, model, halfPlanes, N, &o, nullptr, device);
+	if (r) return r;
+	batchIsData_ = true;
+	batchDataOpts_ = o;
 	asif_hip_dims d;
 	asif_hip_get_dims(batch_, &d);
 	if ((uint32_t)d.nx != nx_ || (uint32_t)d.nu != nu_ || (uint32_t)d.nc != nc_ || (uint32_t)d.nv != nv_) {

@@ -1,0 +1,89 @@
+// di_robust.cpp -- ASIF::ASIFrobust exactly as examples/DoubleIntegrator_Robust.cpp:17-90 sets it up (interval mass,
+// gain and friction, safety set = the half-planes of include/KernelData_*.h, npSSmax = 5), the half-planes read from
+// a text file ("N" then N lines "a0 a1"; tests write it from tests/golden/robust_halfplanes.json).
+// Single-agent filter() (host affine arithmetic, the full 22-variable QP on the GPU's wave-per-QP kernel) next to
+// filterBatch() on the same states, which are read from stdin as "x0 x1 uDes" lines.
+//   usage: di_robust halfplanes.txt < states.txt
+//   prints  i,uAct,relax,rc,uActBatch,relaxBatch,rcBatch  and  "A,<i>,<nc*nv row entries>" lines
+#include <asif++.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+static const double m_max = 135., m_min = 70., K = 5.7, dK = 0.1, F = 23, DF = 2;
+static interval_t mInt, KInt, FInt;
+static std::vector<std::vector<double>> SafetySetData;
+
+static void safetySet(const double *x, double *h, double *Dh)
+{
+	for (uint32_t i = 0; i < SafetySetData.size(); i++) {
+		h[i] = 1. - SafetySetData[i][0] * x[0] - SafetySetData[i][1] * x[1];
+		Dh[i] = -SafetySetData[i][0];
+		Dh[i + SafetySetData.size()] = -SafetySetData[i][1];
+	}
+}
+
+static void dynamics(const interval_t *x, interval_t *f, interval_t *g)
+{
+	f[0] = x[1];
+	f[1] = -FInt * x[1] / mInt;
+	g[0] = 0.;
+	g[1] = KInt / mInt;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 2) return 2;
+	FILE *fp = std::fopen(argv[1], "r");
+	if (!fp) return 2;
+	int N;
+	if (std::fscanf(fp, "%d", &N) != 1) return 2;
+	SafetySetData.assign(N, std::vector<double>(2));
+	std::vector<double> flat(2 * N);
+	for (int i = 0; i < N; i++) {
+		if (std::fscanf(fp, "%lf %lf", &SafetySetData[i][0], &SafetySetData[i][1]) != 2) return 2;
+		flat[2 * i] = SafetySetData[i][0];
+		flat[2 * i + 1] = SafetySetData[i][1];
+	}
+	std::fclose(fp);
+	// the example's globals, constructed in its order (m, K, F) before anything else creates a symbol
+	mInt = interval(m_min, m_max);
+	KInt = interval(K - dK, K + dK);
+	FInt = interval(F - DF, F - DF);
+	const double lb[1] = {-20}, ub[1] = {20};
+	ASIF::ASIFrobust::Options opts;
+	opts.relaxCost = 50.0;
+	opts.relaxLb = 5.0;
+	ASIF::ASIFrobust flt(2, 1, (uint32_t)N, safetySet, dynamics, 5);
+	if (flt.initialize(lb, ub, opts) != 1) return 3;
+	asif_hip_robust_data_options md;
+	asif_hip_default_robust_data_options(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_ROBUST, &md); // same m, K, F intervals
+	if (flt.bindDeviceData(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_ROBUST, flat.data(), N, md) != 0) return 3;
+
+	std::vector<double> xs, us;
+	double a, b, c;
+	while (std::scanf("%lf %lf %lf", &a, &b, &c) == 3) {
+		xs.push_back(a);
+		xs.push_back(b);
+		us.push_back(c);
+	}
+	const long n = (long)us.size();
+	std::vector<double> bx(2 * n), ba(n, 0.0), br(n, 0.0);
+	std::vector<int32_t> brc(n, 0);
+	for (long i = 0; i < n; i++) {
+		bx[i] = xs[2 * i];
+		bx[n + i] = xs[2 * i + 1];
+	}
+	if (flt.filterBatch(n, bx.data(), us.data(), ba.data(), br.data(), brc.data()) != 0) return 4;
+	std::printf("i,uAct,relax,rc,uActBatch,relaxBatch,rcBatch\n");
+	for (long i = 0; i < n; i++) {
+		const double x[2] = {xs[2 * i], xs[2 * i + 1]}, ud[1] = {us[i]};
+		double ua[1] = {0.0}, rl = 0.0;
+		const int32_t rc = flt.filter(x, ud, ua, rl);
+		std::printf("%ld,%.17g,%.17g,%d,%.17g,%.17g,%d\n", i, ua[0], rl, rc, ba[i], br[i], brc[i]);
+		std::printf("A,%ld", i);
+		for (uint32_t e = 0; e < flt.nc() * flt.nv(); e++) std::printf(",%.17g", flt.rowsA()[e]);
+		std::printf("\n");
+	}
+	return 0;
+}

@@ -37,6 +37,10 @@ public:
 
 	// modelData carries what only the callbacks know: half-planes, pMin/pMax (asif_hip_options fields)
 	int32_t bindDeviceModel(int asif_hip_model_id, const asif_hip_options &modelData, int device = 0);
+	// half-plane safety set as data (examples/DoubleIntegrator_Robust.cpp: SafetySetData, [N][2] flattened);
+	// modelData carries the interval parameters of the device model, the rest is taken from this object
+	int32_t bindDeviceData(int asif_hip_model_id, const double halfPlanes[], int32_t N,
+	                       const asif_hip_robust_data_options &modelData, int device = 0);
 	int32_t filterBatch(int64_t B, const double x[], const double uDes[], double uAct[], double relax[], int32_t rc[]);
 
 	const double *rowsA(void) const { return A_.data(); } // last assembled rows (nc x nv, column-major)
@@ -53,6 +57,8 @@ protected:
 	std::vector<double> H_, c_, A_, b_, lb_, ub_;
 	asif_hip_ctx *batch_;
 	asif_hip_options batchOpts_;
+	bool batchIsData_ = false;
+	asif_hip_robust_data_options batchDataOpts_;
 };
 
 } // namespace ASIF

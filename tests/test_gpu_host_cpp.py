@@ -147,3 +147,36 @@ def test_realizable_class_single_agent_and_batch(hip, oracle, tmp_path):
     assert np.abs(res[ok, 2] - rl[ok, 0]).max() <= 1e-5
     assert np.abs(res[ok, 6] - ua[ok, 0]).max() <= 1e-6      # batch
     assert np.abs(res[ok, 7] - rl[ok, 1]).max() <= 1e-6
+
+
+def test_robust_class_on_shipped_data(hip, oracle, tmp_path):
+    """ASIF::ASIFrobust as examples/DoubleIntegrator_Robust.cpp builds it (npSSmax = 5 of the 100 shipped half-planes):
+    rows bit-identical to the oracle's; single-agent filter() solves the full 22 x 15 QP on the wave-per-QP kernel
+    (plain ADMM: 1e-4 here, the problem is badly conditioned near the boundary), filterBatch() the eliminated one."""
+    exe = os.path.join(HOST, "di_robust")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HOST, "-s"])
+    hp = oracle.load_halfplanes()
+    hfile = tmp_path / "hp.txt"
+    with open(hfile, "w") as f:
+        f.write(f"{hp.shape[0]}\n")
+        for a in hp:
+            f.write(f"{float(a[0])!r} {float(a[1])!r}\n")
+    n = 64
+    x, u = oracle.make_batch_robust_data(hp, n)
+    stdin = "".join(f"{float(x[i, 0])!r} {float(x[i, 1])!r} {float(u[i, 0])!r}\n" for i in range(n))
+    out = subprocess.run([exe, str(hfile)], input=stdin, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().split("\n")[1:]
+    res = np.array([[float(v) for v in l.split(",")] for l in lines if not l.startswith("A,")])
+    rowsA = np.array([[float(v) for v in l.split(",")[2:]] for l in lines if l.startswith("A,")])
+    z = oracle.RobustData(hp)
+    A, b, code, sel = z.assemble(x)
+    assert np.array_equal(rowsA, A)
+    ua, rl, rc = z.filter(x, u)
+    assert np.array_equal(res[:, 6].astype(int), rc)                     # batch: every code
+    ok = rc == 1
+    assert np.abs(res[ok, 4] - ua[ok, 0]).max() <= 1e-6 and np.abs(res[ok, 5] - rl[ok, 0]).max() <= 1e-6
+    both = ok & (res[:, 3].astype(int) == 1)                              # single agent: where plain ADMM converged
+    assert both.sum() >= 0.8 * ok.sum()
+    assert np.abs(res[both, 1] - ua[both, 0]).max() <= 1e-4
