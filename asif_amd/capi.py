@@ -20,7 +20,10 @@ CONFIGS = {
     3: (MODEL_INVERTED_PENDULUM, IMPLICIT, 16384),
     4: (MODEL_SEGWAY, IMPLICIT_TB, 32768),
     5: (MODEL_INVERTED_PENDULUM_ROBUST, ROBUST, 8192),
+    # not a BASELINE.json config: examples/InvertedPendulum_ImplicitTB.cpp (11 551-step backup trajectory)
+    8: (6, IMPLICIT_TB, 16384),
 }
+MODEL_INVERTED_PENDULUM_TB = 6
 
 EXPORTS = [
     "asif_hip_version", "asif_hip_error_string", "asif_hip_device_count", "asif_hip_default_options",

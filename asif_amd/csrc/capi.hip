@@ -105,6 +105,17 @@ extern "C" int asif_hip_default_options(int model, int variant, asif_hip_options
 		o->relaxMinOrtho = 60.0;
 		o->backTrajMinOrtho = 0.001;
 		break;
+	case ASIF_HIP_MODEL_INVERTED_PENDULUM_TB: // examples/InvertedPendulum_ImplicitTB.cpp:19-22,106-114
+		o->lb[0] = -1.5;
+		o->ub[0] = 1.5;
+		o->backTrajHorizon = 11.0;
+		o->backTrajDt = 0.001;
+		o->relaxCost = 10.;
+		o->relaxLb = 10.0;
+		o->relaxTTS = 30.0;
+		o->relaxMinOrtho = 60.0;
+		o->backTrajMinOrtho = 0.001;
+		break;
 	case ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST: {
 		o->lb[0] = -1.5;
 		o->ub[0] = 1.5;
@@ -203,8 +214,8 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 		d.ndiag = d.npBTSS + 1;                 // critical sample indexes, ADMM iterations
 		return ASIF_HIP_OK;
 	}
-	if (model == ASIF_HIP_MODEL_SEGWAY && variant == ASIF_HIP_IMPLICIT_TB) {
-		d.nx = 4; d.nu = 1; d.npSS = 4; d.npBS = 1;
+	if ((model == ASIF_HIP_MODEL_SEGWAY || model == ASIF_HIP_MODEL_INVERTED_PENDULUM_TB) && variant == ASIF_HIP_IMPLICIT_TB) {
+		d.nx = model == ASIF_HIP_MODEL_SEGWAY ? 4 : 2; d.nu = 1; d.npSS = 4; d.npBS = 1;
 		d.npBTSS = 4;                           // examples/segway_implicit_tb.cpp:16
 		d.nv = d.nu + 1;                        // src/asif_implicit_tb.cpp:122
 		d.nc = d.npBTSS * d.npSS + 2;           // src/asif_implicit_tb.cpp:125
@@ -687,6 +698,13 @@ static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipSt
 			if (r) return r;
 		}
 		return launch_tb_segway(ctx->dev, ctx->solver, a, assemble_only, stream);
+	}
+	if (ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM_TB && ctx->variant == ASIF_HIP_IMPLICIT_TB) {
+		if (!assemble_only) {
+			int r = stage_rows(ctx, a);
+			if (r) return r;
+		}
+		return launch_tb_pendulum(ctx->dev, ctx->solver, a, assemble_only, stream);
 	}
 	if (ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST && ctx->variant == ASIF_HIP_ROBUST)
 		return launch_robust_ip(ctx->dev, ctx->solver, a, assemble_only, stream); // fused, nothing staged

@@ -254,10 +254,11 @@ struct TbPolicy {
 	}
 };
 
-int launch_tb_segway(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+template <class M>
+static int launch_tb(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                      hipStream_t stream)
 {
-	using M = Segway;
+	static_assert(M::NPBTSS * M::NPSS + 2 == 18 && M::NU == 1, "QP shape 2 x 18");
 	if (a.B <= 0) return 0;
 	hipLaunchKernelGGL((tb_rows_kernel<M>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
 	int e = (int)hipGetLastError();
@@ -270,6 +271,18 @@ int launch_tb_segway(const DevOptions &o, const asif_hip_solver &S, const Filter
 	case 4: return launch_policy<2, 18, 4>(S, p, stream);
 	default: return ASIF_HIP_EINVAL;
 	}
+}
+
+int launch_tb_segway(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                     hipStream_t stream)
+{
+	return launch_tb<Segway>(o, S, a, assemble_only, stream);
+}
+
+int launch_tb_pendulum(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                       hipStream_t stream)
+{
+	return launch_tb<InvertedPendulumTB>(o, S, a, assemble_only, stream);
 }
 
 } // namespace asif

@@ -33,6 +33,10 @@ int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const Filt
 int launch_tb_segway(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                      hipStream_t stream);
 
+// same class, model = InvertedPendulumTB (examples/InvertedPendulum_ImplicitTB.cpp)
+int launch_tb_pendulum(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                       hipStream_t stream);
+
 // robust explicit filter (class ASIFrobust), model = InvertedPendulumRobust (half-plane safety set)
 int launch_robust_ip(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                      hipStream_t stream);

@@ -154,6 +154,53 @@ struct InvertedPendulum {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Inverted pendulum of the time-to-backup-set example, examples/InvertedPendulum_ImplicitTB.cpp:14-99:
+// asymmetric box, half-space backup set x0 >= pi/2 - 0.1, backup controller tracking the velocity pi/10.
+// Dynamics and their gradients are the pendulum's (:67-74, :87-94).
+struct InvertedPendulumTB {
+	static constexpr int NX = 2, NU = 1, NPSS = 4, NPBS = 1, NPBTSS = 4;
+
+	// :28-34  -pi/2 <= theta <= pi, |omega| <= pi/2
+	__device__ static void safetySet(const DevOptions &, const double (&x)[NX], double (&h)[NPSS], double (&Dh)[NPSS * NX])
+	{
+		h[0] = -x[0] + kPi;        Dh[0] = -1.0; Dh[4] = 0.0;
+		h[1] = x[0] - (-kPi / 2.); Dh[1] = 1.0;  Dh[5] = 0.0;
+		h[2] = x[1] - (-kPi / 2.); Dh[2] = 0.0;  Dh[6] = 1.0;
+		h[3] = -x[1] + kPi / 2.;   Dh[3] = 0.0;  Dh[7] = -1.0;
+	}
+	__device__ static double safetyMin(const DevOptions &, const double (&x)[NX])
+	{
+		return fmin(fmin(-x[0] + kPi, x[0] - (-kPi / 2.)), fmin(x[1] - (-kPi / 2.), -x[1] + kPi / 2.));
+	}
+	// :36-65
+	__device__ static void backupSet(const DevOptions &, const double (&x)[NX], double &h, double (&Dh)[NX],
+	                                 double (&DDh)[NX * NX])
+	{
+		h = x[0] - kPi / 2. + 0.1;
+		Dh[0] = 1.;
+		Dh[1] = 0.;
+		DDh[0] = 0.; DDh[1] = 0.; DDh[2] = 0.; DDh[3] = 0.;
+	}
+	__device__ static double backupSetValue(const DevOptions &, const double (&x)[NX]) { return x[0] - kPi / 2. + 0.1; }
+	// :76-85  u = K (vDes - omega)
+	__device__ static void backupController(const DevOptions &, const double (&x)[NX], double (&u)[NU], double (&Du)[NU * NX])
+	{
+		u[0] = 10. * ((kPi / 10.) - x[1]);
+		Du[0] = 0.;
+		Du[1] = -10.;
+	}
+	__device__ static void dynamics(const DevOptions &o, const double (&x)[NX], double (&f)[NX], double (&g)[NX * NU])
+	{
+		InvertedPendulum::dynamics(o, x, f, g);
+	}
+	__device__ static void dynamicsAndGradients(const DevOptions &o, const double (&x)[NX], double (&f)[NX],
+	                                            double (&g)[NX * NU], double (&Df)[NX * NX], double (&Dg)[NX * NU * NX])
+	{
+		InvertedPendulum::dynamicsAndGradients(o, x, f, g, Df, Dg);
+	}
+};
+
+// ---------------------------------------------------------------------------------------------
 // Segway, examples/segway_implicit_tb.cpp:13-212 (MATLAB-generated dynamics and Jacobians).
 // x = (position, velocity, pitch, pitch rate).  The friction factor of f is multiplied by 0.0 in the
 // reference (:78) so its terms vanish identically; the Jacobian was generated WITH the tanh friction

@@ -35,6 +35,9 @@ def make_batch(cfg, B, first=0):
     elif cfg == 5:  # robust pendulum
         x = np.stack([-3.0 + 6.0 * uniform(4, i, 0), -3.0 + 6.0 * uniform(4, i, 1)])
         u = (-1.5 + 3.0 * uniform(4, i, 2))[None, :]
+    elif cfg == 8:  # pendulum TB (examples/InvertedPendulum_ImplicitTB.cpp): around and inside the backup set
+        x = np.stack([-1.4 + 3.0 * uniform(8, i, 0), -1.4 + 2.8 * uniform(8, i, 1)])
+        u = (-1.5 + 3.0 * uniform(8, i, 2))[None, :]
     else:
         raise ValueError(f"unknown config {cfg}")
     return np.ascontiguousarray(x), np.ascontiguousarray(u)

@@ -61,6 +61,17 @@ void or_default_options(int model, int variant, or_options *o)
 		o->relaxMinOrtho = 60.0;
 		o->backTrajMinOrtho = 0.001;
 		break;
+	case OR_MODEL_INVERTED_PENDULUM_TB: /* examples/InvertedPendulum_ImplicitTB.cpp:19-22,106-114 */
+		o->lb[0] = -1.5;
+		o->ub[0] = 1.5;
+		o->backTrajHorizon = 11.0;
+		o->backTrajDt = 0.001;
+		o->relaxCost = 10.;
+		o->relaxLb = 10.0;
+		o->relaxTTS = 30.0;
+		o->relaxMinOrtho = 60.0;
+		o->backTrajMinOrtho = 0.001;
+		break;
 	case OR_MODEL_INVERTED_PENDULUM_ROBUST: {
 		o->lb[0] = -1.5;
 		o->ub[0] = 1.5;

@@ -236,6 +236,11 @@ void or_make_batch(int cfg, int64_t B, int64_t first, double *x, double *uDes)
 			uDes[k] = -5.0 + 10.0 * or_rng_uniform(3, i, 4);
 			break;
 		}
+		case 8: /* pendulum TB (examples/InvertedPendulum_ImplicitTB.cpp), seed 8: around and inside the backup set */
+			x[2 * k + 0] = -1.4 + 3.0 * or_rng_uniform(8, i, 0);
+			x[2 * k + 1] = -1.4 + 2.8 * or_rng_uniform(8, i, 1);
+			uDes[k] = -1.5 + 3.0 * or_rng_uniform(8, i, 2);
+			break;
 		case 5: /* robust pendulum, seed 4 */
 			x[2 * k + 0] = -3.0 + 6.0 * or_rng_uniform(4, i, 0);
 			x[2 * k + 1] = -3.0 + 6.0 * or_rng_uniform(4, i, 1);

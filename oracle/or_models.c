@@ -303,15 +303,49 @@ static void ipr_dynamics_af(const void *ud, or_af_ctx *cx, const or_af *x, or_af
 	or_af_interval(cx, &g[1], o->pMin, o->pMax);
 }
 
-static const or_model MODELS[4] = {
+/* ----------------------------------------------------------------------------
+ * Inverted pendulum for the time-to-backup-set filter -- examples/InvertedPendulum_ImplicitTB.cpp:14-99:
+ * asymmetric box, half-space backup set x0 >= pi/2 - 0.1, velocity-tracking backup controller. */
+static void ipt_safety(const void *ud, const double *x, double *h, double *Dh)
+{
+	(void)ud;
+	const double xlo = -M_PI / 2., xhi = M_PI, vlo = -M_PI / 2., vhi = M_PI / 2.; /* :23-24 */
+	h[0] = -x[0] + xhi; Dh[0] = -1.0; Dh[4] = 0.0;
+	h[1] = x[0] - xlo;  Dh[1] = 1.0;  Dh[5] = 0.0;
+	h[2] = x[1] - vlo;  Dh[2] = 0.0;  Dh[6] = 1.0;
+	h[3] = -x[1] + vhi; Dh[3] = 0.0;  Dh[7] = -1.0;
+}
+
+static void ipt_backup(const void *ud, const double *x, double *h, double *Dh, double *DDh)
+{
+	(void)ud;
+	const double x0 = M_PI / 2.; /* :36-65 */
+	h[0] = x[0] - x0 + 0.1;
+	Dh[0] = 1.;
+	Dh[1] = 0.;
+	if (DDh)
+		for (int i = 0; i < 4; i++) DDh[i] = 0.;
+}
+
+static void ipt_ctrl(const void *ud, const double *x, double *u, double *Du)
+{
+	(void)ud;
+	const double vDes = (M_PI / 10.), K = 10.; /* :76-85 */
+	u[0] = K * (vDes - x[1]);
+	Du[0] = 0.;
+	Du[1] = -K;
+}
+
+static const or_model MODELS[5] = {
     {2, 1, 4, 0, di_safety, 0, di_dynamics, 0, 0, 0},
     {2, 1, 4, 1, ip_safety, ip_backup, ip_dynamics, ip_grad, ip_ctrl, 0},
     {4, 1, 4, 1, sg_safety, sg_backup, sg_dynamics, sg_grad, sg_ctrl, 0},
     {2, 1, 0, 0, ipr_safety, 0, 0, 0, 0, ipr_dynamics_af},
+    {2, 1, 4, 1, ipt_safety, ipt_backup, ip_dynamics, ip_grad, ipt_ctrl, 0}, /* dynamics :67-74,87-94 = the pendulum's */
 };
 
 const or_model *or_model_get(int id)
 {
-	if (id < 0 || id > 3) return 0;
+	if (id < 0 || id > 4) return 0;
 	return &MODELS[id];
 }

@@ -34,7 +34,8 @@ enum or_model_id {
 	OR_MODEL_DOUBLE_INTEGRATOR = 0,        /* examples/DoubleIntegrator.cpp:12-61          */
 	OR_MODEL_INVERTED_PENDULUM = 1,        /* examples/InvertedPendulum_Implicit.cpp:13-80 */
 	OR_MODEL_SEGWAY = 2,                   /* examples/segway_implicit_tb.cpp:13-212       */
-	OR_MODEL_INVERTED_PENDULUM_ROBUST = 3  /* examples/InvertedPendulum_Robust.cpp:20-79   */
+	OR_MODEL_INVERTED_PENDULUM_ROBUST = 3, /* examples/InvertedPendulum_Robust.cpp:20-79   */
+	OR_MODEL_INVERTED_PENDULUM_TB = 4      /* examples/InvertedPendulum_ImplicitTB.cpp:14-99 */
 };
 
 enum or_variant_id {

@@ -14,13 +14,14 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_LIB_PATH = os.path.join(ORACLE_DIR, "_ref", "libaffa_ref.so")
 
-MODEL_DI, MODEL_IP, MODEL_SEGWAY, MODEL_IP_ROBUST = 0, 1, 2, 3
+MODEL_DI, MODEL_IP, MODEL_SEGWAY, MODEL_IP_ROBUST, MODEL_IP_TB = 0, 1, 2, 3, 4
 VAR_EXPLICIT, VAR_IMPLICIT, VAR_TB, VAR_ROBUST = 0, 1, 2, 3
 SOLVER_EXACT, SOLVER_ADMM = 0, 1
 
 # config id (BASELINE.json configs[]) -> (model, variant)
 CONFIGS = {2: (MODEL_DI, VAR_EXPLICIT), 3: (MODEL_IP, VAR_IMPLICIT), 4: (MODEL_SEGWAY, VAR_TB),
-           5: (MODEL_IP_ROBUST, VAR_ROBUST)}
+           5: (MODEL_IP_ROBUST, VAR_ROBUST),
+           8: (MODEL_IP_TB, VAR_TB)}  # examples/InvertedPendulum_ImplicitTB.cpp (not a BASELINE.json config)
 
 
 class Options(C.Structure):
