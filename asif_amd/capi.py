@@ -22,8 +22,11 @@ CONFIGS = {
     5: (MODEL_INVERTED_PENDULUM_ROBUST, ROBUST, 8192),
     # not a BASELINE.json config: examples/InvertedPendulum_ImplicitTB.cpp (11 551-step backup trajectory)
     8: (6, IMPLICIT_TB, 16384),
+    # not a BASELINE.json config: examples/DoubleIntegrator_implicit.cpp (201-step trajectory, npBTSS = 4)
+    9: (7, IMPLICIT, 65536),
 }
 MODEL_INVERTED_PENDULUM_TB = 6
+MODEL_DOUBLE_INTEGRATOR_IMPLICIT = 7
 
 EXPORTS = [
     "asif_hip_version", "asif_hip_error_string", "asif_hip_device_count", "asif_hip_default_options",

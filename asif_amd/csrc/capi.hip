@@ -105,6 +105,14 @@ extern "C" int asif_hip_default_options(int model, int variant, asif_hip_options
 		o->relaxMinOrtho = 60.0;
 		o->backTrajMinOrtho = 0.001;
 		break;
+	case ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT: // examples/DoubleIntegrator_implicit.cpp:19-20,89-93
+		o->lb[0] = -1.0;
+		o->ub[0] = 1.0;
+		o->backTrajHorizon = 2.0;
+		o->backTrajDt = 0.01;
+		o->relaxReachLb = 5.0;
+		o->relaxLb = 10.0;
+		break;
 	case ASIF_HIP_MODEL_INVERTED_PENDULUM_TB: // examples/InvertedPendulum_ImplicitTB.cpp:19-22,106-114
 		o->lb[0] = -1.5;
 		o->ub[0] = 1.5;
@@ -195,9 +203,11 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 		d.ndiag = 3; // working-set solves, certificate iterations, ADMM iterations
 		return ASIF_HIP_OK;
 	}
-	if (model == ASIF_HIP_MODEL_INVERTED_PENDULUM && variant == ASIF_HIP_IMPLICIT) {
+	if ((model == ASIF_HIP_MODEL_INVERTED_PENDULUM || model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT) &&
+	    variant == ASIF_HIP_IMPLICIT) {
 		d.nx = 2; d.nu = 1; d.npSS = 4; d.npBS = 1;
-		d.npBTSS = 10;                          // examples/InvertedPendulum_Implicit.cpp:17
+		// examples/InvertedPendulum_Implicit.cpp:17, examples/DoubleIntegrator_implicit.cpp:17
+		d.npBTSS = model == ASIF_HIP_MODEL_INVERTED_PENDULUM ? 10 : 4;
 		d.nv = d.nu + 2;                        // src/asif_implicit.cpp:125
 		d.nc = d.npBTSS * d.npSS + d.npBS;      // src/asif_implicit.cpp:129
 		d.nrelax = 2;
@@ -698,6 +708,13 @@ static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipSt
 			if (r) return r;
 		}
 		return launch_tb_segway(ctx->dev, ctx->solver, a, assemble_only, stream);
+	}
+	if (ctx->model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT && ctx->variant == ASIF_HIP_IMPLICIT) {
+		if (!assemble_only) {
+			int r = stage_rows(ctx, a);
+			if (r) return r;
+		}
+		return launch_implicit_di(ctx->dev, ctx->solver, a, assemble_only, stream);
 	}
 	if (ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM_TB && ctx->variant == ASIF_HIP_IMPLICIT_TB) {
 		if (!assemble_only) {

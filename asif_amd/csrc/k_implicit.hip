@@ -184,4 +184,24 @@ int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const Filt
 	}
 }
 
+// examples/DoubleIntegrator_implicit.cpp: npBTSS = 4 -> nc = 4*4 + 1 = 17 rows
+int launch_implicit_di(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                       hipStream_t stream)
+{
+	using M = DoubleIntegratorImplicit;
+	static_assert(M::NPBTSS * M::NPSS + M::NPBS == 17, "QP shape 3 x 17");
+	if (a.B <= 0) return 0;
+	hipLaunchKernelGGL((implicit_rows_kernel<M>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
+	int e = (int)hipGetLastError();
+	if (e || assemble_only) return e;
+	const ImplicitPolicy<M> p = {a.B, o, a};
+	switch (S.lanes_per_qp) {
+	case 0:
+	case 4: return launch_policy<3, 17, 4>(S, p, stream);
+	case 2: return launch_policy<3, 17, 2>(S, p, stream);
+	case 8: return launch_policy<3, 17, 8>(S, p, stream);
+	default: return ASIF_HIP_EINVAL;
+	}
+}
+
 } // namespace asif

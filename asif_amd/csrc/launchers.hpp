@@ -28,6 +28,10 @@ int launch_explicit_di(const DevOptions &o, const asif_hip_solver &S, const Filt
 int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                        hipStream_t stream);
 
+// same class, model = DoubleIntegratorImplicit (examples/DoubleIntegrator_implicit.cpp, npBTSS = 4)
+int launch_implicit_di(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                       hipStream_t stream);
+
 // time-to-backup-set filter (class ASIFimplicitTB), model = Segway.
 // Filter mode additionally needs a.code to point at B staged int32 branch codes.
 int launch_tb_segway(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,

@@ -154,6 +154,66 @@ struct InvertedPendulum {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Double integrator with an LQR-like backup controller, examples/DoubleIntegrator_implicit.cpp:13-90:
+// plain box |x|,|v| <= 1 (not the braking parabola of examples/DoubleIntegrator.cpp), ellipsoidal backup set.
+// Sums are accumulated from 0.0 like the reference's matrixVectorMultiply (include/asif_utils.h:46-62).
+struct DoubleIntegratorImplicit {
+	static constexpr int NX = 2, NU = 1, NPSS = 4, NPBS = 1, NPBTSS = 4;
+
+	__device__ static void safetySet(const DevOptions &, const double (&x)[NX], double (&h)[NPSS], double (&Dh)[NPSS * NX])
+	{
+		h[0] = -x[0] + 1.0;    Dh[0] = -1.0; Dh[4] = 0.0;
+		h[1] = x[0] - (-1.0);  Dh[1] = 1.0;  Dh[5] = 0.0;
+		h[2] = x[1] - (-1.0);  Dh[2] = 0.0;  Dh[6] = 1.0;
+		h[3] = -x[1] + 1.0;    Dh[3] = 0.0;  Dh[7] = -1.0;
+	}
+	__device__ static double safetyMin(const DevOptions &, const double (&x)[NX])
+	{
+		return fmin(fmin(-x[0] + 1.0, x[0] - (-1.0)), fmin(x[1] - (-1.0), -x[1] + 1.0));
+	}
+	// :42-55  h = Pv - x'Px;  Dh = mPpPt x with the shipped mPpPt = {-1, -0.577.., -0.577.., +1} (last entry is
+	// not -(P+P')(1,1) = -1; reproduced as is)
+	__device__ static void backupSet(const DevOptions &, const double (&x)[NX], double &h, double (&Dh)[NX],
+	                                 double (&DDh)[NX * NX])
+	{
+		const double P00 = 0.500000000000000, P10 = 0.288675134594813, P01 = 0.288675134594813, P11 = 0.5;
+		double v = 0.002;
+		v -= P00 * x[0] * x[0];
+		v -= P01 * x[0] * x[1];
+		v -= P10 * x[1] * x[0];
+		v -= P11 * x[1] * x[1];
+		h = v;
+		Dh[0] = (0.0 + -1.0 * x[0]) + -0.577350269189626 * x[1];
+		Dh[1] = (0.0 + -0.577350269189626 * x[0]) + 1.0 * x[1];
+		DDh[0] = 0.0; DDh[1] = 0.0; DDh[2] = 0.0; DDh[3] = 0.0; // not used by ASIFimplicit
+	}
+	// :57-63, :75-80  f = A x, g = B;  Df = A, Dg = 0
+	__device__ static void dynamics(const DevOptions &, const double (&x)[NX], double (&f)[NX], double (&g)[NX * NU])
+	{
+		f[0] = (0.0 + 0.0 * x[0]) + 1.0 * x[1];
+		f[1] = (0.0 + 0.0 * x[0]) + 0.0 * x[1];
+		g[0] = 0.0;
+		g[1] = 1.0;
+	}
+	__device__ static void dynamicsAndGradients(const DevOptions &o, const double (&x)[NX], double (&f)[NX],
+	                                            double (&g)[NX * NU], double (&Df)[NX * NX], double (&Dg)[NX * NU * NX])
+	{
+		dynamics(o, x, f, g);
+		Df[0] = 0.0; Df[2] = 1.0;
+		Df[1] = 0.0; Df[3] = 0.0;
+#pragma unroll
+		for (int i = 0; i < NX * NU * NX; i++) Dg[i] = 0.0;
+	}
+	// :65-73  u = K x, K = (-10, -20)
+	__device__ static void backupController(const DevOptions &, const double (&x)[NX], double (&u)[NU], double (&Du)[NU * NX])
+	{
+		u[0] = (0.0 + -10.0 * x[0]) + -20.0 * x[1];
+		Du[0] = -10.0;
+		Du[1] = -20.0;
+	}
+};
+
+// ---------------------------------------------------------------------------------------------
 // Inverted pendulum of the time-to-backup-set example, examples/InvertedPendulum_ImplicitTB.cpp:14-99:
 // asymmetric box, half-space backup set x0 >= pi/2 - 0.1, backup controller tracking the velocity pi/10.
 // Dynamics and their gradients are the pendulum's (:67-74, :87-94).

@@ -38,6 +38,9 @@ def make_batch(cfg, B, first=0):
     elif cfg == 8:  # pendulum TB (examples/InvertedPendulum_ImplicitTB.cpp): around and inside the backup set
         x = np.stack([-1.4 + 3.0 * uniform(8, i, 0), -1.4 + 2.8 * uniform(8, i, 1)])
         u = (-1.5 + 3.0 * uniform(8, i, 2))[None, :]
+    elif cfg == 9:  # double integrator implicit (examples/DoubleIntegrator_implicit.cpp); |x| <= 0.4, see or_make_batch
+        x = np.stack([-0.4 + 0.8 * uniform(9, i, 0), -0.4 + 0.8 * uniform(9, i, 1)])
+        u = (-1.5 + 3.0 * uniform(9, i, 2))[None, :]
     else:
         raise ValueError(f"unknown config {cfg}")
     return np.ascontiguousarray(x), np.ascontiguousarray(u)

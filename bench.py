@@ -29,7 +29,7 @@ from asif_amd import capi, dist, workloads  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 # algorithmic HBM bytes per instance of the state->input path: read 8(nx+nu), write 8(nu+nrelax)+4
-ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44, 6: 52, 7: 44, 8: 44}
+ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44, 6: 52, 7: 44, 8: 44, 9: 52}
 REALIZABLE_CFG = 6  # ASIFrealizable on the sampled double integrator; not a BASELINE.json config
 ROBUST_DATA_CFG = 7  # ASIFrobust on the shipped data: examples/DoubleIntegrator_Robust.cpp + KernelData_70-135kg.h
 WORKLOAD = {
@@ -40,6 +40,7 @@ WORKLOAD = {
     6: "C6 DoubleIntegrator_RealizableSampled (ASIFrealizable::filter, polytopic kernel, facet search + interval rows)",
     7: "C7 DoubleIntegrator_Robust (ASIFrobust::filter on the shipped 100 half-planes, 5 kept per call, nv=22 nc=15)",
     8: "C8 InvertedPendulum_ImplicitTB (ASIFimplicitTB::filter, 11 551-step backup trajectory)",
+    9: "C9 DoubleIntegrator_implicit (ASIFimplicit::filter, 201-step backup trajectory, npBTSS 4, nv=3 nc=17)",
 }
 
 
@@ -97,7 +98,7 @@ def cpu_baseline(cfg, gpu_uact, gpu_rc, x, udes):
     model, variant = O.CONFIGS[cfg]
     o = O.default_options(model, variant)
     cores = host_cores()
-    probe = {2: 20000, 3: 16, 4: 256, 5: 2000, 8: 16}[cfg]
+    probe = {2: 20000, 3: 16, 4: 256, 5: 2000, 8: 16, 9: 512}[cfg]
     xs, us = O.make_batch(cfg, probe)
     t = time.perf_counter()
     O.filter_batch(model, variant, o, xs, us, O.SOLVER_ADMM, None, 1)
@@ -107,7 +108,7 @@ def cpu_baseline(cfg, gpu_uact, gpu_rc, x, udes):
     t = time.perf_counter()
     O.filter_batch(model, variant, o, xs, us, O.SOLVER_ADMM, None, cores)
     dt = time.perf_counter() - t
-    m = min(x.shape[1], {2: 65536, 3: 512, 4: 16384, 5: 8192, 8: 512}[cfg])
+    m = min(x.shape[1], {2: 65536, 3: 512, 4: 16384, 5: 8192, 8: 512, 9: 16384}[cfg])
     ua, _, rc = O.filter_batch(model, variant, o, np.ascontiguousarray(x[:, :m].T),
                                np.ascontiguousarray(udes[:, :m].T), O.SOLVER_EXACT, None, cores,
                                uact_init=np.zeros((m, 1)))

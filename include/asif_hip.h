@@ -59,7 +59,8 @@ enum asif_hip_model {
 	ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST = 3,/* examples/InvertedPendulum_Robust.cpp:20-79   */
 	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_SAMPLED = 4,/* examples/DoubleIntegrator_RealizableSampled.cpp:16-62 (interval dynamics) */
 	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_ROBUST = 5, /* examples/DoubleIntegrator_Robust.cpp:17-58 (asif_hip_create_robust_data) */
-	ASIF_HIP_MODEL_INVERTED_PENDULUM_TB = 6      /* examples/InvertedPendulum_ImplicitTB.cpp:14-99 (ASIF_HIP_IMPLICIT_TB) */
+	ASIF_HIP_MODEL_INVERTED_PENDULUM_TB = 6,     /* examples/InvertedPendulum_ImplicitTB.cpp:14-99 (ASIF_HIP_IMPLICIT_TB) */
+	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT = 7 /* examples/DoubleIntegrator_implicit.cpp:13-90 (ASIF_HIP_IMPLICIT) */
 };
 
 enum asif_hip_variant {

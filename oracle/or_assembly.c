@@ -61,6 +61,14 @@ void or_default_options(int model, int variant, or_options *o)
 		o->relaxMinOrtho = 60.0;
 		o->backTrajMinOrtho = 0.001;
 		break;
+	case OR_MODEL_DOUBLE_INTEGRATOR_IMPLICIT: /* examples/DoubleIntegrator_implicit.cpp:19-20,89-93 */
+		o->lb[0] = -1.0;
+		o->ub[0] = 1.0;
+		o->backTrajHorizon = 2.0;
+		o->backTrajDt = 0.01;
+		o->relaxReachLb = 5.0;
+		o->relaxLb = 10.0;
+		break;
 	case OR_MODEL_INVERTED_PENDULUM_TB: /* examples/InvertedPendulum_ImplicitTB.cpp:19-22,106-114 */
 		o->lb[0] = -1.5;
 		o->ub[0] = 1.5;
@@ -121,7 +129,7 @@ int or_get_dims(int model, int variant, const or_options *o, or_dims *d)
 		break;
 	case OR_VARIANT_IMPLICIT: /* src/asif_implicit.cpp:121-129 */
 		if (!m->controller) return -1;
-		d->npBTSS = 10; /* examples/InvertedPendulum_Implicit.cpp:17 */
+		d->npBTSS = m->npBTSS; /* examples/InvertedPendulum_Implicit.cpp:17, examples/DoubleIntegrator_implicit.cpp:17 */
 		d->nv = m->nu + 2;
 		d->nc = d->npBTSS * m->npSS + m->npBS;
 		d->nrelax = 2;
@@ -314,7 +322,7 @@ static void sort_by_hmin(traj_t *T, int count)
 /* src/asif_implicit.cpp:403-651 */
 static int assemble_implicit(const or_model *m, const or_options *o, const double *x, double *A, double *b)
 {
-	const int nx = m->nx, nu = m->nu, np = m->npSS, nb = m->npBS, npBTSS = 10;
+	const int nx = m->nx, nu = m->nu, np = m->npSS, nb = m->npBS, npBTSS = m->npBTSS;
 	const int nTC = npBTSS * np + nb, nv = nu + 2;
 	double f[OR_MAX_NX], g[OR_MAX_NX * OR_MAX_NU];
 	m->dynamics(o, x, f, g);

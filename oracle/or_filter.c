@@ -236,6 +236,13 @@ void or_make_batch(int cfg, int64_t B, int64_t first, double *x, double *uDes)
 			uDes[k] = -5.0 + 10.0 * or_rng_uniform(3, i, 4);
 			break;
 		}
+		case 9: /* double integrator implicit (examples/DoubleIntegrator_implicit.cpp), seed 9 */
+			/* |x| <= 0.4: beyond that the 2 s backup trajectory rarely reaches the small backup set (Pv = 0.002)
+			 * and nearly every QP is infeasible (rc -1 + backup controller); this mixes both outcomes about evenly */
+			x[2 * k + 0] = -0.4 + 0.8 * or_rng_uniform(9, i, 0);
+			x[2 * k + 1] = -0.4 + 0.8 * or_rng_uniform(9, i, 1);
+			uDes[k] = -1.5 + 3.0 * or_rng_uniform(9, i, 2);
+			break;
 		case 8: /* pendulum TB (examples/InvertedPendulum_ImplicitTB.cpp), seed 8: around and inside the backup set */
 			x[2 * k + 0] = -1.4 + 3.0 * or_rng_uniform(8, i, 0);
 			x[2 * k + 1] = -1.4 + 2.8 * or_rng_uniform(8, i, 1);

@@ -19,6 +19,7 @@ typedef struct {
 	void (*gradients)(const void *ud, const double *x, double *Df, double *Dg);
 	void (*controller)(const void *ud, const double *x, double *u, double *Du);
 	void (*dynamics_af)(const void *ud, or_af_ctx *cx, const or_af *x, or_af *f, or_af *g);
+	int npBTSS; /* critical samples kept by the implicit variant (constructor argument of the example) */
 } or_model;
 
 const or_model *or_model_get(int id);

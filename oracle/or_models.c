@@ -336,16 +336,62 @@ static void ipt_ctrl(const void *ud, const double *x, double *u, double *Du)
 	Du[1] = -K;
 }
 
-static const or_model MODELS[5] = {
-    {2, 1, 4, 0, di_safety, 0, di_dynamics, 0, 0, 0},
-    {2, 1, 4, 1, ip_safety, ip_backup, ip_dynamics, ip_grad, ip_ctrl, 0},
-    {4, 1, 4, 1, sg_safety, sg_backup, sg_dynamics, sg_grad, sg_ctrl, 0},
-    {2, 1, 0, 0, ipr_safety, 0, 0, 0, 0, ipr_dynamics_af},
-    {2, 1, 4, 1, ipt_safety, ipt_backup, ip_dynamics, ip_grad, ipt_ctrl, 0}, /* dynamics :67-74,87-94 = the pendulum's */
+/* ----------------------------------------------------------------------------
+ * Double integrator with an LQR-like backup controller -- examples/DoubleIntegrator_implicit.cpp:13-90
+ * (plain box, unlike examples/DoubleIntegrator.cpp; ellipsoidal backup set). */
+static const double dii_K[2] = {-10.0, -20};
+static const double dii_P[4] = {0.500000000000000, 0.288675134594813, 0.288675134594813, 0.5};
+/* shipped as {-1, -0.577.., -0.577.., +1}: the last entry is not -(P+P')(1,1) = -1 (:30); reproduced as is */
+static const double dii_mPpPt[4] = {-1.0, -0.577350269189626, -0.577350269189626, 1.0};
+static const double dii_Pv = 0.002;
+
+static void dii_safety(const void *ud, const double *x, double *h, double *Dh)
+{
+	(void)ud;
+	const double lo = -1.0, hi = 1.0; /* xBound = vBound = {-1, 1}, :21-22 */
+	h[0] = -x[0] + hi; Dh[0] = -1.0; Dh[4] = 0.0;
+	h[1] = x[0] - lo;  Dh[1] = 1.0;  Dh[5] = 0.0;
+	h[2] = x[1] - lo;  Dh[2] = 0.0;  Dh[6] = 1.0;
+	h[3] = -x[1] + hi; Dh[3] = 0.0;  Dh[7] = -1.0;
+}
+
+static void dii_backup(const void *ud, const double *x, double *h, double *Dh, double *DDh)
+{
+	(void)ud;
+	(void)DDh;
+	h[0] = dii_Pv; /* :42-55 */
+	for (int i = 0; i < 2; i++)
+		for (int j = 0; j < 2; j++) h[0] -= dii_P[i + j * 2] * x[i] * x[j];
+	or_matvec(dii_mPpPt, 2, 2, x, Dh);
+}
+
+static void dii_ctrl(const void *ud, const double *x, double *u, double *Du)
+{
+	(void)ud;
+	or_matvec(dii_K, 1, 2, x, u); /* :65-73 */
+	Du[0] = dii_K[0];
+	Du[1] = dii_K[1];
+}
+
+static void dii_grad(const void *ud, const double *x, double *Df, double *Dg)
+{
+	(void)ud;
+	(void)x;
+	Df[0] = 0.0; Df[1] = 0.0; Df[2] = 1.0; Df[3] = 0.0; /* A, :75-80 */
+	for (int i = 0; i < 4; i++) Dg[i] = 0.0;
+}
+
+static const or_model MODELS[6] = {
+    {2, 1, 4, 0, di_safety, 0, di_dynamics, 0, 0, 0, 0},
+    {2, 1, 4, 1, ip_safety, ip_backup, ip_dynamics, ip_grad, ip_ctrl, 0, 10}, /* examples/InvertedPendulum_Implicit.cpp:17 */
+    {4, 1, 4, 1, sg_safety, sg_backup, sg_dynamics, sg_grad, sg_ctrl, 0, 4},
+    {2, 1, 0, 0, ipr_safety, 0, 0, 0, 0, ipr_dynamics_af, 0},
+    {2, 1, 4, 1, ipt_safety, ipt_backup, ip_dynamics, ip_grad, ipt_ctrl, 0, 4}, /* dynamics :67-74,87-94 = the pendulum's */
+    {2, 1, 4, 1, dii_safety, dii_backup, di_dynamics, dii_grad, dii_ctrl, 0, 4}, /* dynamics :57-63 = A x, B; npBTSS :17 */
 };
 
 const or_model *or_model_get(int id)
 {
-	if (id < 0 || id > 4) return 0;
+	if (id < 0 || id > 5) return 0;
 	return &MODELS[id];
 }

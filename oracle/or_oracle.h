@@ -35,7 +35,8 @@ enum or_model_id {
 	OR_MODEL_INVERTED_PENDULUM = 1,        /* examples/InvertedPendulum_Implicit.cpp:13-80 */
 	OR_MODEL_SEGWAY = 2,                   /* examples/segway_implicit_tb.cpp:13-212       */
 	OR_MODEL_INVERTED_PENDULUM_ROBUST = 3, /* examples/InvertedPendulum_Robust.cpp:20-79   */
-	OR_MODEL_INVERTED_PENDULUM_TB = 4      /* examples/InvertedPendulum_ImplicitTB.cpp:14-99 */
+	OR_MODEL_INVERTED_PENDULUM_TB = 4,     /* examples/InvertedPendulum_ImplicitTB.cpp:14-99 */
+	OR_MODEL_DOUBLE_INTEGRATOR_IMPLICIT = 5 /* examples/DoubleIntegrator_implicit.cpp:13-90 */
 };
 
 enum or_variant_id {

@@ -21,7 +21,8 @@ SOLVER_EXACT, SOLVER_ADMM = 0, 1
 # config id (BASELINE.json configs[]) -> (model, variant)
 CONFIGS = {2: (MODEL_DI, VAR_EXPLICIT), 3: (MODEL_IP, VAR_IMPLICIT), 4: (MODEL_SEGWAY, VAR_TB),
            5: (MODEL_IP_ROBUST, VAR_ROBUST),
-           8: (MODEL_IP_TB, VAR_TB)}  # examples/InvertedPendulum_ImplicitTB.cpp (not a BASELINE.json config)
+           8: (MODEL_IP_TB, VAR_TB),     # examples/InvertedPendulum_ImplicitTB.cpp (not a BASELINE.json config)
+           9: (5, VAR_IMPLICIT)}         # examples/DoubleIntegrator_implicit.cpp   (not a BASELINE.json config)
 
 
 class Options(C.Structure):
