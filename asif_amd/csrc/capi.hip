@@ -154,7 +154,7 @@ extern "C" int asif_hip_default_solver(asif_hip_solver *s)
 	s->adaptive_rho_tolerance = 5.0;
 	s->max_iter = 4000;
 	s->check_interval = 2;
-	s->scaling_iters = 2; // power-of-two Ruiz: two passes equilibrate these problems as well as OSQP's ten
+	s->scaling_iters = 0; // power-of-two Ruiz passes; 0 = the path's default (1 explicit / robust pendulum, 2 elsewhere, >= 4 wave kernel)
 	s->polish = 1;
 	s->active_set_rounds = 12;
 	s->refine_steps = 2;

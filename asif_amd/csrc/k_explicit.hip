@@ -145,10 +145,12 @@ __global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_f
 }
 
 template <int G>
-static int launch_g(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+static int launch_g(const DevOptions &o, const asif_hip_solver &S0, const FilterArgs &a, bool assemble_only,
                     hipStream_t stream)
 {
 	const int block = 64;
+	// one Ruiz pass by default: the 4 x 2 rows are well scaled and a second pass only costs finish rounds
+	const asif_hip_solver S = resolve_scaling(S0, 1);
 	hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, G, false>), dim3(grid_for(a.B, G, block)), dim3(block),
 	                   0, stream, o, S, a, assemble_only);
 	return (int)hipGetLastError();

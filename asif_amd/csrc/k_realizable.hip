@@ -410,10 +410,11 @@ int launch_realizable_tables(const RzDev &z, const double *vertices, const int32
 	return (int)hipGetLastError();
 }
 
-int launch_realizable(const RzDev &z, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+int launch_realizable(const RzDev &z, const asif_hip_solver &S0, const FilterArgs &a, bool assemble_only,
                       hipStream_t stream)
 {
 	if (a.B <= 0) return 0;
+	const asif_hip_solver S = resolve_scaling(S0, 2);
 	if (z.maxCrit > kRzMaxCrit || z.npSSmax > 4) return ASIF_HIP_EUNSUPPORTED;
 	const dim3 grid(grid_for(a.B, 1, 64)), block(64);
 	if (z.npSSmax <= 2) hipLaunchKernelGGL(realizable_filter_kernel<2>, grid, block, 0, stream, z, S, a, assemble_only);

@@ -176,9 +176,10 @@ int launch_robust_ip(const DevOptions &o, const asif_hip_solver &S, const Filter
 	int G = S.lanes_per_qp;
 	if (G == 0) G = a.B >= 32768 ? 2 : (a.B >= 16384 ? 4 : 8); // enough lane groups for one wave on every SIMD
 	switch (G) {
-	case 2: return launch_policy<2, kRobustRedRows, 2>(S, p, stream);
-	case 4: return launch_policy<2, kRobustRedRows, 4>(S, p, stream);
-	case 8: return launch_policy<2, kRobustRedRows, 8>(S, p, stream);
+	// one Ruiz pass by default: these rows are well scaled and a second pass only costs finish rounds
+	case 2: return launch_policy<2, kRobustRedRows, 2>(S, p, stream, 1);
+	case 4: return launch_policy<2, kRobustRedRows, 4>(S, p, stream, 1);
+	case 8: return launch_policy<2, kRobustRedRows, 8>(S, p, stream, 1);
 	default: return ASIF_HIP_EINVAL;
 	}
 }

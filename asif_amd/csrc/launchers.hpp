@@ -89,6 +89,15 @@ struct QpArgs {
 // pre-assembled QPs; returns ASIF_HIP_EUNSUPPORTED for shapes without a compiled kernel
 int launch_qp_small(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream);
 
+// asif_hip_solver::scaling_iters: 0 = the path's default number of Ruiz passes, negative = no scaling
+inline asif_hip_solver resolve_scaling(const asif_hip_solver &S, int path_default)
+{
+	asif_hip_solver r = S;
+	if (r.scaling_iters == 0) r.scaling_iters = path_default;
+	else if (r.scaling_iters < 0) r.scaling_iters = 0;
+	return r;
+}
+
 inline int grid_for(int64_t B, int G, int block)
 {
 	const int64_t threads = B * G;

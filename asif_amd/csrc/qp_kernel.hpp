@@ -48,9 +48,10 @@ __global__ __launch_bounds__(64) void qp_policy_kernel(asif_hip_solver S, Policy
 }
 
 template <int NV, int NC, int G, class Policy>
-static int launch_policy(const asif_hip_solver &S, const Policy &pol, hipStream_t stream)
+static int launch_policy(const asif_hip_solver &S0, const Policy &pol, hipStream_t stream, int default_scaling = 2)
 {
 	const int block = 64;
+	const asif_hip_solver S = resolve_scaling(S0, default_scaling);
 	hipLaunchKernelGGL((qp_policy_kernel<NV, NC, G, Policy>), dim3(grid_for(pol.B, G, block)), dim3(block), 0, stream,
 	                   S, pol);
 	return (int)hipGetLastError();

@@ -106,7 +106,7 @@ typedef struct asif_hip_solver {
 	double adaptive_rho_tolerance;
 	int32_t max_iter;
 	int32_t check_interval; /* termination check + polish attempt + rho adaptation every this many iterations */
-	int32_t scaling_iters;
+	int32_t scaling_iters;  /* Ruiz equilibration passes; 0 = the path's default, negative = none */
 	int32_t polish;            /* 1: run the active-set finish at every check */
 	int32_t active_set_rounds; /* primal-dual working-set corrections per finish */
 	int32_t refine_steps;      /* refinement steps of each regularised working-set solve */
