@@ -14,6 +14,10 @@
  *                              replaces  ASIFrealizable::ASIFrealizable / initialize / filter
  *                                        (src/asif_realizable.cpp:5-75,100-267,284-352): facet search incl. the
  *                                        per-facet feasibility QP (:381-441), interval rows, barrier rows, solve.
+ *   asif_hip_create_robust_data + asif_hip_filter_batch
+ *                              replaces  ASIFrobust with npSSmax < npSS on a half-plane data set, the reference's
+ *                                        default-built examples/DoubleIntegrator_Robust.cpp
+ *                                        (row selection src/asif_robust.cpp:296-315).
  *   asif_hip_assemble_batch    replaces  updateConstraints alone (src/asif.cpp:233-312,
  *                                        src/asif_implicit.cpp:403-651, src/asif_implicit_tb.cpp:407-733,
  *                                        src/asif_robust.cpp:275-367): rows A, b as handed to updateA/updateb.
@@ -41,7 +45,7 @@
 extern "C" {
 #endif
 
-#define ASIF_HIP_VERSION 100
+#define ASIF_HIP_VERSION 110 /* 110: realizable / robust-data handles, solver.presolve, scaling_iters 0 = default */
 
 enum asif_hip_error {
 	ASIF_HIP_OK = 0,
