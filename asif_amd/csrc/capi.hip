@@ -153,7 +153,7 @@ extern "C" int asif_hip_default_solver(asif_hip_solver *s)
 	s->eps_dual_inf = 1e-4;
 	s->adaptive_rho_tolerance = 5.0;
 	s->max_iter = 4000;
-	s->check_interval = 2;
+	s->check_interval = 0; // 0 = the path's default (1 on the explicit path, 2 elsewhere)
 	s->scaling_iters = 0; // power-of-two Ruiz passes; 0 = the path's default (1 explicit / robust pendulum, 2 elsewhere, >= 4 wave kernel)
 	s->polish = 1;
 	s->active_set_rounds = 12;

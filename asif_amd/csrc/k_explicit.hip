@@ -150,7 +150,8 @@ static int launch_g(const DevOptions &o, const asif_hip_solver &S0, const Filter
 {
 	const int block = 64;
 	// one Ruiz pass by default: the 4 x 2 rows are well scaled and a second pass only costs finish rounds
-	const asif_hip_solver S = resolve_scaling(S0, 1);
+	// and the finish is tried after the first iteration already
+	const asif_hip_solver S = resolve_scaling(S0, 1, 1);
 	hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, G, false>), dim3(grid_for(a.B, G, block)), dim3(block),
 	                   0, stream, o, S, a, assemble_only);
 	return (int)hipGetLastError();

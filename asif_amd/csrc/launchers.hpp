@@ -89,12 +89,14 @@ struct QpArgs {
 // pre-assembled QPs; returns ASIF_HIP_EUNSUPPORTED for shapes without a compiled kernel
 int launch_qp_small(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream);
 
-// asif_hip_solver::scaling_iters: 0 = the path's default number of Ruiz passes, negative = no scaling
-inline asif_hip_solver resolve_scaling(const asif_hip_solver &S, int path_default)
+// asif_hip_solver::scaling_iters: 0 = the path's default number of Ruiz passes, negative = no scaling;
+// check_interval: 0 = the path's default
+inline asif_hip_solver resolve_scaling(const asif_hip_solver &S, int path_default, int check_default = 2)
 {
 	asif_hip_solver r = S;
 	if (r.scaling_iters == 0) r.scaling_iters = path_default;
 	else if (r.scaling_iters < 0) r.scaling_iters = 0;
+	if (r.check_interval <= 0) r.check_interval = check_default;
 	return r;
 }
 

@@ -109,7 +109,7 @@ typedef struct asif_hip_solver {
 	double eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
 	double adaptive_rho_tolerance;
 	int32_t max_iter;
-	int32_t check_interval; /* termination check + polish attempt + rho adaptation every this many iterations */
+	int32_t check_interval; /* termination check + polish attempt + rho adaptation every this many iterations; 0 = the path's default */
 	int32_t scaling_iters;  /* Ruiz equilibration passes; 0 = the path's default, negative = none */
 	int32_t polish;            /* 1: run the active-set finish at every check */
 	int32_t active_set_rounds; /* primal-dual working-set corrections per finish */
