@@ -34,7 +34,7 @@ EXPORTS = [
     "asif_hip_update_options", "asif_hip_filter_batch", "asif_hip_assemble_batch", "asif_hip_qp_solve_batch",
     "asif_hip_filter_batch_host", "asif_hip_default_realizable_options", "asif_hip_create_realizable",
     "asif_hip_update_realizable_options", "asif_hip_realizable_tables", "asif_hip_default_robust_data_options",
-    "asif_hip_create_robust_data", "asif_hip_update_robust_data_options",
+    "asif_hip_create_robust_data", "asif_hip_update_robust_data_options", "asif_hip_rollout_batch",
 ]
 
 MODEL_DOUBLE_INTEGRATOR_SAMPLED = 4
@@ -119,6 +119,7 @@ def load():
         lib.asif_hip_create_robust_data.argtypes = [C.POINTER(C.c_void_p), C.c_int, vp, C.c_int32,
                                                     C.POINTER(RobustDataOptions), C.POINTER(Solver), C.c_int]
         lib.asif_hip_update_robust_data_options.argtypes = [vp, C.POINTER(RobustDataOptions)]
+        lib.asif_hip_rollout_batch.argtypes = [vp, i64, i64, C.c_int32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         _lib = lib
     return _lib
 
@@ -189,6 +190,12 @@ class Filter:
         B = x.shape[1]
         check(self.lib.asif_hip_filter_batch(self.handle, B, x.stride(0), _ptr(x), _ptr(udes), _ptr(uact),
                                              _ptr(relax), _ptr(rc), _ptr(diag), _stream()))
+
+    def rollout(self, T, dt, x, udes, uact, relax, nfail, xlog=None, ulog=None, rclog=None):
+        """T closed-loop steps (filter + plant Euler step) in one launch; x, uact, relax are updated in place."""
+        B = x.shape[1]
+        check(self.lib.asif_hip_rollout_batch(self.handle, B, x.stride(0), T, dt, _ptr(x), _ptr(udes), _ptr(uact),
+                                              _ptr(relax), _ptr(nfail), _ptr(xlog), _ptr(ulog), _ptr(rclog), _stream()))
 
     def assemble(self, x, A, b, code, diag=None):
         B = x.shape[1]

@@ -739,6 +739,19 @@ extern "C" int asif_hip_filter_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, 
 	return run_filter(ctx, a, false, (hipStream_t)stream);
 }
 
+extern "C" int asif_hip_rollout_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, int32_t T, double dt, double *x,
+                                      const double *udes, double *uact, double *relax, int32_t *nfail, double *xlog,
+                                      double *ulog, int32_t *rclog, void *stream)
+{
+	if (!ctx || B < 0 || ldx < B || T < 0 || (B > 0 && (!x || !udes || !uact || !relax || !nfail))) return ASIF_HIP_EINVAL;
+	if (ctx->model != ASIF_HIP_MODEL_DOUBLE_INTEGRATOR || ctx->variant != ASIF_HIP_EXPLICIT) return ASIF_HIP_EUNSUPPORTED;
+	if (B == 0 || T == 0) return ASIF_HIP_OK;
+	hipError_t e = hipSetDevice(ctx->device);
+	if (e != hipSuccess) return (int)e;
+	const RolloutArgs a = {B, ldx, T, dt, x, udes, uact, relax, nfail, xlog, ulog, rclog};
+	return launch_rollout_explicit_di(ctx->dev, ctx->solver, a, (hipStream_t)stream);
+}
+
 extern "C" int asif_hip_assemble_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, const double *x, double *A,
                                        double *b, int32_t *code, double *diag, void *stream)
 {

@@ -144,6 +144,112 @@ __global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_f
 	}
 }
 
+// Closed loop, T control steps per launch (the caller's side of filter(): examples/DoubleIntegrator.cpp:81-116).
+// Per step:  rc = filter(x, uDes, uAct, relax)  exactly as above (cold start, like every batched call);  then the
+// plant's forward-Euler step  fCl = 0 + f + uAct*g,  x += dt*fCl  (:96-110) with the dynamics at the state the
+// filter saw.  When the filter fails uAct keeps its previous value -- the example never resets it (:89-94).
+// The state stays in registers for the whole rollout; HBM traffic is 8(nx+2nu+1)+4 bytes in and out per
+// instance per LAUNCH (plus the optional logs), not per step.
+template <class M>
+__global__ __launch_bounds__(64) void explicit_rollout_kernel(DevOptions o, asif_hip_solver S, RolloutArgs a)
+{
+	constexpr int NX = M::NX, NU = M::NU, NP = M::NPSS, NV = NU + 1, NC = NP;
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const bool live = i < a.B;
+	if (!live) i = a.B - 1;
+	const int64_t ld = a.ld;
+	double x[NX], uDes[NU], uAct[NU], relax;
+#pragma unroll
+	for (int k = 0; k < NX; k++) x[k] = a.x[k * ld + i];
+#pragma unroll
+	for (int k = 0; k < NU; k++) {
+		uDes[k] = a.udes[k * ld + i];
+		uAct[k] = a.uact[k * ld + i];
+	}
+	relax = a.relax[i];
+	int nfail = 0;
+#pragma unroll 1
+	for (int t = 0; t < a.T; t++) { // wave-uniform trip count
+		double h[NP], Dh[NP * NX], f[NX], gm[NX * NU];
+		M::safetySet(o, x, h, Dh);
+		M::dynamics(o, x, f, gm);
+		QpLaneData<NV, NC> qp;
+#pragma unroll
+		for (int r = 0; r < NP; r++) {
+			double s = 0.0;
+#pragma unroll
+			for (int k = 0; k < NX; k++) s += Dh[r + k * NP] * f[k];
+#pragma unroll
+			for (int j = 0; j < NU; j++) {
+				double tt = 0.0;
+#pragma unroll
+				for (int k = 0; k < NX; k++) tt += Dh[r + k * NP] * gm[k + j * NX];
+				qp.A[r][j] = tt;
+			}
+			qp.A[r][NU] = h[r];
+			qp.b[r] = -s;
+			qp.eq[r] = false;
+		}
+#pragma unroll
+		for (int j = 0; j < NU; j++) {
+			qp.Hd[j] = 1.0;
+			qp.c[j] = -2.0 * uDes[j];
+			qp.lb[j] = o.lb[j];
+			qp.ub[j] = o.ub[j];
+		}
+		qp.Hd[NU] = o.relaxCost;
+		qp.c[NU] = -2.0 * o.relaxCost * o.relaxLb;
+		qp.lb[NU] = o.relaxLb;
+		qp.ub[NU] = o.relaxLb;
+		AdmmSmall<NV, NC, 1> admm;
+		double sol[NV];
+		int status, iters;
+		admm.solve(qp, S, sol, status, iters);
+		if (live && a.xlog) {
+#pragma unroll
+			for (int k = 0; k < NX; k++) a.xlog[((int64_t)t * NX + k) * ld + i] = x[k];
+		}
+		const bool ok = status == kStatusSolved;
+		if (ok) {
+#pragma unroll
+			for (int j = 0; j < NU; j++) uAct[j] = fmin(fmax(sol[j], o.lb[j]), o.ub[j]);
+			relax = sol[NU];
+		} else nfail++;
+		if (live && a.ulog) {
+#pragma unroll
+			for (int j = 0; j < NU; j++) a.ulog[((int64_t)t * NU + j) * ld + i] = uAct[j];
+		}
+		if (live && a.rclog) a.rclog[(int64_t)t * ld + i] = ok ? ASIF_HIP_RC_OK : ASIF_HIP_RC_QP_FAILED;
+		{
+#pragma clang fp contract(off)
+#pragma unroll
+			for (int k = 0; k < NX; k++) {
+				double fcl = 0.0;
+				fcl += f[k];
+#pragma unroll
+				for (int j = 0; j < NU; j++) fcl += uAct[j] * gm[k + j * NX];
+				x[k] += a.dt * fcl;
+			}
+		}
+	}
+	if (!live) return;
+#pragma unroll
+	for (int k = 0; k < NX; k++) a.x[k * ld + i] = x[k];
+#pragma unroll
+	for (int j = 0; j < NU; j++) a.uact[j * ld + i] = uAct[j];
+	a.relax[i] = relax;
+	a.nfail[i] = nfail;
+}
+
+int launch_rollout_explicit_di(const DevOptions &o, const asif_hip_solver &S0, const RolloutArgs &a, hipStream_t stream)
+{
+	if (a.B <= 0 || a.T <= 0) return 0;
+	const asif_hip_solver S = resolve_scaling(S0, 1, 1);
+	hipLaunchKernelGGL((explicit_rollout_kernel<DoubleIntegrator>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, S,
+	                   a);
+	return (int)hipGetLastError();
+}
+
 template <int G>
 static int launch_g(const DevOptions &o, const asif_hip_solver &S0, const FilterArgs &a, bool assemble_only,
                     hipStream_t stream)

@@ -23,6 +23,22 @@ struct FilterArgs {
 int launch_explicit_di(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                        hipStream_t stream);
 
+// closed loop: T x (explicit filter + plant Euler step) per launch, model = DoubleIntegrator
+struct RolloutArgs {
+	int64_t B, ld;
+	int T;
+	double dt;
+	double *x;          // [nx][ld] in: initial state, out: state after T steps
+	const double *udes; // [nu][ld], held over the rollout
+	double *uact;       // [nu][ld] in: input applied if the first filter call fails, out: last applied input
+	double *relax;      // [1][ld] in/out
+	int32_t *nfail;     // [B] number of steps whose filter call failed
+	double *xlog;       // [T][nx][ld] state seen by each filter call, or nullptr
+	double *ulog;       // [T][nu][ld] input applied after each filter call, or nullptr
+	int32_t *rclog;     // [T][ld], or nullptr
+};
+int launch_rollout_explicit_di(const DevOptions &o, const asif_hip_solver &S, const RolloutArgs &a, hipStream_t stream);
+
 // implicit backup-trajectory filter (class ASIFimplicit), model = InvertedPendulum.
 // Filter mode needs a.A / a.b to point at staging rows of (nc*nv + nc) * ld doubles.
 int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,

@@ -226,6 +226,17 @@ int asif_hip_update_robust_data_options(asif_hip_ctx *ctx, const asif_hip_robust
 int asif_hip_filter_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, const double *x, const double *udes,
                           double *uact, double *relax, int32_t *rc, double *diag, void *stream);
 
+/* Closed loop, T control steps per launch -- the caller's side of filter(), examples/DoubleIntegrator.cpp:81-116:
+ * per step  rc = filter(x, uDes, uAct, relax)  (cold start, same arithmetic as asif_hip_filter_batch), then the
+ * plant's forward-Euler step  x += dt (f(x) + g(x) uAct)  (:96-110); a failed filter call leaves uAct at its previous
+ * value, as the example does.  x[nx][ldx] in/out, udes[nu][ldx] held over the rollout, uact[nu][ldx] in (input applied
+ * if the first call fails) / out (last applied), relax[1][ldx] in/out, nfail[B] = steps with rc != 1.  Optional logs
+ * (NULL to skip): xlog[T][nx][ldx] = state each filter call saw, ulog[T][nu][ldx] = input applied after it,
+ * rclog[T][ldx].  Explicit filter on ASIF_HIP_MODEL_DOUBLE_INTEGRATOR only (ASIF_HIP_EUNSUPPORTED otherwise). */
+int asif_hip_rollout_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, int32_t T, double dt, double *x,
+                           const double *udes, double *uact, double *relax, int32_t *nfail, double *xlog,
+                           double *ulog, int32_t *rclog, void *stream);
+
 /* Rows only: A[(nc*nv)][ldx], b[nc][ldx], code[B] (1; TB: 2 trivial rows, -3 backup set unreached). */
 int asif_hip_assemble_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, const double *x, double *A, double *b,
                             int32_t *code, double *diag, void *stream);
