@@ -194,6 +194,9 @@ struct AdmmSmall {
 	double L[NV][NV], Dinv[NV];
 	// diagnostics: working-set solves and certificate iterations this lane went through
 	int stat_rounds, stat_farkas;
+	// working set of the last problem this object solved to optimality (see finish()); survives solve() calls
+	int ws_act[RPL], ws_actb[NV];
+	bool ws_valid, ws_stored;
 
 	__device__ __forceinline__ void load_and_scale(const QpLaneData<NV, RPL> &in, int iters)
 	{
@@ -369,11 +372,21 @@ struct AdmmSmall {
 #pragma unroll
 		for (int j = 0; j < NV; j++) {
 			actb[j] = 0;
-			rtb[j] = lbs[j];
 			if (clsb[j] > 0) actb[j] = 2;
 			else if (zb[j] - lbs[j] < -yb[j]) actb[j] = -1;
-			else if (ubs[j] - zb[j] < yb[j]) { actb[j] = 1; rtb[j] = ubs[j]; }
+			else if (ubs[j] - zb[j] < yb[j]) actb[j] = 1;
 		}
+		// warm start (closed-loop rollouts): the first attempt starts from the working set the previous control
+		// step ended with -- between consecutive steps it rarely changes
+		if (ws_valid) {
+#pragma unroll
+			for (int r = 0; r < RPL; r++) act[r] = eqr[r] ? 2 : ws_act[r];
+#pragma unroll
+			for (int j = 0; j < NV; j++) actb[j] = clsb[j] > 0 ? 2 : ws_actb[j];
+		}
+		ws_valid = false;
+#pragma unroll
+		for (int j = 0; j < NV; j++) rtb[j] = actb[j] == 1 ? ubs[j] : lbs[j];
 		int verdict = 0;
 #pragma unroll 1
 		for (int round = 0; round <= rounds; round++) {
@@ -484,7 +497,15 @@ struct AdmmSmall {
 				const double mag = gsum<G>(gm[j]) + fabs(P[j] * xp[j]) + fabs(q[j]) + fabs(tb);
 				ok = ok && !(fabs(gj) > 1e-10 * mag + 1e-300);
 			}
-			if (gand<G>(ok ? 1 : 0)) { verdict = 1; break; }
+			if (gand<G>(ok ? 1 : 0)) {
+				verdict = 1;
+#pragma unroll
+				for (int r = 0; r < RPL; r++) ws_act[r] = act[r];
+#pragma unroll
+				for (int j = 0; j < NV; j++) ws_actb[j] = actb[j];
+				ws_stored = true;
+				break;
+			}
 			// -- infeasibility: least-squares point of the working rows.  Rows met with slack there
 			//    leave (removal only -> monotone), the rest must all show the sign of a violation.
 			if (gand<G>(viol_active ? 0 : 1) == 0) {
@@ -605,9 +626,13 @@ struct AdmmSmall {
 	// Cold-start solve.  `status` follows QPWrapperOsqp::solve() (src/qpwrapper_osqp.cpp:225-238):
 	// 1 when solved, the raw OSQP-style code otherwise.  xout is unscaled.  Must be called by every
 	// lane of the wave (group reductions and the wave-uniform exit test).
+	// warm = true: the first finish attempt starts from the working set the previous solve() of this object ended
+	// with (if it ended at an optimum); iterates still start from zero.
 	__device__ __forceinline__ void solve(const QpLaneData<NV, RPL> &in, const asif_hip_solver &S_, double (&xout)[NV],
-	                                      int &status, int &iters)
+	                                      int &status, int &iters, bool warm = false)
 	{
+		ws_valid = warm && ws_stored;
+		ws_stored = false;
 		load_and_scale(in, S_.scaling_iters);
 #pragma unroll
 		for (int j = 0; j < NV; j++) { x[j] = 0.0; zb[j] = 0.0; yb[j] = 0.0; dyb[j] = 0.0; dx[j] = 0.0; xout[j] = 0.0; }

@@ -161,6 +161,7 @@ extern "C" int asif_hip_default_solver(asif_hip_solver *s)
 	s->adaptive_rho = 1;
 	s->lanes_per_qp = 0;
 	s->presolve = 0;
+	s->warm_start = 1;
 	return ASIF_HIP_OK;
 }
 

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(64) void explicit_rollout_kernel(DevOptions o, asif
 	}
 	relax = a.relax[i];
 	int nfail = 0;
+	AdmmSmall<NV, NC, 1> admm; // one object for the rollout: it carries the working set from step to step
 #pragma unroll 1
 	for (int t = 0; t < a.T; t++) { // wave-uniform trip count
 		double h[NP], Dh[NP * NX], f[NX], gm[NX * NU];
@@ -201,10 +202,9 @@ __global__ __launch_bounds__(64) void explicit_rollout_kernel(DevOptions o, asif
 		qp.c[NU] = -2.0 * o.relaxCost * o.relaxLb;
 		qp.lb[NU] = o.relaxLb;
 		qp.ub[NU] = o.relaxLb;
-		AdmmSmall<NV, NC, 1> admm;
 		double sol[NV];
 		int status, iters;
-		admm.solve(qp, S, sol, status, iters);
+		admm.solve(qp, S, sol, status, iters, S.warm_start != 0 && t > 0);
 		if (live && a.xlog) {
 #pragma unroll
 			for (int k = 0; k < NX; k++) a.xlog[((int64_t)t * NX + k) * ld + i] = x[k];

@@ -121,6 +121,11 @@ typedef struct asif_hip_solver {
 	 * relaxation variable is pinned by construction (src/asif.cpp:88-91).  Same optimum, same return codes.
 	 * Default 0: every QP goes through the in-kernel ADMM the way the reference sends every QP through OSQP. */
 	int32_t presolve;
+	/* asif_hip_rollout_batch only.  1 (default): from the second control step on, the first finish attempt starts from
+	 * the working set the previous step ended with (iterates still start from zero) -- the batched analogue of the
+	 * warm start OSQP gives the reference's closed loops.  The optimum does not depend on it; 0 makes a rollout
+	 * bitwise equal to T separate asif_hip_filter_batch calls. */
+	int32_t warm_start;
 } asif_hip_solver;
 
 typedef struct asif_hip_dims {

@@ -64,7 +64,9 @@ def test_rollout_equals_single_step_launches(hip):
     from asif_amd import workloads
     B, T, dt = 4096, 25, 0.002
     x, u = workloads.make_batch(2, B, first=5000)
-    out = _rollout(hip, B, T, dt, x, u)
+    out = _rollout(hip, B, T, dt, x, u, solver=hip.default_solver(warm_start=0))  # cold working sets: bitwise
+    warm = _rollout(hip, B, T, dt, x, u)                                          # default: warm working sets
+    assert np.array_equal(warm["rclog"], out["rclog"]) and np.abs(warm["ulog"] - out["ulog"]).max() <= 1e-9
     flt = hip.Filter(hip.MODEL_DOUBLE_INTEGRATOR, hip.EXPLICIT)
     dev = torch.device("cuda:0")
     tx, tu = torch.from_numpy(x.copy()).to(dev), torch.from_numpy(u).to(dev)

@@ -7,8 +7,9 @@ from asif_amd import capi, workloads
 B = 65536
 x, u = workloads.make_batch(2, B)
 dev = torch.device("cuda:0")
-flt = capi.Filter(capi.MODEL_DOUBLE_INTEGRATOR, capi.EXPLICIT)
-for T in (1, 10, 100, 1000):
+import itertools
+for ws, T in itertools.product((0, 1), (10, 100, 1000)):
+    flt = capi.Filter(capi.MODEL_DOUBLE_INTEGRATOR, capi.EXPLICIT, solver=capi.default_solver(warm_start=ws))
     tx = torch.from_numpy(x.copy()).to(dev); tu = torch.from_numpy(u).to(dev)
     uact = torch.zeros((1, B), dtype=torch.float64, device=dev); relax = torch.zeros((1, B), dtype=torch.float64, device=dev)
     nf = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -17,4 +18,4 @@ for T in (1, 10, 100, 1000):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); flt.rollout(T, 0.001, tx, tu, uact, relax, nf); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    print(f"T {T:5d}: {ms*1e3:10.1f} us per launch, {ms*1e3/T:7.2f} us per control step, {B*T/ms/1e6:8.2f} G filter()/s, failed steps/instance {nf.float().mean().item():.1f}")
+    print(f"warm {ws} T {T:5d}: {ms*1e3:10.1f} us per launch, {ms*1e3/T:7.2f} us per control step, {B*T/ms/1e6:8.2f} G filter()/s, failed steps/instance {nf.float().mean().item():.1f}")
