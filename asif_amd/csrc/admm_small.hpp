@@ -363,7 +363,7 @@ struct AdmmSmall {
 	//   return 0  undecided -> ADMM keeps iterating and the next check tries again.
 	// act: 0 inactive, -1 at lower bound, +1 at upper bound, 2 equality (always in, multiplier free).
 	// idl: penalty (1/delta) of the working-set solve; the caller raises it after an undecided attempt.
-	__device__ __forceinline__ int finish(double (&xp)[NV], int rounds, int refine, double idl)
+	__device__ __forceinline__ int finish(double (&xp)[NV], int rounds, int refine, double idl, bool empty_start)
 	{
 		int act[RPL], actb[NV];
 		double nu[RPL], nub[NV], rtb[NV];
@@ -383,6 +383,11 @@ struct AdmmSmall {
 			for (int r = 0; r < RPL; r++) act[r] = eqr[r] ? 2 : ws_act[r];
 #pragma unroll
 			for (int j = 0; j < NV; j++) actb[j] = clsb[j] > 0 ? 2 : ws_actb[j];
+		} else if (empty_start) { // before any iteration (z, y) carry no information: start from the equalities alone
+#pragma unroll
+			for (int r = 0; r < RPL; r++) act[r] = eqr[r] ? 2 : 0;
+#pragma unroll
+			for (int j = 0; j < NV; j++) actb[j] = clsb[j] > 0 ? 2 : 0;
 		}
 		ws_valid = false;
 #pragma unroll
@@ -629,7 +634,7 @@ struct AdmmSmall {
 	// warm = true: the first finish attempt starts from the working set the previous solve() of this object ended
 	// with (if it ended at an optimum); iterates still start from zero.
 	__device__ __forceinline__ void solve(const QpLaneData<NV, RPL> &in, const asif_hip_solver &S_, double (&xout)[NV],
-	                                      int &status, int &iters, bool warm = false)
+	                                      int &status, int &iters, bool warm = false, bool finish_first = false)
 	{
 		ws_valid = warm && ws_stored;
 		ws_stored = false;
@@ -647,11 +652,17 @@ struct AdmmSmall {
 		int it = 0;
 		double penalty = 1.0 / kPolishDelta; // of the finish's working-set solves; per problem, see finish()
 		const int K = S_.check_interval > 0 ? S_.check_interval : 10;
+		// finish_first: one attempt of the active-set finish from the empty working set BEFORE the first iteration
+		// (a primal-dual active-set method on its own; for these QPs with 0-2 active rows it usually decides the
+		// problem, and the iterations only run for what it leaves undecided)
+		bool pre = finish_first && S_.polish != 0;
 		while (it < S_.max_iter) {
 			if (__all(status != 0)) break; // wave-uniform: every lane has latched its result
+			if (!pre) {
 #pragma unroll 1
-			for (int k = 0; k < K; k++) iterate(S_.sigma, S_.alpha);
-			it += K;
+				for (int k = 0; k < K; k++) iterate(S_.sigma, S_.alpha);
+				it += K;
+			}
 			const bool last = it >= S_.max_iter;
 
 			int st = 0;
@@ -660,20 +671,20 @@ struct AdmmSmall {
 			for (int j = 0; j < NV; j++) xs[j] = x[j];
 			if (S_.polish) {
 				double xp[NV];
-				const int v = finish(xp, S_.active_set_rounds, S_.refine_steps, penalty);
+				const int v = finish(xp, S_.active_set_rounds, S_.refine_steps, penalty, pre);
 				if (v == 1) {
 					st = kStatusSolved;
 #pragma unroll
 					for (int j = 0; j < NV; j++) xs[j] = xp[j];
 				} else if (v == 2) {
 					st = kStatusPrimalInf;
-				} else if (status == 0 && penalty < 1e14) {
+				} else if (status == 0 && penalty < 1e14 && !pre) {
 					penalty *= 1e3; // undecided: the next attempt, K iterations on, solves its working sets more stiffly
 				}
 			}
 			// The residual tests below are only needed by lanes the finish left undecided
 			// (wave-uniform branch: the block contains group reductions).
-			if (__any(st == 0 && status == 0)) {
+			if (!pre && __any(st == 0 && status == 0)) {
 				// ---- residual norms, unscaled (termination) and scaled (rho estimate)
 				double aty[NV], pri = 0.0, nz = 0.0, nax = 0.0, pri_s = 0.0, nz_s = 0.0, nax_s = 0.0;
 #pragma unroll
@@ -802,13 +813,14 @@ struct AdmmSmall {
 						fact_ok = set_rho_and_factor(rn, S_.sigma) && fact_ok;
 				}
 			}
-			if (!st && (last || !fact_ok)) st = kStatusMaxIter;
+			if (!st && !pre && (last || !fact_ok)) st = kStatusMaxIter;
 			if (status == 0 && st != 0) { // latch the first verdict
 				status = st;
 				iters = it;
 #pragma unroll
 				for (int j = 0; j < NV; j++) xout[j] = D[j] * xs[j];
 			}
+			pre = false;
 		}
 		if (status == 0) { // max_iter == 0
 			status = kStatusMaxIter;

@@ -125,7 +125,7 @@ __global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_f
 	AdmmSmall<NV, RPL, G> admm;
 	double sol[NV];
 	int status, iters;
-	admm.solve(qp, S, sol, status, iters);
+	admm.solve(qp, S, sol, status, iters, false, S.polish == 2);
 
 	if (live && g == 0) {
 		if (status == kStatusSolved) {
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void explicit_rollout_kernel(DevOptions o, asif
 		qp.ub[NU] = o.relaxLb;
 		double sol[NV];
 		int status, iters;
-		admm.solve(qp, S, sol, status, iters, S.warm_start != 0 && t > 0);
+		admm.solve(qp, S, sol, status, iters, S.warm_start != 0 && t > 0, S.polish == 2);
 		if (live && a.xlog) {
 #pragma unroll
 			for (int k = 0; k < NX; k++) a.xlog[((int64_t)t * NX + k) * ld + i] = x[k];

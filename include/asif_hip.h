@@ -111,7 +111,8 @@ typedef struct asif_hip_solver {
 	int32_t max_iter;
 	int32_t check_interval; /* termination check + polish attempt + rho adaptation every this many iterations; 0 = the path's default */
 	int32_t scaling_iters;  /* Ruiz equilibration passes; 0 = the path's default, negative = none */
-	int32_t polish;            /* 1: run the active-set finish at every check */
+	int32_t polish;            /* 0 off; 1: run the active-set finish at every check; 2 (default): also once, from the
+	                            * empty working set, before the first iteration */
 	int32_t active_set_rounds; /* primal-dual working-set corrections per finish */
 	int32_t refine_steps;      /* refinement steps of each regularised working-set solve */
 	int32_t adaptive_rho;

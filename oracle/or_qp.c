@@ -654,7 +654,27 @@ int or_qp_admm(const or_qp *qp, const or_admm_settings *s, double *xout, or_admm
 	double pri_res = 0, dua_res = 0;
 	const int ct = s->check_termination;
 
-	for (iter = 1; iter <= s->max_iter; iter++) {
+	/* polish == 2 (device default): one attempt of the active-set finish from the empty working set before the
+	 * first iteration; z0 = the point of [l,u] nearest to 0 with y0 = 0 marks nothing but the equalities active */
+	if (s->polish == 2) {
+		double z0[MAXM], y0[MAXM], xpol[MAXN];
+		for (int i = 0; i < m; i++) {
+			z0[i] = w->l[i] > 0 ? w->l[i] : (w->u[i] < 0 ? w->u[i] : 0.0);
+			y0[i] = 0.0;
+		}
+		g_as_delta = polish_delta;
+		const int pr = try_polish(w, z0, y0, xpol, 1e-9);
+		if (pr == 1) {
+			memcpy(x, xpol, sizeof(double) * n);
+			status = OR_OSQP_SOLVED;
+			rho_updates += 1000;
+		} else if (pr == 2) {
+			status = OR_OSQP_PRIMAL_INFEASIBLE;
+			rho_updates += 2000;
+		}
+	}
+	const int decided_before = status != 0;
+	for (iter = decided_before ? s->max_iter + 1 : 1; iter <= s->max_iter; iter++) {
 		memcpy(xp, x, sizeof(double) * n);
 		memcpy(zp, z, sizeof(double) * m);
 		/* x~, z~ */
@@ -821,6 +841,7 @@ int or_qp_admm(const or_qp *qp, const or_admm_settings *s, double *xout, or_admm
 			}
 		}
 	}
+	if (decided_before) iter = 0;
 	if (!status) {
 		status = OR_OSQP_MAX_ITER_REACHED;
 		iter = s->max_iter;

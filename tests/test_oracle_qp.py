@@ -87,6 +87,14 @@ def test_device_algorithm_emulation_is_exact(oracle):
         ok = st == 1
         assert np.abs(sol[ok] - ex[ok]).max() <= 1e-9, cfg
         assert it.max() <= 50, cfg
+        # the device's defaults: finish first (polish 2), checks every 2 iterations, 2 Ruiz passes
+        s = oracle.admm_settings(max_iter=4000, polish=2, check_termination=2, adaptive_rho_interval=2,
+                                 eps_abs=1e-8, eps_rel=1e-8, reduced_kkt=1, scaling_pow2=1, scaling=2)
+        sol, st, it = oracle.qp_solve_batch(d.nv, d.nc, Hd, c, A, b, lb, ub, be, oracle.SOLVER_ADMM, s)
+        assert np.array_equal(st == 1, stex == 1), cfg
+        ok = st == 1
+        assert np.abs(sol[ok] - ex[ok]).max() <= 1e-9, cfg
+        assert (it == 0).mean() > 0.9, cfg  # decided before the first iteration
 
 
 def test_infeasible_and_edge_qps(oracle):
