@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--kernel", default="100Hz", help="config 6: RealizableKernelData_<name> polytope")
     ap.add_argument("--halfplanes", default="70-135kg", help="config 7: KernelData_<name> half-plane set")
+    ap.add_argument("--polish", type=int, default=-1,
+                    help="asif_hip_solver.polish: 0 pure ADMM, 1 active-set finish at the checks, 2 (library default) also "
+                         "once before the first iteration")
     ap.add_argument("--presolve", type=int, default=0,
                     help="asif_hip_solver.presolve (config 2: closed-form clip instead of the in-kernel ADMM; default 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -147,6 +150,8 @@ def main():
 
     cfg = args.config
     solver = capi.default_solver(lanes_per_qp=args.lanes, presolve=args.presolve)
+    if args.polish >= 0:
+        solver.polish = args.polish
     if cfg == REALIZABLE_CFG:
         default_b = 65536
         kernel = workloads.load_kernel(args.kernel)
@@ -218,8 +223,14 @@ def main():
         hip.hipEventDestroy(e)
     step_ms = ms.value / max(args.steps, 1)
 
+    # one extra, untimed call with the diagnostics buffer: ADMM iterations used per instance (last diag row)
+    diag = torch.zeros((d.ndiag, B), dtype=torch.float64, device=dev)
+    capi.check(fn(*(call_args[:8] + (C.c_void_p(diag.data_ptr()), call_args[9]))))
+    torch.cuda.synchronize()
+    iters_host = diag[d.ndiag - 1].cpu().numpy()
     rc_host = rc.cpu().numpy()
-    solved = int(np.isin(rc_host, (1, 2, -1)).sum())  # instances whose QP was solved (or found infeasible)
+    solved_mask = np.isin(rc_host, (1, 2, -1))
+    solved = int(solved_mask.sum())  # instances whose QP was solved (or found infeasible)
     value = B * grp.world * args.steps / elapsed
     alg_bytes = ALG_BYTES[cfg] * B
     achieved = alg_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
@@ -248,6 +259,12 @@ def main():
         "config": {"workload": WORKLOAD[cfg], "batch_per_gpu": B, "sharding": "instances, no collective",
                    "lanes_per_qp": args.lanes or "default",
                    "presolve": args.presolve,
+                   # how the QPs were decided: the solver first tries a primal-dual active-set attempt from the empty
+                   # working set (polish 2), then OSQP-style ADMM iterations with the same attempt at every check
+                   "solver": {"polish": solver.polish,
+                              "admm_iterations_mean": float(iters_host[solved_mask].mean()) if solved else 0.0,
+                              "admm_iterations_max": float(iters_host[solved_mask].max()) if solved else 0.0,
+                              "decided_before_first_iteration": float((iters_host[solved_mask] == 0).mean()) if solved else 0.0},
                    "rc_histogram": {str(int(k)): int(v) for k, v in zip(*np.unique(rc_host, return_counts=True))},
                    "qp_solved_fraction": solved / B},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
