@@ -41,9 +41,35 @@ def make_batch(cfg, B, first=0):
     elif cfg == 9:  # double integrator implicit (examples/DoubleIntegrator_implicit.cpp); |x| <= 0.4, see or_make_batch
         x = np.stack([-0.4 + 0.8 * uniform(9, i, 0), -0.4 + 0.8 * uniform(9, i, 1)])
         u = (-1.5 + 3.0 * uniform(9, i, 2))[None, :]
+    elif cfg == 10:  # pendulum under ASIFimplicitRB (no reference example; C3's distribution, own seed)
+        x = np.stack([-1.5 + 3.0 * uniform(10, i, 0), -1.5 + 3.0 * uniform(10, i, 1)])
+        u = (-1.5 + 3.0 * uniform(10, i, 2))[None, :]
     else:
         raise ValueError(f"unknown config {cfg}")
     return np.ascontiguousarray(x), np.ascontiguousarray(u)
+
+
+RB_X_UNC = (0.02, 0.01)  # state uncertainty radius of config 10 (Options::x_unc, include/asif_implicit_robust.h:25)
+
+
+def make_learning(nx=2, nu=1, hidden=(16, 16), amp=0.2, bias=0.05, seed=11):
+    """Seeded weights for LearningData (include/asif_learning_utils.h:8-32): two ReLU layers and a linear
+    one for the drift residual (1 output) and for the actuation residual (nu outputs), inputs [x; Dh] (2 nx).
+    The reference ships no weights; these are synthetic, of that architecture.  Matrices are column-major
+    [rows x cols] flattened, as matrixVectorMultiply reads them."""
+    h1, h2 = hidden
+    w = dict(d_drift_in=2 * nx, d_act_in=2 * nx, d_drift_hidden=h1, d_act_hidden=h1, d_drift_hidden_2=h2,
+             d_act_hidden_2=h2, d_drift_out=1, d_act_out=nu)
+    shapes = [("w_1_drift", h1 * 2 * nx, amp), ("b_1_drift", h1, bias), ("w_2_drift", h2 * h1, amp),
+              ("b_2_drift", h2, bias), ("w_3_drift", 1 * h2, amp), ("b_3_drift", 1, bias),
+              ("w_1_act", h1 * 2 * nx, amp), ("b_1_act", h1, bias), ("w_2_act", h2 * h1, amp),
+              ("b_2_act", h2, bias), ("w_3_act", nu * h2, amp), ("b_3_act", nu, bias)]
+    k = 0
+    for name, n, a in shapes:
+        idx = np.arange(k, k + n, dtype=np.uint64)
+        w[name] = np.ascontiguousarray(a * (2.0 * uniform(seed, idx, 0) - 1.0))
+        k += n
+    return w
 
 
 def load_kernel(name="100Hz", path=None):

@@ -37,6 +37,8 @@ void or_default_options(int model, int variant, or_options *o)
 	o->satSharpness = (variant == OR_VARIANT_EXPLICIT) ? 5.0 : 0.1;
 	o->inf = 1e20;
 	o->pMin = o->pMax = 1.0;
+	o->backContDt = 0.01; /* include/asif_implicit_robust.h:31 */
+	o->n_debug = -1;      /* :26 */
 	switch (model) {
 	case OR_MODEL_DOUBLE_INTEGRATOR:
 		o->lb[0] = -1.0;
@@ -127,6 +129,9 @@ int or_get_dims(int model, int variant, const or_options *o, or_dims *d)
 		d->nc = m->npSS;
 		d->nrelax = 1;
 		break;
+	case OR_VARIANT_IMPLICIT_RB: /* src/asif_implicit_robust.cpp:206-214: same shape as ASIFimplicit */
+		if (!m->safety_af) return -1;
+		/* fall through */
 	case OR_VARIANT_IMPLICIT: /* src/asif_implicit.cpp:121-129 */
 		if (!m->controller) return -1;
 		d->npBTSS = m->npBTSS; /* examples/InvertedPendulum_Implicit.cpp:17, examples/DoubleIntegrator_implicit.cpp:17 */
@@ -216,15 +221,35 @@ static void saturate_soft(const or_model *m, const or_options *o, const double *
 	}
 }
 
-/* src/asif_implicit.cpp:751-815 (separate dynamics + dynamicsGradients branch, :789-807) */
-static void backup_cl(const or_model *m, const or_options *o, const double *x, double *fCL, double *DfCL)
+/* ASIFimplicitRB holds the backup input over backContDt along the trajectory
+ * (src/asif_implicit_robust.cpp:891-903; members t_last_zoh_, u_zoh_, Du_zoh_) */
+typedef struct {
+	double dt;     /* options_.backTrajDt as initialize() left it */
+	double t_last;
+	double u[OR_MAX_NU], Du[OR_MAX_NU * OR_MAX_NX];
+} zoh_t;
+
+/* src/asif_implicit.cpp:751-815 (separate dynamics + dynamicsGradients branch, :789-807);
+ * with zoh != NULL: src/asif_implicit_robust.cpp:878-953, same branch (:923-941) -- it saturates the held
+ * input but keeps the FRESH Du in the sensitivity (Du_zoh_ is only read by the fused-gradient branch) */
+static void backup_cl(const or_model *m, const or_options *o, const double *x, double *fCL, double *DfCL, zoh_t *zoh,
+                      double t)
 {
 	const int nx = m->nx, nu = m->nu;
 	double f[OR_MAX_NX], g[OR_MAX_NX * OR_MAX_NU], u[OR_MAX_NU], Du[OR_MAX_NU * OR_MAX_NX];
 	double uSat[OR_MAX_NU], DuSat[OR_MAX_NU];
 	double Df[OR_MAX_NX * OR_MAX_NX], Dg[OR_MAX_NX * OR_MAX_NU * OR_MAX_NX];
 	m->controller(o, x, u, Du);
-	saturate_soft(m, o, u, uSat, DuSat);
+	if (zoh) {
+		if (t <= zoh->dt) zoh->t_last = -1.;
+		if (t >= (zoh->t_last + o->backContDt - 0.0001)) {
+			for (int i = 0; i < nu; i++) zoh->u[i] = u[i];
+			for (int i = 0; i < nu * nx; i++) zoh->Du[i] = Du[i];
+			zoh->t_last = t;
+		}
+		saturate_soft(m, o, zoh->u, uSat, DuSat);
+	} else
+		saturate_soft(m, o, u, uSat, DuSat);
 	m->dynamics(o, x, f, g);
 	m->gradients(o, x, Df, Dg);
 	for (int i = 0; i < nx; i++)
@@ -239,10 +264,10 @@ static void backup_cl(const or_model *m, const or_options *o, const double *x, d
 }
 
 /* src/asif_implicit.cpp:817-827: z = [x; vec Q], zdot = [fCL; DfCL*Q] */
-static void ode_rhs(const or_model *m, const or_options *o, const double *z, double *zdot)
+static void ode_rhs(const or_model *m, const or_options *o, const double *z, double *zdot, zoh_t *zoh, double t)
 {
 	double DfCL[OR_MAX_NX * OR_MAX_NX];
-	backup_cl(m, o, z, zdot, DfCL);
+	backup_cl(m, o, z, zdot, DfCL, zoh, t);
 	or_matmul(DfCL, m->nx, m->nx, z + m->nx, m->nx, zdot + m->nx);
 }
 
@@ -280,12 +305,17 @@ static void integrate(const or_model *m, const or_options *o, int variant, int n
 	for (int i = 0; i < nx; i++) z0[i] = x[i];
 	for (int i = nx; i < nz; i += nx + 1) z0[i] = 1.0;
 	double zdot[OR_MAX_NX + OR_MAX_NX * OR_MAX_NX];
+	zoh_t zoh;
+	memset(&zoh, 0, sizeof(zoh));
+	zoh.dt = T->dt;
+	const int rb = variant == OR_VARIANT_IMPLICIT_RB;
 	for (int i = 0; i < n; i++) {
 		double *zi = T->z + (size_t)i * nz;
 		if (i > 0) {
 			const double *zp = zi - nz;
 			T->t[i] = T->t[i - 1] + T->dt;
-			ode_rhs(m, o, zp, zdot);
+			/* src/asif_implicit_robust.cpp:567: the rhs at sample i-1 is stamped t = i*backTrajDt */
+			ode_rhs(m, o, zp, zdot, rb ? &zoh : 0, (double)(unsigned)i * T->dt);
 			for (int k = 0; k < nz; k++) zi[k] = zdot[k] * T->dt;
 			for (int k = 0; k < nz; k++) zi[k] = zi[k] + zp[k];
 		}
@@ -318,17 +348,98 @@ static void sort_by_hmin(traj_t *T, int count)
 	}
 }
 
+/* ------------------------------------------------- ASIFimplicitRB extras */
+static __thread double g_rb_dh_index[OR_MAX_NX];
+static __thread double g_rb_lfh_diff, g_rb_lgh_diff[OR_MAX_NU];
+
+void or_rb_last_learning(double *Dh_index, double *Lfh_diff, double *Lgh_diff)
+{
+	if (Dh_index) memcpy(Dh_index, g_rb_dh_index, sizeof(g_rb_dh_index));
+	if (Lfh_diff) *Lfh_diff = g_rb_lfh_diff;
+	if (Lgh_diff) memcpy(Lgh_diff, g_rb_lgh_diff, sizeof(g_rb_lgh_diff));
+}
+
+/* src/asif_implicit_robust.cpp:635-647: x_int[i] = interval(x[i]-x_unc[i], x[i]+x_unc[i]);
+ * safetySet_int_(x_int, h_int, Dh_int); h = h_int.convert().left() */
+static int rb_safety_lo(const or_model *m, const or_options *o, const double *x, double *hlo)
+{
+	or_af_ctx cx = {0, 0};
+	or_af xi[OR_MAX_NX], h[OR_MAX_NPSS];
+	for (int i = 0; i < m->nx; i++) or_af_interval(&cx, &xi[i], x[i] - o->x_unc[i], x[i] + o->x_unc[i]);
+	m->safety_af(o, &cx, xi, h);
+	for (int i = 0; i < m->npSS; i++) {
+		double hi;
+		or_af_convert(&h[i], &hlo[i], &hi);
+	}
+	return cx.overflow ? -100 : 0;
+}
+
+int or_rb_safety_lo(int model, const or_options *o, const double *x, double *hlo)
+{
+	const or_model *m = or_model_get(model);
+	if (!m || !m->safety_af) return -100;
+	return rb_safety_lo(m, o, x, hlo);
+}
+
+/* include/asif_learning_utils.h:34-76 (driftNN) == :78-121 (actNN): two ReLU layers and a linear one */
+static void rb_mlp(const double *w1, const double *b1, const double *w2, const double *b2, const double *w3,
+                   const double *b3, int din, int dh1, int dh2, int dout, const double *in, double *out)
+{
+	double o1[dh1 > 0 ? dh1 : 1], o2[dh2 > 0 ? dh2 : 1], o3[dout > 0 ? dout : 1];
+	or_matvec(w1, dh1, din, in, o1);
+	for (int i = 0; i < dh1; i++) o1[i] = fmax(0., o1[i] + b1[i]);
+	or_matvec(w2, dh2, dh1, o1, o2);
+	for (int i = 0; i < dh2; i++) o2[i] = fmax(0., o2[i] + b2[i]);
+	or_matvec(w3, dout, dh2, o2, o3);
+	for (int i = 0; i < dout; i++) out[i] = o3[i] + b3[i];
+}
+
+/* include/asif_learning_utils.h:123-155 (update_weights): inputs [x; Dh[0..nx)] zero padded to d_*_in,
+ * Lfh[0] += drift[0], Lgh[i] += act[i] for i < nu -- the first nu entries of the column-major Lgh, i.e. row i
+ * of input 0 */
+static int rb_update_weights(const or_learning *L, const double *x, int nx, const double *Dh, double *Lfh, double *Lgh,
+                             int nu)
+{
+	if (!L || (int)L->d_drift_in < 2 * nx || (int)L->d_act_in < 2 * nx || L->d_drift_out < 1 || (int)L->d_act_out < nu)
+		return -100; /* the reference would run off its stack arrays */
+	double din[L->d_drift_in], ain[L->d_act_in], dout[L->d_drift_out], aout[L->d_act_out];
+	memset(din, 0, sizeof(din));
+	memset(ain, 0, sizeof(ain));
+	for (int i = 0; i < nx; i++) {
+		din[i] = x[i];
+		din[i + nx] = Dh[i];
+		ain[i] = x[i];
+		ain[i + nx] = Dh[i];
+	}
+	rb_mlp(L->w_1_drift, L->b_1_drift, L->w_2_drift, L->b_2_drift, L->w_3_drift, L->b_3_drift, L->d_drift_in,
+	       L->d_drift_hidden, L->d_drift_hidden_2, L->d_drift_out, din, dout);
+	rb_mlp(L->w_1_act, L->b_1_act, L->w_2_act, L->b_2_act, L->w_3_act, L->b_3_act, L->d_act_in, L->d_act_hidden,
+	       L->d_act_hidden_2, L->d_act_out, ain, aout);
+	g_rb_lfh_diff = dout[0];
+	Lfh[0] += dout[0];
+	for (int i = 0; i < nu; i++) {
+		Lgh[i] += aout[i];
+		g_rb_lgh_diff[i] = aout[i];
+	}
+	return 0;
+}
+
 /* ---------------------------------------------------------------- implicit */
-/* src/asif_implicit.cpp:403-651 */
-static int assemble_implicit(const or_model *m, const or_options *o, const double *x, double *A, double *b)
+/* src/asif_implicit.cpp:403-651; rb: src/asif_implicit_robust.cpp:481-778 (same rows; safe-row margins
+ * replaced by interval lower ends, optional learned residual on the first row's Lie derivatives; the
+ * interval Lie derivatives Lfh_int / Lgh_int of :698-709 are computed and never used there) */
+static int assemble_implicit(const or_model *m, const or_options *o, const double *x, double *A, double *b, int rb)
 {
 	const int nx = m->nx, nu = m->nu, np = m->npSS, nb = m->npBS, npBTSS = m->npBTSS;
 	const int nTC = npBTSS * np + nb, nv = nu + 2;
 	double f[OR_MAX_NX], g[OR_MAX_NX * OR_MAX_NU];
 	m->dynamics(o, x, f, g);
 	traj_t T;
-	integrate(m, o, OR_VARIANT_IMPLICIT, npBTSS, x, &T);
+	integrate(m, o, rb ? OR_VARIANT_IMPLICIT_RB : OR_VARIANT_IMPLICIT, npBTSS, x, &T);
 	sort_by_hmin(&T, T.npBT);
+	/* initialize() :298-303: n_debug outside (-1, npBT-1) is reset to -1 */
+	const int n_debug = (rb && o->n_debug > -1 && o->n_debug < T.npBT - 1) ? o->n_debug : -1;
+	int rc = 1;
 
 	double h[64] = {0.0}, Dh[64 * OR_MAX_NX] = {0.0};
 	double DhSSDx[OR_MAX_NPSS * OR_MAX_NX], DhBS[OR_MAX_NX], DhBSDx[OR_MAX_NX];
@@ -342,6 +453,18 @@ static int assemble_implicit(const or_model *m, const or_options *o, const doubl
 		or_matmul(DhSS, np, nx, Q, nx, DhSSDx);
 		for (int i = 0; i < np; i++)
 			for (int j = 0; j < nx; j++) Dh[(idx * np + i) + j * nTC] = DhSSDx[i + j * np];
+		if (rb) {
+			/* :624-632: Dh_index_ = the np x nx product of the most critical sample, column-major */
+			if (idx == 0 && n_debug == -1)
+				for (int i = 0; i < nx; i++) g_rb_dh_index[i] = DhSSDx[i];
+			/* :635-647 */
+			if (rb_safety_lo(m, o, T.z + (size_t)cur * T.nz, &h[idx * np])) rc = -100;
+		}
+	}
+	if (rb && n_debug != -1) { /* :590-605 */
+		double DhDbg[OR_MAX_NPSS * OR_MAX_NX];
+		or_matmul(&T.DhFull[(size_t)n_debug * np * nx], np, nx, T.z + (size_t)n_debug * T.nz + nx, nx, DhDbg);
+		for (int i = 0; i < nx; i++) g_rb_dh_index[i] = DhDbg[i];
 	}
 	const double *zend = T.z + (size_t)(T.npBT - 1) * T.nz;
 	m->backup(o, zend, &h[npBTSS * np], DhBS, 0);
@@ -352,6 +475,9 @@ static int assemble_implicit(const or_model *m, const or_options *o, const doubl
 	double Lfh[64], Lgh[64 * OR_MAX_NU];
 	or_matvec(Dh, nTC, nx, f, Lfh);
 	or_matmul(Dh, nTC, nx, g, nu, Lgh);
+	if (rb && o->use_learning) { /* :713-715 */
+		if (rb_update_weights(o->learning, x, nx, g_rb_dh_index, Lfh, Lgh, nu)) rc = -100;
+	}
 	/* :591-611 */
 	for (int i = 0; i < nTC * nv; i++) A[i] = 0.0;
 	for (int i = 0; i < nTC; i++)
@@ -360,7 +486,7 @@ static int assemble_implicit(const or_model *m, const or_options *o, const doubl
 	for (int i = npBTSS * np; i < nTC; i++) A[i + (nu + 1) * nTC] = h[i];
 	for (int i = 0; i < nTC; i++) b[i] = -Lfh[i];
 	traj_free(&T);
-	return 1;
+	return rc;
 }
 
 /* ---------------------------------------------------------------------- TB */
@@ -399,7 +525,7 @@ static int assemble_tb(const or_model *m, const or_options *o, const double *x, 
 				idxHit = i;
 				BSHit = 1;
 				btX = T.z + (size_t)i * T.nz;
-				backup_cl(m, o, btX, fClBS, DfClBS);
+				backup_cl(m, o, btX, fClBS, DfClBS, 0, 0.0);
 				or_matmul(DhBS, 1, nx, fClBS, 1, cosTilde);
 				den1 = or_vecnorm(DhBS, nx);
 				den2 = or_vecnorm(fClBS, nx);
@@ -566,7 +692,9 @@ int or_assemble(int model, int variant, const or_options *o, const double *x, do
 	case OR_VARIANT_EXPLICIT:
 		return assemble_explicit(m, o, x, A, b);
 	case OR_VARIANT_IMPLICIT:
-		return assemble_implicit(m, o, x, A, b);
+		return assemble_implicit(m, o, x, A, b, 0);
+	case OR_VARIANT_IMPLICIT_RB:
+		return assemble_implicit(m, o, x, A, b, 1);
 	case OR_VARIANT_IMPLICIT_TB: {
 		/* src/asif_implicit_tb.cpp:278-290: inside the backup set -> trivial rows, filter() returns 2 */
 		double hb[1], Dhb[OR_MAX_NX], DDhb[OR_MAX_NX * OR_MAX_NX];
@@ -609,6 +737,7 @@ void or_qp_static(int model, int variant, const or_options *o, const double *uDe
 		ub[nu] = o->relaxLb; /* src/asif.cpp:91: the relax variable is pinned */
 		break;
 	case OR_VARIANT_IMPLICIT:
+	case OR_VARIANT_IMPLICIT_RB: /* src/asif_implicit_robust.cpp:305-334,780-791: identical */
 		Hd[nu] = Hd[nu + 1] = o->relaxCost;
 		c[nu] = -2.0 * o->relaxCost * o->relaxLb;
 		c[nu + 1] = -2.0 * o->relaxCost * o->relaxReachLb;

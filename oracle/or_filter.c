@@ -104,6 +104,7 @@ int or_filter(int model, int variant, const or_options *o, int solver, const or_
 	case OR_VARIANT_EXPLICIT: /* src/asif.cpp:208-209: uAct, relax untouched */
 	case OR_VARIANT_ROBUST:   /* src/asif_robust.cpp:250-251 */
 		return -1;
+	case OR_VARIANT_IMPLICIT_RB: /* src/asif_implicit_robust.cpp:427-433: identical */
 	case OR_VARIANT_IMPLICIT: { /* src/asif_implicit.cpp:348-355 */
 		double Du[OR_MAX_NU * OR_MAX_NX];
 		m->controller(o, x, uAct, Du);
@@ -247,6 +248,11 @@ void or_make_batch(int cfg, int64_t B, int64_t first, double *x, double *uDes)
 			x[2 * k + 0] = -1.4 + 3.0 * or_rng_uniform(8, i, 0);
 			x[2 * k + 1] = -1.4 + 2.8 * or_rng_uniform(8, i, 1);
 			uDes[k] = -1.5 + 3.0 * or_rng_uniform(8, i, 2);
+			break;
+		case 10: /* pendulum under ASIFimplicitRB (no example in the reference; C3's distribution), seed 10 */
+			x[2 * k + 0] = -1.5 + 3.0 * or_rng_uniform(10, i, 0);
+			x[2 * k + 1] = -1.5 + 3.0 * or_rng_uniform(10, i, 1);
+			uDes[k] = -1.5 + 3.0 * or_rng_uniform(10, i, 2);
 			break;
 		case 5: /* robust pendulum, seed 4 */
 			x[2 * k + 0] = -3.0 + 6.0 * or_rng_uniform(4, i, 0);

@@ -19,6 +19,9 @@ typedef struct {
 	void (*gradients)(const void *ud, const double *x, double *Df, double *Dg);
 	void (*controller)(const void *ud, const double *x, double *u, double *Du);
 	void (*dynamics_af)(const void *ud, or_af_ctx *cx, const or_af *x, or_af *f, or_af *g);
+	/* the safety set on affine forms (ASIFimplicitRB's safetySet_int, include/asif_implicit_robust.h:47-49);
+	 * only h is consumed by the reference (src/asif_implicit_robust.cpp:645-647), Dh_int feeds dead code */
+	void (*safety_af)(const void *ud, or_af_ctx *cx, const or_af *x, or_af *h);
 	int npBTSS; /* critical samples kept by the implicit variant (constructor argument of the example) */
 } or_model;
 

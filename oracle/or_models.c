@@ -103,6 +103,28 @@ static void ip_safety(const void *ud, const double *x, double *h, double *Dh)
 	h[3] = -x[1] + hi; Dh[3] = 0.0;  Dh[7] = -1.0;
 }
 
+/* the box safety set above with interval_t operands: -x + hi is unary minus then "+ double",
+ * x - lo is "- double" (lib/libaffa/src/aa_aafarithm.cpp: constants move the central value only) */
+static void box_safety_af(const or_af *x, double lo, double hi, or_af *h)
+{
+	or_af cl, ch, t;
+	or_af_const(&cl, lo);
+	or_af_const(&ch, hi);
+	or_af_neg(&x[0], &t);
+	or_af_add(&t, &ch, &h[0]);
+	or_af_sub(&x[0], &cl, &h[1]);
+	or_af_sub(&x[1], &cl, &h[2]);
+	or_af_neg(&x[1], &t);
+	or_af_add(&t, &ch, &h[3]);
+}
+
+static void ip_safety_af(const void *ud, or_af_ctx *cx, const or_af *x, or_af *h)
+{
+	(void)ud;
+	(void)cx;
+	box_safety_af(x, -M_PI, M_PI, h);
+}
+
 static void ip_backup(const void *ud, const double *x, double *h, double *Dh, double *DDh)
 {
 	(void)ud;
@@ -355,6 +377,13 @@ static void dii_safety(const void *ud, const double *x, double *h, double *Dh)
 	h[3] = -x[1] + hi; Dh[3] = 0.0;  Dh[7] = -1.0;
 }
 
+static void dii_safety_af(const void *ud, or_af_ctx *cx, const or_af *x, or_af *h)
+{
+	(void)ud;
+	(void)cx;
+	box_safety_af(x, -1.0, 1.0, h);
+}
+
 static void dii_backup(const void *ud, const double *x, double *h, double *Dh, double *DDh)
 {
 	(void)ud;
@@ -382,12 +411,12 @@ static void dii_grad(const void *ud, const double *x, double *Df, double *Dg)
 }
 
 static const or_model MODELS[6] = {
-    {2, 1, 4, 0, di_safety, 0, di_dynamics, 0, 0, 0, 0},
-    {2, 1, 4, 1, ip_safety, ip_backup, ip_dynamics, ip_grad, ip_ctrl, 0, 10}, /* examples/InvertedPendulum_Implicit.cpp:17 */
-    {4, 1, 4, 1, sg_safety, sg_backup, sg_dynamics, sg_grad, sg_ctrl, 0, 4},
-    {2, 1, 0, 0, ipr_safety, 0, 0, 0, 0, ipr_dynamics_af, 0},
-    {2, 1, 4, 1, ipt_safety, ipt_backup, ip_dynamics, ip_grad, ipt_ctrl, 0, 4}, /* dynamics :67-74,87-94 = the pendulum's */
-    {2, 1, 4, 1, dii_safety, dii_backup, di_dynamics, dii_grad, dii_ctrl, 0, 4}, /* dynamics :57-63 = A x, B; npBTSS :17 */
+    {2, 1, 4, 0, di_safety, 0, di_dynamics, 0, 0, 0, 0, 0},
+    {2, 1, 4, 1, ip_safety, ip_backup, ip_dynamics, ip_grad, ip_ctrl, 0, ip_safety_af, 10}, /* examples/InvertedPendulum_Implicit.cpp:17 */
+    {4, 1, 4, 1, sg_safety, sg_backup, sg_dynamics, sg_grad, sg_ctrl, 0, 0, 4},
+    {2, 1, 0, 0, ipr_safety, 0, 0, 0, 0, ipr_dynamics_af, 0, 0},
+    {2, 1, 4, 1, ipt_safety, ipt_backup, ip_dynamics, ip_grad, ipt_ctrl, 0, 0, 4}, /* dynamics :67-74,87-94 = the pendulum's */
+    {2, 1, 4, 1, dii_safety, dii_backup, di_dynamics, dii_grad, dii_ctrl, 0, dii_safety_af, 4}, /* dynamics :57-63 = A x, B; npBTSS :17 */
 };
 
 const or_model *or_model_get(int id)

@@ -43,12 +43,23 @@ enum or_variant_id {
 	OR_VARIANT_EXPLICIT = 0,     /* src/asif.cpp             */
 	OR_VARIANT_IMPLICIT = 1,     /* src/asif_implicit.cpp    */
 	OR_VARIANT_IMPLICIT_TB = 2,  /* src/asif_implicit_tb.cpp */
-	OR_VARIANT_ROBUST = 3        /* src/asif_robust.cpp      */
+	OR_VARIANT_ROBUST = 3,       /* src/asif_robust.cpp      */
+	OR_VARIANT_IMPLICIT_RB = 5   /* src/asif_implicit_robust.cpp (4 = realizable, which has its own entry points) */
 };
 
 #define OR_MAX_NX 4
 #define OR_MAX_NU 1
 #define OR_MAX_NPSS 8
+
+/* LearningData, include/asif_learning_utils.h:8-32 (the two output-side pointers Lfh_diff / Lgh_diff are
+ * diagnostics the reference allocates per call, :146-147; not carried).  Weight matrices are dense
+ * column-major [rows x cols] as matrixVectorMultiply reads them (include/asif_utils.h:46-62). */
+typedef struct {
+	uint32_t d_drift_in, d_act_in, d_drift_hidden, d_act_hidden, d_drift_hidden_2, d_act_hidden_2, d_drift_out,
+	    d_act_out;
+	const double *w_1_drift, *w_2_drift, *w_3_drift, *b_1_drift, *b_2_drift, *b_3_drift;
+	const double *w_1_act, *w_2_act, *w_3_act, *b_1_act, *b_2_act, *b_3_act;
+} or_learning;
 
 /* Union of the four Options structs (include/asif.h:11-17, asif_implicit.h:20-34,
  * asif_implicit_tb.h:19-33, asif_robust.h:14-19) plus input bounds. */
@@ -71,6 +82,12 @@ typedef struct {
 	double pMin, pMax;
 	int32_t nHalfPlanes;
 	double halfPlanes[2 * OR_MAX_NPSS]; /* {a0,a1} pairs of 1 - a.x >= 0 */
+	/* ASIFimplicitRB only (include/asif_implicit_robust.h:21-38) */
+	double backContDt;          /* zero-order hold of the backup controller along the trajectory */
+	double x_unc[OR_MAX_NX];    /* state uncertainty radius (Options::x_unc, nullptr -> zeros) */
+	int32_t n_debug;            /* -1: Dh_index_ taken at the most critical sample */
+	int32_t use_learning;
+	const or_learning *learning;/* ASIFimplicitRB::learning_data_ (public member the caller fills) */
 } or_options;
 
 /* Defaults per variant+model exactly as the named example's main() sets them. */
@@ -166,6 +183,13 @@ void or_qp_static(int model, int variant, const or_options *o, const double *uDe
 
 /* critical sample indexes picked by the last or_assemble on this thread (implicit/TB) */
 int or_last_crit_idx(int *idx, int cap);
+
+/* ASIFimplicitRB: lower end of the interval safety set over x +- x_unc, h_int[i].convert().left()
+ * (src/asif_implicit_robust.cpp:635-647); the interval safety set is the model's safetySet written on
+ * interval_t, as a user of the class would supply it (no example in the reference constructs one). */
+int or_rb_safety_lo(int model, const or_options *o, const double *x, double *hlo);
+/* Dh_index_ (first nx entries), Lfh_diff, Lgh_diff[nu] of the last RB or_assemble on this thread */
+void or_rb_last_learning(double *Dh_index, double *Lfh_diff, double *Lgh_diff);
 
 /* -------------------------------------------------------------- filter */
 enum or_solver_kind { OR_SOLVER_EXACT = 0, OR_SOLVER_ADMM = 1 };

@@ -16,13 +16,37 @@ REF_LIB_PATH = os.path.join(ORACLE_DIR, "_ref", "libaffa_ref.so")
 
 MODEL_DI, MODEL_IP, MODEL_SEGWAY, MODEL_IP_ROBUST, MODEL_IP_TB = 0, 1, 2, 3, 4
 VAR_EXPLICIT, VAR_IMPLICIT, VAR_TB, VAR_ROBUST = 0, 1, 2, 3
+VAR_IMPLICIT_RB = 5  # src/asif_implicit_robust.cpp
 SOLVER_EXACT, SOLVER_ADMM = 0, 1
 
 # config id (BASELINE.json configs[]) -> (model, variant)
 CONFIGS = {2: (MODEL_DI, VAR_EXPLICIT), 3: (MODEL_IP, VAR_IMPLICIT), 4: (MODEL_SEGWAY, VAR_TB),
            5: (MODEL_IP_ROBUST, VAR_ROBUST),
            8: (MODEL_IP_TB, VAR_TB),     # examples/InvertedPendulum_ImplicitTB.cpp (not a BASELINE.json config)
-           9: (5, VAR_IMPLICIT)}         # examples/DoubleIntegrator_implicit.cpp   (not a BASELINE.json config)
+           9: (5, VAR_IMPLICIT),         # examples/DoubleIntegrator_implicit.cpp   (not a BASELINE.json config)
+           10: (MODEL_IP, VAR_IMPLICIT_RB)}  # ASIFimplicitRB on the pendulum model
+
+
+class Learning(C.Structure):
+    """or_learning == LearningData of include/asif_learning_utils.h:8-32 (weights column-major)."""
+    DIMS = ("d_drift_in", "d_act_in", "d_drift_hidden", "d_act_hidden", "d_drift_hidden_2", "d_act_hidden_2",
+            "d_drift_out", "d_act_out")
+    PTRS = ("w_1_drift", "w_2_drift", "w_3_drift", "b_1_drift", "b_2_drift", "b_3_drift",
+            "w_1_act", "w_2_act", "w_3_act", "b_1_act", "b_2_act", "b_3_act")
+    _fields_ = [(n, C.c_uint32) for n in DIMS] + [(n, C.POINTER(C.c_double)) for n in PTRS]
+
+    @classmethod
+    def from_dict(cls, w):
+        """w: dict with the DIMS as ints and the PTRS as float64 arrays (asif_amd.workloads.make_learning)."""
+        L = cls()
+        L._keep = {}
+        for n in cls.DIMS:
+            setattr(L, n, int(w[n]))
+        for n in cls.PTRS:
+            a = np.ascontiguousarray(w[n], dtype=np.float64)
+            L._keep[n] = a
+            setattr(L, n, a.ctypes.data_as(C.POINTER(C.c_double)))
+        return L
 
 
 class Options(C.Structure):
@@ -30,7 +54,14 @@ class Options(C.Structure):
         "relaxCost", "relaxLb", "relaxReachLb", "relaxTTS", "relaxMinOrtho", "backTrajHorizon",
         "backTrajExtend", "backTrajDt", "backTrajMinOrtho", "satSharpness", "inf")] + [
         ("lb", C.c_double * 1), ("ub", C.c_double * 1), ("pMin", C.c_double), ("pMax", C.c_double),
-        ("nHalfPlanes", C.c_int32), ("halfPlanes", C.c_double * 16)]
+        ("nHalfPlanes", C.c_int32), ("halfPlanes", C.c_double * 16),
+        ("backContDt", C.c_double), ("x_unc", C.c_double * 4), ("n_debug", C.c_int32),
+        ("use_learning", C.c_int32), ("learning", C.POINTER(Learning))]
+
+    def set_learning(self, L):
+        self._learning_keep = L
+        self.learning = C.pointer(L) if L is not None else None
+        self.use_learning = 1 if L is not None else 0
 
 
 class Dims(C.Structure):
@@ -176,6 +207,33 @@ def last_crit_idx(cap=16):
     idx = np.zeros(cap, dtype=np.int32)
     n = lib().or_last_crit_idx(_p(idx, C.c_int32), cap)
     return idx[:n].copy()
+
+
+def assemble(model, variant, o, x):
+    """One or_assemble on the calling thread (so or_last_crit_idx / or_rb_last_learning refer to it)."""
+    d = dims(model, variant, o)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    A = np.zeros(d.nc * d.nv)
+    b = np.zeros(d.nc)
+    diag = np.zeros(8)
+    code = lib().or_assemble(model, variant, C.byref(o), _p(x), _p(A), _p(b), _p(diag))
+    return A, b, code
+
+
+def rb_safety_lo(model, o, x):
+    d = dims(model, VAR_IMPLICIT_RB, o)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    h = np.zeros(d.npSS)
+    assert lib().or_rb_safety_lo(model, C.byref(o), _p(x), _p(h)) == 0
+    return h
+
+
+def rb_last_learning():
+    dh = np.zeros(4)
+    lf = C.c_double()
+    lg = np.zeros(1)
+    lib().or_rb_last_learning(_p(dh), C.byref(lf), _p(lg))
+    return dh, lf.value, lg
 
 
 def _run_program(fn, prog, nreg, cap=48):
