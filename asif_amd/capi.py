@@ -24,7 +24,11 @@ CONFIGS = {
     8: (6, IMPLICIT_TB, 16384),
     # not a BASELINE.json config: examples/DoubleIntegrator_implicit.cpp (201-step trajectory, npBTSS = 4)
     9: (7, IMPLICIT, 65536),
+    # not a BASELINE.json config: class ASIFimplicitRB on the pendulum model, workload of
+    # asif_amd.workloads (x_unc = RB_X_UNC, seeded networks of make_learning())
+    10: (MODEL_INVERTED_PENDULUM, 5, 16384),
 }
+IMPLICIT_RB = 5
 MODEL_INVERTED_PENDULUM_TB = 6
 MODEL_DOUBLE_INTEGRATOR_IMPLICIT = 7
 
@@ -35,6 +39,7 @@ EXPORTS = [
     "asif_hip_filter_batch_host", "asif_hip_default_realizable_options", "asif_hip_create_realizable",
     "asif_hip_update_realizable_options", "asif_hip_realizable_tables", "asif_hip_default_robust_data_options",
     "asif_hip_create_robust_data", "asif_hip_update_robust_data_options", "asif_hip_rollout_batch",
+    "asif_hip_set_learning",
 ]
 
 MODEL_DOUBLE_INTEGRATOR_SAMPLED = 4
@@ -66,7 +71,31 @@ class Options(C.Structure):
         "relaxCost", "relaxLb", "relaxReachLb", "relaxTTS", "relaxMinOrtho", "backTrajHorizon",
         "backTrajExtend", "backTrajDt", "backTrajMinOrtho", "satSharpness", "inf")] + [
         ("lb", C.c_double * 1), ("ub", C.c_double * 1), ("pMin", C.c_double), ("pMax", C.c_double),
-        ("nHalfPlanes", C.c_int32), ("halfPlanes", C.c_double * 16)]
+        ("nHalfPlanes", C.c_int32), ("halfPlanes", C.c_double * 16),
+        # ASIFimplicitRB extras (include/asif_implicit_robust.h:24-37)
+        ("backContDt", C.c_double), ("x_unc", C.c_double * 4), ("n_debug", C.c_int32), ("use_learning", C.c_int32)]
+
+
+class LearningData(C.Structure):
+    """asif_hip_learning_data == LearningData of include/asif_learning_utils.h:8-32 (host pointers)."""
+    DIMS = ("d_drift_in", "d_act_in", "d_drift_hidden", "d_act_hidden", "d_drift_hidden_2", "d_act_hidden_2",
+            "d_drift_out", "d_act_out")
+    PTRS = ("w_1_drift", "w_2_drift", "w_3_drift", "b_1_drift", "b_2_drift", "b_3_drift",
+            "w_1_act", "w_2_act", "w_3_act", "b_1_act", "b_2_act", "b_3_act")
+    _fields_ = [(n, C.c_uint32) for n in DIMS] + [(n, C.POINTER(C.c_double)) for n in PTRS]
+
+    @classmethod
+    def from_dict(cls, w):
+        import numpy as np
+        L = cls()
+        L._keep = {}
+        for n in cls.DIMS:
+            setattr(L, n, int(w[n]))
+        for n in cls.PTRS:
+            a = np.ascontiguousarray(w[n], dtype=np.float64)
+            L._keep[n] = a
+            setattr(L, n, a.ctypes.data_as(C.POINTER(C.c_double)))
+        return L
 
 
 class Solver(C.Structure):
@@ -120,6 +149,7 @@ def load():
                                                     C.POINTER(RobustDataOptions), C.POINTER(Solver), C.c_int]
         lib.asif_hip_update_robust_data_options.argtypes = [vp, C.POINTER(RobustDataOptions)]
         lib.asif_hip_rollout_batch.argtypes = [vp, i64, i64, C.c_int32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.asif_hip_set_learning.argtypes = [vp, C.POINTER(LearningData)]
         _lib = lib
     return _lib
 
@@ -184,6 +214,14 @@ class Filter:
         check(self.lib.asif_hip_update_options(self.handle, C.byref(options)))
         self.options = options
         check(self.lib.asif_hip_get_dims(self.handle, C.byref(self.dims)))
+
+    def set_learning(self, weights):
+        """ASIFimplicitRB::learning_data_: weights = dict of LearningData's fields (numpy), or None to clear."""
+        if weights is None:
+            check(self.lib.asif_hip_set_learning(self.handle, None))
+        else:
+            L = LearningData.from_dict(weights)
+            check(self.lib.asif_hip_set_learning(self.handle, C.byref(L)))
 
     def filter(self, x, udes, uact, relax, rc, diag=None):
         """x [nx,B], udes [nu,B] -> uact [nu,B], relax [nrelax,B], rc int32[B]; all CUDA tensors, in place."""

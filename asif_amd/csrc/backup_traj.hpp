@@ -48,12 +48,30 @@ struct BackupLoop {
 		}
 	}
 
-	__device__ __forceinline__ static void closedLoop(const DevOptions &o, const double (&x)[NX], double (&fCL)[NX],
-	                                                  double (&DfCL)[NX * NX])
+	// Zero-order hold of the backup input, ASIFimplicitRB only (src/asif_implicit_robust.cpp:891-903, members
+	// t_last_zoh_ / u_zoh_): re-sampled when t >= t_last + backContDt - 1e-4; the first rhs of a trajectory
+	// (t <= backTrajDt) resets the clock.  Du_zoh_ is read only by the fused-gradient branch (:913-919); the
+	// separate dynamics / dynamicsGradients branch every device model takes keeps the FRESH Du (:936-938).
+	struct Hold {
+		double u, tLast;
+	};
+
+	template <bool HOLD>
+	__device__ __forceinline__ static void closedLoopT(const DevOptions &o, const double (&x)[NX], double (&fCL)[NX],
+	                                                   double (&DfCL)[NX * NX], Hold &hold, double t)
 	{
 		double f[NX], g[NX], Df[NX * NX], Dg[NX * NX], u[1], Du[NX], uSat, DuSat;
 		M::backupController(o, x, u, Du);
-		saturateSoft(o, u[0], uSat, DuSat);
+		double us = u[0];
+		if (HOLD) {
+			if (t <= o.trajDt) hold.tLast = -1.;
+			if (t >= (hold.tLast + o.backContDt - 0.0001)) {
+				hold.u = u[0];
+				hold.tLast = t;
+			}
+			us = hold.u;
+		}
+		saturateSoft(o, us, uSat, DuSat);
 		M::dynamicsAndGradients(o, x, f, g, Df, Dg);
 #pragma unroll
 		for (int i = 0; i < NX; i++) {
@@ -64,13 +82,28 @@ struct BackupLoop {
 		}
 	}
 
-	// one forward-Euler step of [x; vec Q] (src/asif_implicit.cpp:470-477: rhs*dt + previous)
+	__device__ __forceinline__ static void closedLoop(const DevOptions &o, const double (&x)[NX], double (&fCL)[NX],
+	                                                  double (&DfCL)[NX * NX])
+	{
+		Hold none = {0.0, 0.0};
+		closedLoopT<false>(o, x, fCL, DfCL, none, 0.0);
+	}
+
 	__device__ __forceinline__ static void eulerStep(const DevOptions &o, double (&z)[NZ])
+	{
+		Hold none = {0.0, 0.0};
+		eulerStepT<false>(o, z, none, 0.0);
+	}
+
+	// one forward-Euler step of [x; vec Q] (src/asif_implicit.cpp:470-477: rhs*dt + previous); t is the time
+	// the reference stamps on this rhs (src/asif_implicit_robust.cpp:567: i*backTrajDt for the step INTO sample i)
+	template <bool HOLD>
+	__device__ __forceinline__ static void eulerStepT(const DevOptions &o, double (&z)[NZ], Hold &hold, double t)
 	{
 		double x[NX], fCL[NX], DfCL[NX * NX], zd[NZ];
 #pragma unroll
 		for (int i = 0; i < NX; i++) x[i] = z[i];
-		closedLoop(o, x, fCL, DfCL);
+		closedLoopT<HOLD>(o, x, fCL, DfCL, hold, t);
 #pragma unroll
 		for (int i = 0; i < NX; i++) zd[i] = fCL[i];
 #pragma unroll

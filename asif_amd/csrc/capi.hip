@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 using namespace asif;
 
@@ -38,6 +39,9 @@ struct asif_hip_ctx {
 		RbDev dev;
 		double *d_hp, *d_pointC;
 	} *rb;
+	// ASIFimplicitRB::learning_data_: one device buffer holding both networks (nullptr until set)
+	double *d_learn;
+	DevOptions::Learn learn;
 };
 
 extern "C" int asif_hip_version(void) { return ASIF_HIP_VERSION; }
@@ -81,6 +85,8 @@ extern "C" int asif_hip_default_options(int model, int variant, asif_hip_options
 	o->satSharpness = (variant == ASIF_HIP_EXPLICIT) ? 5.0 : 0.1;
 	o->inf = 1e20;
 	o->pMin = o->pMax = 1.0;
+	o->backContDt = 0.01; // ASIFimplicitRB extras at their header defaults (include/asif_implicit_robust.h:26,31,37)
+	o->n_debug = -1;
 	switch (model) {
 	case ASIF_HIP_MODEL_DOUBLE_INTEGRATOR:
 		o->lb[0] = -1.0;
@@ -205,7 +211,7 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 		return ASIF_HIP_OK;
 	}
 	if ((model == ASIF_HIP_MODEL_INVERTED_PENDULUM || model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT) &&
-	    variant == ASIF_HIP_IMPLICIT) {
+	    (variant == ASIF_HIP_IMPLICIT || variant == ASIF_HIP_IMPLICIT_RB)) {
 		d.nx = 2; d.nu = 1; d.npSS = 4; d.npBS = 1;
 		// examples/InvertedPendulum_Implicit.cpp:17, examples/DoubleIntegrator_implicit.cpp:17
 		d.npBTSS = model == ASIF_HIP_MODEL_INVERTED_PENDULUM ? 10 : 4;
@@ -223,6 +229,19 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 		dev.npBT = npBT;
 		dev.trajDt = dt;
 		d.ndiag = d.npBTSS + 1;                 // critical sample indexes, ADMM iterations
+		if (variant == ASIF_HIP_IMPLICIT_RB) {
+			// critical samples, Dh_index_[nx], Lfh_diff, Lgh_diff[nu], ADMM iterations
+			d.ndiag = d.npBTSS + d.nx + 1 + d.nu + 1;
+			if (!(o.backContDt > 0)) return ASIF_HIP_EINVAL;
+			dev.backContDt = o.backContDt;
+			for (int i = 0; i < d.nx; i++) {
+				if (!(o.x_unc[i] >= 0)) return ASIF_HIP_EINVAL;
+				dev.xUnc[i] = o.x_unc[i];
+			}
+			// initialize(), src/asif_implicit_robust.cpp:298-303: outside (-1, npBT-1) means "most critical sample"
+			dev.nDebug = (o.n_debug > -1 && o.n_debug < npBT - 1) ? o.n_debug : -1;
+			dev.useLearning = o.use_learning ? 1 : 0;
+		}
 		return ASIF_HIP_OK;
 	}
 	if ((model == ASIF_HIP_MODEL_SEGWAY || model == ASIF_HIP_MODEL_INVERTED_PENDULUM_TB) && variant == ASIF_HIP_IMPLICIT_TB) {
@@ -302,7 +321,75 @@ extern "C" int asif_hip_create(asif_hip_ctx **out, int model, int variant, const
 	c->s_code = nullptr;
 	c->s_code_cap = 0;
 	c->rz = nullptr;
+	c->rb = nullptr;
+	c->d_learn = nullptr;
+	std::memset(&c->learn, 0, sizeof(c->learn));
 	*out = c;
+	return ASIF_HIP_OK;
+}
+
+// ---- ASIFimplicitRB::learning_data_ -------------------------------------------------------------
+extern "C" int asif_hip_set_learning(asif_hip_ctx *ctx, const asif_hip_learning_data *L)
+{
+	if (!ctx || ctx->variant != ASIF_HIP_IMPLICIT_RB) return ASIF_HIP_EINVAL;
+	hipError_t e = hipSetDevice(ctx->device);
+	if (e != hipSuccess) return (int)e;
+	if (ctx->d_learn) {
+		(void)hipDeviceSynchronize(); // a launch in flight may still read the old weights
+		(void)hipFree(ctx->d_learn);
+		ctx->d_learn = nullptr;
+	}
+	std::memset(&ctx->learn, 0, sizeof(ctx->learn));
+	if (!L) return ASIF_HIP_OK;
+	const int nx = ctx->dims.nx, nu = ctx->dims.nu;
+	const uint32_t din[2] = {L->d_drift_in, L->d_act_in}, h1[2] = {L->d_drift_hidden, L->d_act_hidden},
+	               h2[2] = {L->d_drift_hidden_2, L->d_act_hidden_2}, dout[2] = {L->d_drift_out, L->d_act_out};
+	const double *w1[2] = {L->w_1_drift, L->w_1_act}, *b1[2] = {L->b_1_drift, L->b_1_act};
+	const double *w2[2] = {L->w_2_drift, L->w_2_act}, *b2[2] = {L->b_2_drift, L->b_2_act};
+	const double *w3[2] = {L->w_3_drift, L->w_3_act}, *b3[2] = {L->b_3_drift, L->b_3_act};
+	size_t total = 0;
+	for (int n = 0; n < 2; n++) {
+		// update_weights writes 2 nx inputs and reads 1 (drift) / nu (act) outputs (include/asif_learning_utils.h:123-154)
+		if ((int)din[n] < 2 * nx || h1[n] < 1 || h2[n] < 1 || (int)dout[n] < (n == 0 ? 1 : nu)) return ASIF_HIP_EINVAL;
+		if (h1[n] > 32 || h2[n] > 32 || dout[n] > 64 || din[n] > 64) return ASIF_HIP_EUNSUPPORTED;
+		if (!w1[n] || !b1[n] || !w2[n] || !b2[n] || !w3[n] || !b3[n]) return ASIF_HIP_EINVAL;
+		// only the first 2 nx input columns of w1 are ever multiplied by non-zeros
+		total += (size_t)h1[n] * 2 * nx + h1[n] + (size_t)h2[n] * h1[n] + h2[n] + (size_t)dout[n] * h2[n] + dout[n];
+	}
+	std::vector<double> host(total);
+	size_t off = 0;
+	size_t o1[2], ob1[2], o2[2], ob2[2], o3[2], ob3[2];
+	for (int n = 0; n < 2; n++) {
+		auto put = [&](const double *src, size_t cnt) {
+			std::memcpy(host.data() + off, src, cnt * sizeof(double));
+			const size_t at = off;
+			off += cnt;
+			return at;
+		};
+		o1[n] = put(w1[n], (size_t)h1[n] * 2 * nx); // column-major [h1 x d_in]: the leading 2 nx columns are contiguous
+		ob1[n] = put(b1[n], h1[n]);
+		o2[n] = put(w2[n], (size_t)h2[n] * h1[n]);
+		ob2[n] = put(b2[n], h2[n]);
+		o3[n] = put(w3[n], (size_t)dout[n] * h2[n]);
+		ob3[n] = put(b3[n], dout[n]);
+	}
+	if ((e = hipMalloc((void **)&ctx->d_learn, total * sizeof(double))) != hipSuccess) return (int)e;
+	if ((e = hipMemcpy(ctx->d_learn, host.data(), total * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) {
+		(void)hipFree(ctx->d_learn);
+		ctx->d_learn = nullptr;
+		return (int)e;
+	}
+	for (int n = 0; n < 2; n++) {
+		ctx->learn.dHidden[n] = (int)h1[n];
+		ctx->learn.dHidden2[n] = (int)h2[n];
+		ctx->learn.dOut[n] = (int)dout[n];
+		ctx->learn.w1[n] = ctx->d_learn + o1[n];
+		ctx->learn.b1[n] = ctx->d_learn + ob1[n];
+		ctx->learn.w2[n] = ctx->d_learn + o2[n];
+		ctx->learn.b2[n] = ctx->d_learn + ob2[n];
+		ctx->learn.w3[n] = ctx->d_learn + o3[n];
+		ctx->learn.b3[n] = ctx->d_learn + ob3[n];
+	}
 	return ASIF_HIP_OK;
 }
 
@@ -623,6 +710,10 @@ extern "C" int asif_hip_destroy(asif_hip_ctx *ctx)
 		(void)hipSetDevice(ctx->device);
 		rb_free(ctx->rb);
 	}
+	if (ctx->d_learn) {
+		(void)hipSetDevice(ctx->device);
+		(void)hipFree(ctx->d_learn);
+	}
 	if (ctx->s_rows) {
 		(void)hipSetDevice(ctx->device);
 		(void)hipFree(ctx->s_rows);
@@ -696,6 +787,22 @@ static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipSt
 	if (ctx->rb) return launch_robust_data(ctx->rb->dev, ctx->solver, a, assemble_only, stream);
 	if (ctx->model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR && ctx->variant == ASIF_HIP_EXPLICIT)
 		return launch_explicit_di(ctx->dev, ctx->solver, a, assemble_only, stream);
+	if (ctx->variant == ASIF_HIP_IMPLICIT_RB) {
+		DevOptions dev = ctx->dev;
+		if (dev.useLearning) {
+			if (!ctx->d_learn) return ASIF_HIP_EINVAL; // the reference would dereference null weights
+			dev.learn = ctx->learn;
+		}
+		if (!assemble_only) {
+			int r = stage_rows(ctx, a);
+			if (r) return r;
+		}
+		if (ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM)
+			return launch_implicit_ip(dev, ctx->solver, a, assemble_only, stream, true);
+		if (ctx->model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT)
+			return launch_implicit_di(dev, ctx->solver, a, assemble_only, stream, true);
+		return ASIF_HIP_EINVAL;
+	}
 	if (ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM && ctx->variant == ASIF_HIP_IMPLICIT) {
 		if (!assemble_only) {
 			int r = stage_rows(ctx, a);

@@ -11,6 +11,13 @@
 // Stage 2  qp_policy_kernel<3,41,G>: cost/bounds of initialize()/updateCost() (:237-254,653-664),
 //   in-register ADMM, then the epilogue of filter(): inputSaturate + relax on success (:338-347),
 //   saturated backup controller and rc = -1 on failure (:348-355).
+// ASIFimplicitRB (src/asif_implicit_robust.cpp, RB = true): the same two stages with
+//   * the backup input held over backContDt along the trajectory (:891-903),
+//   * the safe rows' margins replaced by the lower end of the interval safety set over x_k +- x_unc (:635-647),
+//   * optionally two small ReLU networks evaluated on [x; Dh_index_] whose outputs are added to the first
+//     row's Lfh / Lgh (include/asif_learning_utils.h:123-155); Dh_index_ is the first column of Dh_SS Q at the
+//     most critical sample, or at sample n_debug (:590-605,624-632).
+//   The interval Lie derivatives the reference also forms (:698-709) feed nothing there and are not computed.
 // The 5000-step trajectory is ~99 % of the work and is inherently sequential per instance; the solve
 // is re-dealt G lanes per QP so the second launch fills the whole chip.
 #include "backup_traj.hpp"
@@ -18,13 +25,46 @@
 
 namespace asif {
 
-template <class M>
+constexpr int kLearnMaxHidden = 32; // widest hidden layer the rows kernel keeps in LDS (2 x 32 x 64 doubles)
+
+// driftNN / actNN (include/asif_learning_utils.h:34-121), one instance per lane: weights are wave-uniform
+// (scalar loads), the two hidden activations live in LDS as [unit][lane].  The reference zero-pads the input
+// to d_*_in; the padded columns multiply zeros and are skipped.
+template <int NIN>
+__device__ inline double learn_net(const DevOptions::Learn &L, int net, const double (&in)[NIN], double *act,
+                                         int lane, int outIdx)
+{
+	const int h1 = L.dHidden[net], h2 = L.dHidden2[net];
+	const double *__restrict__ w1 = L.w1[net], *__restrict__ b1 = L.b1[net];
+	const double *__restrict__ w2 = L.w2[net], *__restrict__ b2 = L.b2[net];
+	const double *__restrict__ w3 = L.w3[net], *__restrict__ b3 = L.b3[net];
+	double *a1 = act, *a2 = act + kLearnMaxHidden * 64;
+	for (int j = 0; j < h1; j++) {
+		double s = 0.0;
+#pragma unroll
+		for (int i = 0; i < NIN; i++) s += w1[j + i * h1] * in[i];
+		a1[j * 64 + lane] = fmax(0., s + b1[j]);
+	}
+	for (int j = 0; j < h2; j++) {
+		double s = 0.0;
+		for (int i = 0; i < h1; i++) s += w2[j + i * h2] * a1[i * 64 + lane];
+		a2[j * 64 + lane] = fmax(0., s + b2[j]);
+	}
+	const int nout = L.dOut[net];
+	double s = 0.0;
+	for (int i = 0; i < h2; i++) s += w3[outIdx + i * nout] * a2[i * 64 + lane];
+	return s + b3[outIdx];
+}
+
+template <class M, bool RB>
 __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterArgs a)
 {
 	constexpr int NX = M::NX, NP = M::NPSS, K = M::NPBTSS, NB = M::NPBS, NZ = NX + NX * NX;
 	constexpr int NC = K * NP + NB;
 	static_assert(NB == 1, "one backup-set function");
+	static_assert(!RB || NP >= NX, "Dh_index_ takes the first nx entries of a column of the npSS x nx product");
 	__shared__ double pay[K * NZ * 64];
+	__shared__ double act[RB ? 2 * kLearnMaxHidden * 64 : 1];
 	const int lane = threadIdx.x;
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const bool live = i < a.B;
@@ -45,9 +85,17 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 	}
 	TopK<K> top;
 	top.init();
+	typename BackupLoop<M>::Hold hold = {0.0, 0.0};
+	double zDbg[NZ]; // the sample feeding the networks when n_debug selects one (:590-605)
+#pragma unroll
+	for (int k = 0; k < NZ; k++) zDbg[k] = z[k];
 #pragma unroll 1
 	for (int s = 0; s < o.npBT; s++) {
-		if (s > 0) BackupLoop<M>::eulerStep(o, z);
+		if (s > 0) BackupLoop<M>::template eulerStepT<RB>(o, z, hold, (double)(unsigned)s * o.trajDt);
+		if (RB && s == o.nDebug) {
+#pragma unroll
+			for (int k = 0; k < NZ; k++) zDbg[k] = z[k];
+		}
 		double xs[NX];
 #pragma unroll
 		for (int k = 0; k < NX; k++) xs[k] = z[k];
@@ -64,6 +112,9 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 	}
 	if (!live) return;
 	const int64_t ld = a.ld;
+	double dhIndex[NX], Lf00 = 0.0, Lg00 = 0.0; // Dh_index_[0..nx), Lfh[0], Lgh[0]
+#pragma unroll
+	for (int c = 0; c < NX; c++) dhIndex[c] = 0.0;
 	// safe rows from the parked critical samples
 #pragma unroll 1
 	for (int k = 0; k < K; k++) {
@@ -74,6 +125,7 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 #pragma unroll
 		for (int c = 0; c < NX; c++) xs[c] = zk[c];
 		M::safetySet(o, xs, h, Dh);
+		if (RB) M::safetySetLo(o, xs, h); // :635-647
 #pragma unroll
 		for (int r = 0; r < NP; r++) {
 			double DhQ[NX];
@@ -89,6 +141,13 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 			for (int j = 0; j < NX; j++) {
 				Lf += DhQ[j] * f0[j];
 				Lg += DhQ[j] * g0[j];
+			}
+			if (RB && k == 0) {
+				if (r < NX) dhIndex[r] = DhQ[0]; // :624-632, Dh_index_[i] = (Dh_SS Q)[i + 0*npSS]
+				if (r == 0) {
+					Lf00 = Lf;
+					Lg00 = Lg;
+				}
 			}
 			const int row = k * NP + r;
 			a.A[(int64_t)(row + 0 * NC) * ld + i] = Lg;
@@ -118,6 +177,40 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 		a.A[(int64_t)(row + 1 * NC) * ld + i] = 0.0;
 		a.A[(int64_t)(row + 2 * NC) * ld + i] = hB;
 		a.b[(int64_t)row * ld + i] = -Lf;
+	}
+	if (RB) {
+		if (o.nDebug >= 0) { // :590-605: Dh_index_ from sample n_debug instead
+			double xs[NX], h[NP], Dh[NP * NX];
+#pragma unroll
+			for (int c = 0; c < NX; c++) xs[c] = zDbg[c];
+			M::safetySet(o, xs, h, Dh);
+#pragma unroll
+			for (int r = 0; r < NX; r++) {
+				double s = 0.0;
+#pragma unroll
+				for (int c = 0; c < NX; c++) s += Dh[r + c * NP] * zDbg[NX + c + 0 * NX];
+				dhIndex[r] = s;
+			}
+		}
+		double dLf = 0.0, dLg = 0.0;
+		if (o.useLearning) { // update_weights, include/asif_learning_utils.h:123-155
+			double in[2 * NX];
+#pragma unroll
+			for (int c = 0; c < NX; c++) {
+				in[c] = x0[c];
+				in[NX + c] = dhIndex[c];
+			}
+			dLf = learn_net<2 * NX>(o.learn, 0, in, act, lane, 0);
+			dLg = learn_net<2 * NX>(o.learn, 1, in, act, lane, 0);
+			a.A[(int64_t)(0 + 0 * NC) * ld + i] = Lg00 + dLg;
+			a.b[(int64_t)0 * ld + i] = -(Lf00 + dLf);
+		}
+		if (a.diag) { // public members Dh_index_, learning_data_.Lfh_diff / Lgh_diff
+#pragma unroll
+			for (int c = 0; c < NX; c++) a.diag[(int64_t)(K + c) * ld + i] = dhIndex[c];
+			a.diag[(int64_t)(K + NX) * ld + i] = dLf;
+			a.diag[(int64_t)(K + NX + 1) * ld + i] = dLg;
+		}
 	}
 	if (a.code) a.code[i] = 1;
 }
@@ -167,11 +260,12 @@ struct ImplicitPolicy {
 };
 
 int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
-                       hipStream_t stream)
+                       hipStream_t stream, bool rb)
 {
 	using M = InvertedPendulum;
 	if (a.B <= 0) return 0;
-	hipLaunchKernelGGL((implicit_rows_kernel<M>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
+	if (rb) hipLaunchKernelGGL((implicit_rows_kernel<M, true>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
+	else hipLaunchKernelGGL((implicit_rows_kernel<M, false>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
 	int e = (int)hipGetLastError();
 	if (e || assemble_only) return e;
 	const ImplicitPolicy<M> p = {a.B, o, a};
@@ -186,12 +280,13 @@ int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const Filt
 
 // examples/DoubleIntegrator_implicit.cpp: npBTSS = 4 -> nc = 4*4 + 1 = 17 rows
 int launch_implicit_di(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
-                       hipStream_t stream)
+                       hipStream_t stream, bool rb)
 {
 	using M = DoubleIntegratorImplicit;
 	static_assert(M::NPBTSS * M::NPSS + M::NPBS == 17, "QP shape 3 x 17");
 	if (a.B <= 0) return 0;
-	hipLaunchKernelGGL((implicit_rows_kernel<M>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
+	if (rb) hipLaunchKernelGGL((implicit_rows_kernel<M, true>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
+	else hipLaunchKernelGGL((implicit_rows_kernel<M, false>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
 	int e = (int)hipGetLastError();
 	if (e || assemble_only) return e;
 	const ImplicitPolicy<M> p = {a.B, o, a};

@@ -41,12 +41,13 @@ int launch_rollout_explicit_di(const DevOptions &o, const asif_hip_solver &S, co
 
 // implicit backup-trajectory filter (class ASIFimplicit), model = InvertedPendulum.
 // Filter mode needs a.A / a.b to point at staging rows of (nc*nv + nc) * ld doubles.
+// rb: class ASIFimplicitRB on the same model (held backup input, interval margins, learned residual).
 int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
-                       hipStream_t stream);
+                       hipStream_t stream, bool rb = false);
 
 // same class, model = DoubleIntegratorImplicit (examples/DoubleIntegrator_implicit.cpp, npBTSS = 4)
 int launch_implicit_di(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
-                       hipStream_t stream);
+                       hipStream_t stream, bool rb = false);
 
 // time-to-backup-set filter (class ASIFimplicitTB), model = Segway.
 // Filter mode additionally needs a.code to point at B staged int32 branch codes.

@@ -28,7 +28,40 @@ struct DevOptions {
 	// forms uc = (u - middle) * twoOverRange where the reference divides, 2*(u-middle)/range
 	// (src/asif_implicit.cpp:696): one rounding of difference, no FP64 divide in the 5000-step loop.
 	double satRange, satMiddle, twoOverRange;
+	// ASIFimplicitRB (include/asif_implicit_robust.h:24-37)
+	double backContDt;
+	double xUnc[ASIF_HIP_MAX_NX];
+	int nDebug;      // already validated against npBT (initialize(), src/asif_implicit_robust.cpp:298-303)
+	int useLearning;
+	// LearningData (include/asif_learning_utils.h:8-32) uploaded by asif_hip_set_learning: device pointers
+	struct Learn {
+		int dHidden[2], dHidden2[2], dOut[2]; // [0] drift network, [1] actuation network
+		const double *w1[2], *b1[2], *w2[2], *b2[2], *w3[2], *b3[2];
+	} learn;
 };
+
+// lower end of the box safety set {-x0+hi, x0-lo, x1-lo, -x1+hi} over x +- unc, evaluated the way libaffa
+// evaluates the same expressions on AAF operands (src/asif_implicit_robust.cpp:640-647):
+//   AAF(interval(a,b)): centre (b+a)/2, one symbol with coefficient (b-a)/2   aa_aafcommon.cpp:81-100
+//   unary minus / +- double: centre only, coefficient sign                    aa_aafarithm.cpp
+//   convert().left(): centre - sum |coefficient|                              aa_aafcommon.cpp:217-245
+// Additions only (the halvings are exact), so no contraction issue: bit-identical to the reference.
+__device__ __forceinline__ void box_safety_lo(const double (&x)[2], const double *unc, double lo, double hi,
+                                              double (&h)[4])
+{
+	double c[2], d[2];
+#pragma unroll
+	for (int i = 0; i < 2; i++) {
+		const double a = x[i] - unc[i], b = x[i] + unc[i];
+		c[i] = (b + a) / 2;
+		d[i] = (b - a) / 2;
+		d[i] = d[i] >= 0.0 ? d[i] : -d[i];
+	}
+	h[0] = (-c[0] + hi) - d[0];
+	h[1] = (c[0] - lo) - d[0];
+	h[2] = (c[1] - lo) - d[1];
+	h[3] = (-c[1] + hi) - d[1];
+}
 
 // sin and cos together for the trajectory loops (|x| <= 1e5; beyond that ocml's sincos takes over):
 // two-term Cody-Waite reduction by pi/2 carried by FMAs, then the fdlibm minimax kernels on
@@ -107,6 +140,11 @@ struct InvertedPendulum {
 	{
 		return fmin(fmin(-x[0] + kPi, x[0] + kPi), fmin(x[1] + kPi, -x[1] + kPi));
 	}
+	// the same set on interval_t operands over x +- x_unc (ASIFimplicitRB's safetySet_int), lower ends
+	__device__ static void safetySetLo(const DevOptions &o, const double (&x)[NX], double (&h)[NPSS])
+	{
+		box_safety_lo(x, o.xUnc, -kPi, kPi, h);
+	}
 	// :39-52  ellipsoid Pv - x'Px >= 0, P = [1.25 .25; .25 .25]; gradient -(P+P')x
 	__device__ static void backupSet(const DevOptions &, const double (&x)[NX], double &h, double (&Dh)[NX],
 	                                 double (&DDh)[NX * NX])
@@ -170,6 +208,11 @@ struct DoubleIntegratorImplicit {
 	__device__ static double safetyMin(const DevOptions &, const double (&x)[NX])
 	{
 		return fmin(fmin(-x[0] + 1.0, x[0] - (-1.0)), fmin(x[1] - (-1.0), -x[1] + 1.0));
+	}
+	// the same set on interval_t operands over x +- x_unc (ASIFimplicitRB's safetySet_int), lower ends
+	__device__ static void safetySetLo(const DevOptions &o, const double (&x)[NX], double (&h)[NPSS])
+	{
+		box_safety_lo(x, o.xUnc, -1.0, 1.0, h);
 	}
 	// :42-55  h = Pv - x'Px;  Dh = mPpPt x with the shipped mPpPt = {-1, -0.577.., -0.577.., +1} (last entry is
 	// not -(P+P')(1,1) = -1; reproduced as is)

@@ -29,7 +29,8 @@ from asif_amd import capi, dist, workloads  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 # algorithmic HBM bytes per instance of the state->input path: read 8(nx+nu), write 8(nu+nrelax)+4
-ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44, 6: 52, 7: 44, 8: 44, 9: 52}
+ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44, 6: 52, 7: 44, 8: 44, 9: 52, 10: 52}
+IMPLICIT_RB_CFG = 10  # ASIFimplicitRB on the pendulum model; not a BASELINE.json config
 REALIZABLE_CFG = 6  # ASIFrealizable on the sampled double integrator; not a BASELINE.json config
 ROBUST_DATA_CFG = 7  # ASIFrobust on the shipped data: examples/DoubleIntegrator_Robust.cpp + KernelData_70-135kg.h
 WORKLOAD = {
@@ -41,7 +42,19 @@ WORKLOAD = {
     7: "C7 DoubleIntegrator_Robust (ASIFrobust::filter on the shipped 100 half-planes, 5 kept per call, nv=22 nc=15)",
     8: "C8 InvertedPendulum_ImplicitTB (ASIFimplicitTB::filter, 11 551-step backup trajectory)",
     9: "C9 DoubleIntegrator_implicit (ASIFimplicit::filter, 201-step backup trajectory, npBTSS 4, nv=3 nc=17)",
+    10: "C10 ASIFimplicitRB::filter on the InvertedPendulum_Implicit model (backup input held 10 steps, interval "
+        "margins under x_unc, two 4-16-16-1 ReLU residual networks with seeded weights)",
 }
+
+
+def rb_options(lib_module, model, variant):
+    """Config 10's options on either side (asif_amd.capi or the oracle's ctypes view): the example's options
+    plus x_unc and use_learning; the caller attaches the weights of workloads.make_learning()."""
+    o = lib_module.default_options(model, variant)
+    for i, v in enumerate(workloads.RB_X_UNC):
+        o.x_unc[i] = v
+    o.use_learning = 1
+    return o
 
 
 def host_cores():
@@ -97,8 +110,11 @@ def cpu_baseline(cfg, gpu_uact, gpu_rc, x, udes):
     O.build()
     model, variant = O.CONFIGS[cfg]
     o = O.default_options(model, variant)
+    if cfg == IMPLICIT_RB_CFG:
+        o = rb_options(O, model, variant)
+        o.set_learning(O.Learning.from_dict(workloads.make_learning()))
     cores = host_cores()
-    probe = {2: 20000, 3: 16, 4: 256, 5: 2000, 8: 16, 9: 512}[cfg]
+    probe = {2: 20000, 3: 16, 4: 256, 5: 2000, 8: 16, 9: 512, 10: 16}[cfg]
     xs, us = O.make_batch(cfg, probe)
     t = time.perf_counter()
     O.filter_batch(model, variant, o, xs, us, O.SOLVER_ADMM, None, 1)
@@ -108,7 +124,7 @@ def cpu_baseline(cfg, gpu_uact, gpu_rc, x, udes):
     t = time.perf_counter()
     O.filter_batch(model, variant, o, xs, us, O.SOLVER_ADMM, None, cores)
     dt = time.perf_counter() - t
-    m = min(x.shape[1], {2: 65536, 3: 512, 4: 16384, 5: 8192, 8: 512, 9: 16384}[cfg])
+    m = min(x.shape[1], {2: 65536, 3: 512, 4: 16384, 5: 8192, 8: 512, 9: 16384, 10: 512}[cfg])
     ua, _, rc = O.filter_batch(model, variant, o, np.ascontiguousarray(x[:, :m].T),
                                np.ascontiguousarray(udes[:, :m].T), O.SOLVER_EXACT, None, cores,
                                uact_init=np.zeros((m, 1)))
@@ -188,6 +204,10 @@ def main():
         default_b = 8192
         halfplanes = workloads.load_halfplanes(args.halfplanes)
         flt = capi.RobustDataFilter(halfplanes, solver=solver, device=dev.index)
+    elif cfg == IMPLICIT_RB_CFG:
+        model, variant, default_b = capi.CONFIGS[cfg]
+        flt = capi.Filter(model, variant, options=rb_options(capi, model, variant), solver=solver, device=dev.index)
+        flt.set_learning(workloads.make_learning())
     else:
         model, variant, default_b = capi.CONFIGS[cfg]
         flt = capi.Filter(model, variant, solver=solver, device=dev.index)

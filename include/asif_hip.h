@@ -45,7 +45,8 @@
 extern "C" {
 #endif
 
-#define ASIF_HIP_VERSION 110 /* 110: realizable / robust-data handles, solver.presolve, scaling_iters 0 = default */
+#define ASIF_HIP_VERSION 120 /* 110: realizable / robust-data handles, solver.presolve, scaling_iters 0 = default;
+                              * 120: ASIF_HIP_IMPLICIT_RB (options grew at the end), asif_hip_set_learning */
 
 enum asif_hip_error {
 	ASIF_HIP_OK = 0,
@@ -72,10 +73,14 @@ enum asif_hip_variant {
 	ASIF_HIP_IMPLICIT = 1,    /* class ASIFimplicit,   include/asif_implicit.h:17-216   */
 	ASIF_HIP_IMPLICIT_TB = 2, /* class ASIFimplicitTB, include/asif_implicit_tb.h:17-208 */
 	ASIF_HIP_ROBUST = 3,      /* class ASIFrobust,     include/asif_robust.h:11-89      */
-	ASIF_HIP_REALIZABLE = 4   /* class ASIFrealizable, include/asif_realizable.h:9-123 (asif_hip_create_realizable) */
+	ASIF_HIP_REALIZABLE = 4,  /* class ASIFrealizable, include/asif_realizable.h:9-123 (asif_hip_create_realizable) */
+	ASIF_HIP_IMPLICIT_RB = 5  /* class ASIFimplicitRB, include/asif_implicit_robust.h:19-279: ASIFimplicit with the
+	                           * backup input held over backContDt, interval safety margins under x_unc and an
+	                           * optional learned residual; models INVERTED_PENDULUM, DOUBLE_INTEGRATOR_IMPLICIT */
 };
 
 #define ASIF_HIP_MAX_NU 1
+#define ASIF_HIP_MAX_NX 4
 #define ASIF_HIP_MAX_HALFPLANES 8
 
 /* Union of the reference's four Options structs (include/asif.h:11-17, include/asif_implicit.h:20-34,
@@ -98,7 +103,22 @@ typedef struct asif_hip_options {
 	double pMin, pMax;
 	int32_t nHalfPlanes;
 	double halfPlanes[2 * ASIF_HIP_MAX_HALFPLANES]; /* {a0,a1}: 1 - a.x >= 0 */
+	/* ASIFimplicitRB::Options extras (include/asif_implicit_robust.h:24-37); ignored by the other variants */
+	double backContDt;             /* the backup input is re-sampled every backContDt along the trajectory */
+	double x_unc[ASIF_HIP_MAX_NX]; /* state uncertainty radius (Options::x_unc; nullptr there = zeros here) */
+	int32_t n_debug;               /* -1: the network sees Dh at the most critical sample; else at this sample */
+	int32_t use_learning;          /* needs asif_hip_set_learning before the first filter call */
 } asif_hip_options;
+
+/* LearningData (include/asif_learning_utils.h:8-32): two small ReLU networks whose outputs are added to the
+ * first row's Lfh / Lgh (update_weights, :123-155).  HOST pointers, dense column-major [rows x cols] as
+ * matrixVectorMultiply reads them; asif_hip_set_learning copies.  Hidden widths <= 64, inputs >= 2 nx. */
+typedef struct asif_hip_learning_data {
+	uint32_t d_drift_in, d_act_in, d_drift_hidden, d_act_hidden, d_drift_hidden_2, d_act_hidden_2, d_drift_out,
+	    d_act_out;
+	const double *w_1_drift, *w_2_drift, *w_3_drift, *b_1_drift, *b_2_drift, *b_3_drift;
+	const double *w_1_act, *w_2_act, *w_3_act, *b_1_act, *b_2_act, *b_3_act;
+} asif_hip_learning_data;
 
 /* In-kernel ADMM settings.  Defaults (asif_hip_default_solver) are tuned for |u - u*| <= 1e-6:
  * OSQP-style splitting with power-of-two Ruiz scaling, per-row rho, adaptive rho, infeasibility
@@ -165,6 +185,10 @@ int asif_hip_destroy(asif_hip_ctx *ctx);
 int asif_hip_get_dims(const asif_hip_ctx *ctx, asif_hip_dims *d);
 /* updateOptions(options) of the reference classes (src/asif.cpp:213-231 etc.) */
 int asif_hip_update_options(asif_hip_ctx *ctx, const asif_hip_options *opts);
+/* Fills ASIFimplicitRB::learning_data_ (public member, include/asif_implicit_robust.h:149) of an
+ * ASIF_HIP_IMPLICIT_RB handle: uploads the weights.  NULL clears them.  A handle whose options say
+ * use_learning without weights fails its filter calls with ASIF_HIP_EINVAL. */
+int asif_hip_set_learning(asif_hip_ctx *ctx, const asif_hip_learning_data *L);
 
 /* ---- realizable filter (class ASIFrealizable) ------------------------------------------------------------
  * ASIFrealizable::kernel_t (include/asif_realizable.h:22-36) flattened; HOST arrays, copied by create.

@@ -6,9 +6,13 @@ import torch
 from asif_amd import capi, workloads
 
 
-def run_filter(cfg, B, first=0, solver=None, options=None, uact_init=0.0, relax_init=0.0, x=None, udes=None):
-    model, variant, _ = capi.CONFIGS[cfg]
+def run_filter(cfg, B, first=0, solver=None, options=None, uact_init=0.0, relax_init=0.0, x=None, udes=None,
+               learning=None, model=None, variant=None):
+    if model is None:
+        model, variant, _ = capi.CONFIGS[cfg]
     flt = capi.Filter(model, variant, options=options, solver=solver)
+    if learning is not None:
+        flt.set_learning(learning)
     d = flt.dims
     if x is None:
         x, udes = workloads.make_batch(cfg, B, first)
@@ -28,9 +32,12 @@ def run_filter(cfg, B, first=0, solver=None, options=None, uact_init=0.0, relax_
     return out
 
 
-def run_assemble(cfg, B, first=0, options=None, x=None):
-    model, variant, _ = capi.CONFIGS[cfg]
+def run_assemble(cfg, B, first=0, options=None, x=None, learning=None, model=None, variant=None):
+    if model is None:
+        model, variant, _ = capi.CONFIGS[cfg]
     flt = capi.Filter(model, variant, options=options)
+    if learning is not None:
+        flt.set_learning(learning)
     d = flt.dims
     if x is None:
         x, _ = workloads.make_batch(cfg, B, first)
