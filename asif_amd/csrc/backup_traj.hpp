@@ -63,7 +63,7 @@ struct BackupLoop {
 		double f[NX], g[NX], Df[NX * NX], Dg[NX * NX], u[1], Du[NX], uSat, DuSat;
 		M::backupController(o, x, u, Du);
 		double us = u[0];
-		if (HOLD) {
+		if (HOLD && o.backContDt > 0) { // backContDt == 0: plain ASIFimplicit routed through the RB kernel (learning)
 			if (t <= o.trajDt) hold.tLast = -1.;
 			if (t >= (hold.tLast + o.backContDt - 0.0001)) {
 				hold.u = u[0];

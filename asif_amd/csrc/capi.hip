@@ -229,6 +229,10 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 		dev.npBT = npBT;
 		dev.trajDt = dt;
 		d.ndiag = d.npBTSS + 1;                 // critical sample indexes, ADMM iterations
+		// n_debug / use_learning exist in both classes (include/asif_implicit.h:23,33; initialize() resets an
+		// n_debug outside (-1, npBT-1) to "most critical sample", src/asif_implicit.cpp:219-224)
+		dev.nDebug = (o.n_debug > -1 && o.n_debug < npBT - 1) ? o.n_debug : -1;
+		dev.useLearning = o.use_learning ? 1 : 0;
 		if (variant == ASIF_HIP_IMPLICIT_RB) {
 			// critical samples, Dh_index_[nx], Lfh_diff, Lgh_diff[nu], ADMM iterations
 			d.ndiag = d.npBTSS + d.nx + 1 + d.nu + 1;
@@ -238,9 +242,6 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 				if (!(o.x_unc[i] >= 0)) return ASIF_HIP_EINVAL;
 				dev.xUnc[i] = o.x_unc[i];
 			}
-			// initialize(), src/asif_implicit_robust.cpp:298-303: outside (-1, npBT-1) means "most critical sample"
-			dev.nDebug = (o.n_debug > -1 && o.n_debug < npBT - 1) ? o.n_debug : -1;
-			dev.useLearning = o.use_learning ? 1 : 0;
 		}
 		return ASIF_HIP_OK;
 	}
@@ -331,7 +332,7 @@ extern "C" int asif_hip_create(asif_hip_ctx **out, int model, int variant, const
 // ---- ASIFimplicitRB::learning_data_ -------------------------------------------------------------
 extern "C" int asif_hip_set_learning(asif_hip_ctx *ctx, const asif_hip_learning_data *L)
 {
-	if (!ctx || ctx->variant != ASIF_HIP_IMPLICIT_RB) return ASIF_HIP_EINVAL;
+	if (!ctx || (ctx->variant != ASIF_HIP_IMPLICIT_RB && ctx->variant != ASIF_HIP_IMPLICIT)) return ASIF_HIP_EINVAL;
 	hipError_t e = hipSetDevice(ctx->device);
 	if (e != hipSuccess) return (int)e;
 	if (ctx->d_learn) {
@@ -787,7 +788,10 @@ static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipSt
 	if (ctx->rb) return launch_robust_data(ctx->rb->dev, ctx->solver, a, assemble_only, stream);
 	if (ctx->model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR && ctx->variant == ASIF_HIP_EXPLICIT)
 		return launch_explicit_di(ctx->dev, ctx->solver, a, assemble_only, stream);
-	if (ctx->variant == ASIF_HIP_IMPLICIT_RB) {
+	// ASIFimplicitRB, and ASIFimplicit with its learned residual switched on (src/asif_implicit.cpp:585-588):
+	// the latter runs the RB rows kernel with the hold off (backContDt = 0) and zero uncertainty, which is
+	// bitwise the plain kernel plus the residual
+	if (ctx->variant == ASIF_HIP_IMPLICIT_RB || (ctx->variant == ASIF_HIP_IMPLICIT && ctx->dev.useLearning)) {
 		DevOptions dev = ctx->dev;
 		if (dev.useLearning) {
 			if (!ctx->d_learn) return ASIF_HIP_EINVAL; // the reference would dereference null weights

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 			a.A[(int64_t)(0 + 0 * NC) * ld + i] = Lg00 + dLg;
 			a.b[(int64_t)0 * ld + i] = -(Lf00 + dLf);
 		}
-		if (a.diag) { // public members Dh_index_, learning_data_.Lfh_diff / Lgh_diff
+		if (a.diag && a.ndiag >= K + NX + 3) { // public members Dh_index_, learning_data_.Lfh_diff / Lgh_diff
 #pragma unroll
 			for (int c = 0; c < NX; c++) a.diag[(int64_t)(K + c) * ld + i] = dhIndex[c];
 			a.diag[(int64_t)(K + NX) * ld + i] = dLf;

@@ -16,7 +16,8 @@ BackupLoopHost::BackupLoopHost(bool hasGradient, uint32_t nx, uint32_t nu, uint3
                                CtrlFn backupController)
     : hasGradient_(hasGradient), nx_(nx), nu_(nu), npSS_(npSS), safetySet_(safetySet), dynamics_(dynamics),
       dynamicsGradients_(dynamicsGradients), dynamicsWithGradient_(dynamicsWithGradient),
-      backupController_(backupController), lbU_(nu, 0.0), ubU_(nu, 0.0), satSharpness_(0.1)
+      backupController_(backupController), lbU_(nu, 0.0), ubU_(nu, 0.0), satSharpness_(0.1), holdDt_(0.0),
+      holdStep_(0.0), tLastHold_(-1.0), uHold_(nu, 0.0), DuHold_(nu * nx, 0.0)
 {
 	if (hasGradient_) {
 		// plain dynamics = the fused callback at zero input (src/asif_implicit.cpp:81-89)
@@ -58,19 +59,31 @@ void BackupLoopHost::saturateHard(double u[]) const
 	for (uint32_t i = 0; i < nu_; i++) u[i] = std::min(std::max(u[i], lbU_[i]), ubU_[i]);
 }
 
-// src/asif_implicit.cpp:751-815
-void BackupLoopHost::closedLoop(const double x[], double fCL[], double DfCL[]) const
+// src/asif_implicit.cpp:751-815; with holdDt_ > 0: src/asif_implicit_robust.cpp:878-953
+void BackupLoopHost::closedLoop(const double x[], double fCL[], double DfCL[], double t) const
 {
 	std::vector<double> f(nx_), g(nx_ * nu_), u(nu_), Du(nu_ * nx_), uSat(nu_), DuSat(nu_);
 	backupController_(x, u.data(), Du.data());
-	saturateSoft(u.data(), uSat.data(), DuSat.data());
+	const bool held = holdDt_ > 0;
+	if (held) {
+		if (t <= holdStep_) tLastHold_ = -1.; // first rhs of a trajectory resets the clock (:891-893)
+		if (t >= (tLastHold_ + holdDt_ - 0.0001)) {
+			uHold_ = u;
+			DuHold_ = Du;
+			tLastHold_ = t;
+		}
+	}
+	saturateSoft(held ? uHold_.data() : u.data(), uSat.data(), DuSat.data());
 	if (hasGradient_) {
+		// the fused-gradient branch of the held class uses the HELD controller Jacobian (:913-919); the
+		// separate branch below keeps the fresh one (:936-938) -- both as in the reference
+		const std::vector<double> &DuJ = held ? DuHold_ : Du;
 		std::vector<double> dfcl(nx_ * nx_);
 		dynamicsWithGradient_(x, uSat.data(), f.data(), g.data(), dfcl.data());
 		for (uint32_t i = 0; i < nx_; i++)
 			for (uint32_t j = 0; j < nx_; j++) {
 				double v = dfcl[i + j * nx_];
-				for (uint32_t k = 0; k < nu_; k++) v += g[i + k * nx_] * DuSat[k] * Du[k + j * nu_];
+				for (uint32_t k = 0; k < nu_; k++) v += g[i + k * nx_] * DuSat[k] * DuJ[k + j * nu_];
 				DfCL[i + j * nx_] = v;
 			}
 	} else {
@@ -109,7 +122,7 @@ void BackupLoopHost::integrate(const double x[], uint32_t npBT, double dt)
 		if (s > 0) {
 			const state_t &zp = traj_[s - 1].second;
 			traj_[s].first = traj_[s - 1].first + dt;
-			closedLoop(zp.data(), zd.data(), DfCL.data());
+			closedLoop(zp.data(), zd.data(), DfCL.data(), (double)s * dt); // :567: stamped s*backTrajDt
 			for (uint32_t i = 0; i < nx_; i++)
 				for (uint32_t j = 0; j < nx_; j++) {
 					double v = 0.0;
@@ -151,6 +164,9 @@ ASIFimplicit::ASIFimplicit(const uint32_t nx, const uint32_t nu, const uint32_t 
       npBT_(0), H_(nv_ * nv_, 0.0), c_(nv_, 0.0), A_(npTC_ * nv_, 0.0), b_(npTC_, 0.0), lb_(nv_, 0.0), ub_(nv_, 0.0),
       batch_(nullptr)
 {
+	index_debug_ = 0;
+	Dh_index_.assign((size_t)nx * npSS, 0.0);
+	h_index_.assign(npSS, 0.0);
 }
 
 ASIFimplicit::ASIFimplicit(const uint32_t nx, const uint32_t nu, const uint32_t npSS, const uint32_t npBS,
@@ -162,6 +178,9 @@ ASIFimplicit::ASIFimplicit(const uint32_t nx, const uint32_t nu, const uint32_t 
       npBT_(0), H_(nv_ * nv_, 0.0), c_(nv_, 0.0), A_(npTC_ * nv_, 0.0), b_(npTC_, 0.0), lb_(nv_, 0.0), ub_(nv_, 0.0),
       batch_(nullptr)
 {
+	index_debug_ = 0;
+	Dh_index_.assign((size_t)nx * npSS, 0.0);
+	h_index_.assign(npSS, 0.0);
 }
 
 ASIFimplicit::~ASIFimplicit(void)
@@ -173,6 +192,11 @@ ASIFimplicit::~ASIFimplicit(void)
 int32_t ASIFimplicit::initialize(const double lb[], const double ub[])
 {
 	npBT_ = trajectoryLength(options_.backTrajHorizon, options_.backTrajDt, npBTSS_); // :211-216
+	holdStep_ = options_.backTrajDt;
+	if (options_.n_debug != -1) { // :219-224
+		if (options_.n_debug > -1 && options_.n_debug < (int)npBT_ - 1) index_debug_ = options_.n_debug;
+		else options_.n_debug = -1;
+	}
 	satSharpness_ = options_.satSharpness;
 	for (uint32_t j = 0; j < nu_; j++) {
 		H_[j + j * nv_] = 1.0;
@@ -263,6 +287,7 @@ int32_t ASIFimplicit::updateOptions(const Options &options)
 int32_t ASIFimplicit::updateOptions(void)
 {
 	npBT_ = trajectoryLength(options_.backTrajHorizon, options_.backTrajDt, npBTSS_);
+	holdStep_ = options_.backTrajDt;
 	H_[(nv_ - 2) + (nv_ - 2) * nv_] = options_.relaxCost;
 	H_[(nv_ - 1) + (nv_ - 1) * nv_] = options_.relaxCost;
 	c_[nv_ - 2] = -2.0 * options_.relaxCost * options_.relaxSafeLb;
@@ -293,17 +318,34 @@ int32_t ASIFimplicit::updateConstraints(const double x[])
 	lowestFirst(order, npBT_);
 	backTrajCritIdx_.assign(order.begin(), order.begin() + npBTSS_);
 	std::vector<double> h(npTC_, 0.0), Dh(npTC_ * nx_, 0.0);
-	for (uint32_t k = 0; k < npBTSS_; k++) {
-		const uint32_t s = order[k];
+	// Dh_SS(x_s) Q_s, column-major npSS x nx
+	auto sampleProduct = [this](uint32_t s, double *out) {
 		const double *Q = traj_[s].second.data() + nx_;
-		for (uint32_t i = 0; i < npSS_; i++) {
-			h[k * npSS_ + i] = hAll_[(size_t)s * npSS_ + i];
+		for (uint32_t i = 0; i < npSS_; i++)
 			for (uint32_t j = 0; j < nx_; j++) {
 				double v = 0.0;
 				for (uint32_t c = 0; c < nx_; c++) v = v + DhAll_[(size_t)s * npSS_ * nx_ + i + c * npSS_] * Q[c + j * nx_];
-				Dh[(k * npSS_ + i) + j * npTC_] = v;
+				out[i + j * npSS_] = v;
 			}
+	};
+	std::vector<double> prod(npSS_ * nx_);
+	if (options_.n_debug != -1) { // :500-515: the sample the network sees is fixed by the caller
+		sampleProduct((uint32_t)index_debug_, Dh_index_.data());
+		for (uint32_t i = 0; i < npSS_; i++) h_index_[i] = hAll_[(size_t)index_debug_ * npSS_ + i];
+	}
+	for (uint32_t k = 0; k < npBTSS_; k++) {
+		const uint32_t s = order[k];
+		sampleProduct(s, prod.data());
+		for (uint32_t i = 0; i < npSS_; i++) {
+			h[k * npSS_ + i] = hAll_[(size_t)s * npSS_ + i];
+			for (uint32_t j = 0; j < nx_; j++) Dh[(k * npSS_ + i) + j * npTC_] = prod[i + j * npSS_];
 		}
+		if (k == 0 && options_.n_debug == -1) { // :533-537
+			Dh_index_ = prod;
+			for (uint32_t i = 0; i < npSS_; i++) h_index_[i] = h[i];
+			index_debug_ = (int)s;
+		}
+		safeMargins(traj_[s].second.data(), &h[k * npSS_]); // ASIFimplicitRB: interval lower ends
 	}
 	const state_t &zend = traj_.back().second;
 	std::vector<double> DhB(npBS_ * nx_);
@@ -314,17 +356,24 @@ int32_t ASIFimplicit::updateConstraints(const double x[])
 			for (uint32_t c = 0; c < nx_; c++) v = v + DhB[i + c * npBS_] * zend[nx_ + c + j * nx_];
 			Dh[(npBTSS_ * npSS_ + i) + j * npTC_] = v;
 		}
-	std::fill(A_.begin(), A_.end(), 0.0);
+	std::vector<double> Lfh(npTC_), Lgh(npTC_ * nu_);
 	for (uint32_t r = 0; r < npTC_; r++) {
 		double Lf = 0.0;
 		for (uint32_t c = 0; c < nx_; c++) Lf = Lf + Dh[r + c * npTC_] * f[c];
+		Lfh[r] = Lf;
 		for (uint32_t j = 0; j < nu_; j++) {
 			double Lg = 0.0;
 			for (uint32_t c = 0; c < nx_; c++) Lg = Lg + Dh[r + c * npTC_] * g[c + j * nx_];
-			A_[r + j * npTC_] = Lg;
+			Lgh[r + j * npTC_] = Lg;
 		}
+	}
+	if (options_.use_learning) // :585-588
+		update_weights(&learning_data_, x, nx_, Dh_index_.data(), Lfh.data(), Lgh.data(), nu_);
+	std::fill(A_.begin(), A_.end(), 0.0);
+	for (uint32_t r = 0; r < npTC_; r++) {
+		for (uint32_t j = 0; j < nu_; j++) A_[r + j * npTC_] = Lgh[r + j * npTC_];
 		A_[r + (r < npBTSS_ * npSS_ ? nu_ : nu_ + 1) * npTC_] = h[r];
-		b_[r] = -Lf;
+		b_[r] = -Lfh[r];
 	}
 	return 1;
 }
@@ -344,6 +393,8 @@ void ASIFimplicit::fillOptions(asif_hip_options &o) const
 	o.backTrajDt = options_.backTrajDt;
 	o.satSharpness = options_.satSharpness;
 	o.inf = options_.inf;
+	o.n_debug = options_.n_debug;
+	o.use_learning = options_.use_learning ? 1 : 0;
 	for (uint32_t j = 0; j < nu_ && j < ASIF_HIP_MAX_NU; j++) {
 		o.lb[j] = lbU_[j];
 		o.ub[j] = ubU_[j];
@@ -356,8 +407,21 @@ int32_t ASIFimplicit::bindDeviceModel(int model, int device)
 	batch_ = nullptr;
 	asif_hip_options o;
 	fillOptions(o);
-	int r = asif_hip_create(&batch_, model, ASIF_HIP_IMPLICIT, &o, nullptr, device);
+	int r = asif_hip_create(&batch_, model, deviceVariant(), &o, nullptr, device);
 	if (r) return r;
+	if (options_.use_learning) {
+		const LearningData &d = learning_data_;
+		asif_hip_learning_data L = {d.d_drift_in, d.d_act_in, d.d_drift_hidden, d.d_act_hidden, d.d_drift_hidden_2,
+		                            d.d_act_hidden_2, d.d_drift_out, d.d_act_out, d.w_1_drift, d.w_2_drift, d.w_3_drift,
+		                            d.b_1_drift, d.b_2_drift, d.b_3_drift, d.w_1_act, d.w_2_act, d.w_3_act, d.b_1_act,
+		                            d.b_2_act, d.b_3_act};
+		r = asif_hip_set_learning(batch_, &L);
+		if (r) {
+			asif_hip_destroy(batch_);
+			batch_ = nullptr;
+			return r;
+		}
+	}
 	asif_hip_dims d;
 	asif_hip_get_dims(batch_, &d);
 	if ((uint32_t)d.nx != nx_ || (uint32_t)d.nu != nu_ || (uint32_t)d.nc != npTC_) {

@@ -13,6 +13,7 @@
 #include <string>
 #include <utility>
 #include <vector>
+#include "asif_learning.h"
 #include "qpwrappers.h"
 
 namespace ASIF {
@@ -36,7 +37,8 @@ public:
 protected:
 	void saturateSoft(const double u[], double uSat[], double DuSat[]) const;
 	void saturateHard(double u[]) const;
-	void closedLoop(const double x[], double fCL[], double DfCL[]) const;
+	// t: the time the reference stamps on this rhs; only the held-input class (ASIFimplicitRB) reads it
+	void closedLoop(const double x[], double fCL[], double DfCL[], double t = 0.0) const;
 	void integrate(const double x[], uint32_t npBT, double dt);   // fills traj_, hAll_, DhAll_, hMin_
 	void lowestFirst(std::vector<uint32_t> &order, uint32_t count) const; // ties -> lowest sample index
 
@@ -49,6 +51,11 @@ protected:
 	CtrlFn backupController_;
 	std::vector<double> lbU_, ubU_;
 	double satSharpness_;
+	// zero-order hold of the backup input (ASIFimplicitRB: t_last_zoh_, u_zoh_, Du_zoh_,
+	// src/asif_implicit_robust.cpp:891-903); holdDt_ <= 0 switches it off
+	double holdDt_, holdStep_;
+	mutable double tLastHold_;
+	mutable std::vector<double> uHold_, DuHold_;
 	std::vector<std::pair<double, state_t>> traj_;
 	std::vector<double> hAll_, DhAll_, hMin_;
 };
@@ -67,7 +74,7 @@ public:
 		double backTrajRelTol = 1.0e-6;
 		double satSharpness = 0.1;
 		double inf = 1e20;
-		bool use_learning = false; // accepted for source compatibility; the learned residual is not built here
+		bool use_learning = false; // adds update_weights(learning_data_, ...) to the first row (src/asif_implicit.cpp:585-588)
 	} Options;
 	typedef std::vector<double> state_t;
 
@@ -92,14 +99,21 @@ public:
 	std::vector<std::pair<double, state_t>> &backTraj_ = traj_;
 	std::vector<uint32_t> backTrajCritIdx_;
 	double hBackupEnd_, hSafetyNow_;
+	int index_debug_;
+	std::vector<double> Dh_index_, h_index_;
+	LearningData learning_data_; // include/asif_implicit.h:125
 
+	// with options.use_learning the weights of learning_data_ are uploaded too (fill it first)
 	int32_t bindDeviceModel(int asif_hip_model_id, int device = 0);
 	int32_t filterBatch(int64_t B, const double x[], const double uDes[], double uAct[], double relax[], int32_t rc[]);
 
 protected:
 	int32_t updateOptions(void);
 	int32_t updateConstraints(const double x[]);
-	void fillOptions(asif_hip_options &o) const;
+	virtual void fillOptions(asif_hip_options &o) const;
+	virtual int deviceVariant(void) const { return ASIF_HIP_IMPLICIT; }
+	// hook of the derived ASIFimplicitRB: replace the margins of one critical sample (state xs) in place
+	virtual void safeMargins(const double xs[], double h[]) const {}
 	const uint32_t nv_, npBS_, npBTSS_, npTC_;
 	SetFn backupSet_;
 	Options options_;

@@ -106,6 +106,7 @@ typedef struct asif_hip_options {
 	/* ASIFimplicitRB::Options extras (include/asif_implicit_robust.h:24-37); ignored by the other variants */
 	double backContDt;             /* the backup input is re-sampled every backContDt along the trajectory */
 	double x_unc[ASIF_HIP_MAX_NX]; /* state uncertainty radius (Options::x_unc; nullptr there = zeros here) */
+	/* in ASIFimplicit::Options too (include/asif_implicit.h:23,33): honoured by ASIF_HIP_IMPLICIT and _IMPLICIT_RB */
 	int32_t n_debug;               /* -1: the network sees Dh at the most critical sample; else at this sample */
 	int32_t use_learning;          /* needs asif_hip_set_learning before the first filter call */
 } asif_hip_options;
@@ -185,8 +186,8 @@ int asif_hip_destroy(asif_hip_ctx *ctx);
 int asif_hip_get_dims(const asif_hip_ctx *ctx, asif_hip_dims *d);
 /* updateOptions(options) of the reference classes (src/asif.cpp:213-231 etc.) */
 int asif_hip_update_options(asif_hip_ctx *ctx, const asif_hip_options *opts);
-/* Fills ASIFimplicitRB::learning_data_ (public member, include/asif_implicit_robust.h:149) of an
- * ASIF_HIP_IMPLICIT_RB handle: uploads the weights.  NULL clears them.  A handle whose options say
+/* Fills learning_data_ (public member of ASIFimplicit, include/asif_implicit.h:125, and of ASIFimplicitRB,
+ * include/asif_implicit_robust.h:149) of an ASIF_HIP_IMPLICIT or ASIF_HIP_IMPLICIT_RB handle: uploads the weights.  NULL clears them.  A handle whose options say
  * use_learning without weights fails its filter calls with ASIF_HIP_EINVAL. */
 int asif_hip_set_learning(asif_hip_ctx *ctx, const asif_hip_learning_data *L);
 

@@ -437,8 +437,11 @@ static int assemble_implicit(const or_model *m, const or_options *o, const doubl
 	traj_t T;
 	integrate(m, o, rb ? OR_VARIANT_IMPLICIT_RB : OR_VARIANT_IMPLICIT, npBTSS, x, &T);
 	sort_by_hmin(&T, T.npBT);
-	/* initialize() :298-303: n_debug outside (-1, npBT-1) is reset to -1 */
-	const int n_debug = (rb && o->n_debug > -1 && o->n_debug < T.npBT - 1) ? o->n_debug : -1;
+	/* n_debug / use_learning / learning_data_ exist in BOTH classes (include/asif_implicit.h:23,33,125,
+	 * src/asif_implicit.cpp:219-224,500-515,533-537,585-588 == src/asif_implicit_robust.cpp:298-303,590-605,
+	 * 627-631,713-715).  initialize(): n_debug outside (-1, npBT-1) is reset to -1 */
+	const int learn = o->use_learning != 0;
+	const int n_debug = ((rb || learn) && o->n_debug > -1 && o->n_debug < T.npBT - 1) ? o->n_debug : -1;
 	int rc = 1;
 
 	double h[64] = {0.0}, Dh[64 * OR_MAX_NX] = {0.0};
@@ -453,15 +456,13 @@ static int assemble_implicit(const or_model *m, const or_options *o, const doubl
 		or_matmul(DhSS, np, nx, Q, nx, DhSSDx);
 		for (int i = 0; i < np; i++)
 			for (int j = 0; j < nx; j++) Dh[(idx * np + i) + j * nTC] = DhSSDx[i + j * np];
-		if (rb) {
-			/* :624-632: Dh_index_ = the np x nx product of the most critical sample, column-major */
-			if (idx == 0 && n_debug == -1)
-				for (int i = 0; i < nx; i++) g_rb_dh_index[i] = DhSSDx[i];
-			/* :635-647 */
-			if (rb_safety_lo(m, o, T.z + (size_t)cur * T.nz, &h[idx * np])) rc = -100;
-		}
+		/* :624-632: Dh_index_ = the np x nx product of the most critical sample, column-major */
+		if ((rb || learn) && idx == 0 && n_debug == -1)
+			for (int i = 0; i < nx; i++) g_rb_dh_index[i] = DhSSDx[i];
+		/* :635-647 */
+		if (rb && rb_safety_lo(m, o, T.z + (size_t)cur * T.nz, &h[idx * np])) rc = -100;
 	}
-	if (rb && n_debug != -1) { /* :590-605 */
+	if (n_debug != -1) { /* :590-605 */
 		double DhDbg[OR_MAX_NPSS * OR_MAX_NX];
 		or_matmul(&T.DhFull[(size_t)n_debug * np * nx], np, nx, T.z + (size_t)n_debug * T.nz + nx, nx, DhDbg);
 		for (int i = 0; i < nx; i++) g_rb_dh_index[i] = DhDbg[i];
@@ -475,7 +476,7 @@ static int assemble_implicit(const or_model *m, const or_options *o, const doubl
 	double Lfh[64], Lgh[64 * OR_MAX_NU];
 	or_matvec(Dh, nTC, nx, f, Lfh);
 	or_matmul(Dh, nTC, nx, g, nu, Lgh);
-	if (rb && o->use_learning) { /* :713-715 */
+	if (learn) { /* :713-715 */
 		if (rb_update_weights(o->learning, x, nx, g_rb_dh_index, Lfh, Lgh, nu)) rc = -100;
 	}
 	/* :591-611 */

@@ -180,3 +180,37 @@ def test_robust_class_on_shipped_data(hip, oracle, tmp_path):
     both = ok & (res[:, 3].astype(int) == 1)                              # single agent: where plain ADMM converged
     assert both.sum() >= 0.8 * ok.sum()
     assert np.abs(res[both, 1] - ua[both, 0]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("plain", [False, True])
+def test_implicit_rb_class_single_agent_and_batch(hip, oracle, plain):
+    """ASIF::ASIFimplicitRB (held backup input, interval margins from the user's safetySet_int on host AAF operands,
+    learned residual) and ASIF::ASIFimplicit with use_learning: single-agent filter() with host callbacks and
+    filterBatch() on the GPU against the oracle's exact answer; the class's public diagnostics Dh_index_ /
+    learning_data_.Lfh_diff / Lgh_diff against the oracle's."""
+    from asif_amd import workloads
+    exe = os.path.join(HOST, "implicit_rb")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HOST, "-s"])
+    n = 24
+    out = subprocess.run([exe, str(n)] + (["plain"] if plain else []), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = np.array([[float(v) for v in line.split(",")] for line in out.stdout.strip().split("\n")[1:]])
+    model = oracle.MODEL_IP
+    variant = oracle.VAR_IMPLICIT if plain else oracle.VAR_IMPLICIT_RB
+    o = oracle.default_options(model, variant)
+    if not plain:
+        o.x_unc[0], o.x_unc[1] = workloads.RB_X_UNC
+    L = oracle.Learning.from_dict(workloads.make_learning())
+    o.set_learning(L)
+    x, u = oracle.make_batch(3 if plain else 10, n)
+    ua, rl, rc = oracle.filter_batch(model, variant, o, x, u, oracle.SOLVER_EXACT)
+    assert np.array_equal(rows[:, 4].astype(int), rc) and np.array_equal(rows[:, 6].astype(int), rc)
+    assert np.abs(rows[:, 1] - ua[:, 0]).max() <= 1e-6      # single agent
+    assert np.abs(rows[:, 5] - ua[:, 0]).max() <= 1e-6      # batch
+    ok = rc == 1
+    assert np.abs(rows[ok, 2] - rl[ok, 0]).max() <= 1e-5 and np.abs(rows[ok, 3] - rl[ok, 1]).max() <= 1e-5
+    for i in range(n):
+        oracle.assemble(model, variant, o, x[i])
+        dh, lf, lg = oracle.rb_last_learning()
+        assert abs(rows[i, 7] - dh[0]) <= 1e-12 and abs(rows[i, 8] - lf) <= 1e-13 and abs(rows[i, 9] - lg[0]) <= 1e-13

@@ -149,3 +149,27 @@ def test_learning_without_weights_fails_loudly(hip, oracle):
     with pytest.raises(Exception):
         flt.set_learning(w)
     flt.close()
+
+
+def test_plain_implicit_class_with_its_learned_residual(hip, oracle):
+    """use_learning / n_debug / learning_data_ also exist in ASIFimplicit (include/asif_implicit.h:23,33,125;
+    src/asif_implicit.cpp:585-588): variant IMPLICIT with the option set adds the same residual, nothing else."""
+    B = 2048
+    w = workloads.make_learning()
+    od = hip.default_options(1, 1)
+    od.use_learning = 1
+    oo = oracle.default_options(oracle.MODEL_IP, oracle.VAR_IMPLICIT)
+    oo.set_learning(oracle.Learning.from_dict(w))
+    out = gpu_util.run_assemble(3, B, options=od, learning=w)
+    A, b, _, _ = oracle.assemble_batch(oracle.MODEL_IP, oracle.VAR_IMPLICIT, oo, np.ascontiguousarray(out["x"].T))
+    np.testing.assert_allclose(out["A"].T, A, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(out["b"].T, b, rtol=1e-9, atol=1e-11)
+    plain = gpu_util.run_assemble(3, B, x=out["x"])
+    dA = (out["A"] - plain["A"]).reshape(3, 41, B)
+    db = out["b"] - plain["b"]
+    assert np.abs(dA[0, 0]).min() > 0 and np.abs(db[0]).min() > 0
+    assert np.all(dA[0, 1:] == 0) and np.all(dA[1:] == 0) and np.all(db[1:] == 0)  # bitwise elsewhere
+    f = gpu_util.run_filter(3, B, options=od, learning=w, x=out["x"], udes=workloads.make_batch(3, B)[1], uact_init=7.0)
+    ua, rl, rc = oracle.filter_batch(oracle.MODEL_IP, oracle.VAR_IMPLICIT, oo, np.ascontiguousarray(f["x"].T),
+                                     np.ascontiguousarray(f["udes"].T), uact_init=np.full((B, 1), 7.0), nthreads=8)
+    assert np.array_equal(f["rc"], rc) and np.abs(f["uact"][0] - ua[:, 0]).max() <= 1e-6

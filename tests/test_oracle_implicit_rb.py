@@ -198,3 +198,24 @@ def test_device_algorithm_emulation_decides_rb_like_exact(oracle):
     if bad.any():
         want = np.clip(x[bad] @ np.array([-3.0, -3.0]), o.lb[0], o.ub[0])
         assert np.abs(ua[bad, 0] - want).max() <= 1e-15
+
+
+def test_plain_implicit_class_carries_the_same_learned_residual(oracle):
+    """include/asif_implicit.h:23,33,125 + src/asif_implicit.cpp:585-588: ASIFimplicit has n_debug / use_learning /
+    learning_data_ as well."""
+    m = oracle.MODEL_IP
+    o = oracle.default_options(m, oracle.VAR_IMPLICIT)
+    x, _ = oracle.make_batch(3, 16)
+    A0, b0, _, _ = oracle.assemble_batch(m, oracle.VAR_IMPLICIT, o, x)
+    w = workloads.make_learning()
+    o.set_learning(oracle.Learning.from_dict(w))
+    d = oracle.dims(m, oracle.VAR_IMPLICIT, o)
+    for i, xi in enumerate(x):
+        A, b, _ = oracle.assemble(m, oracle.VAR_IMPLICIT, o, xi)
+        dh, lf, lg = oracle.rb_last_learning()
+        vin = np.concatenate([xi, dh[:2]])
+        assert abs(_mlp(w, "drift", vin)[0] - lf) <= 1e-13 and abs(_mlp(w, "act", vin)[0] - lg[0]) <= 1e-13
+        dA = A.reshape(d.nv, d.nc) - A0[i].reshape(d.nv, d.nc)
+        assert abs(dA[0, 0] - lg[0]) <= 1e-13 and abs((b0[i][0] - b[0]) - lf) <= 1e-13
+        dA[0, 0] = 0.0
+        assert np.all(dA == 0.0) and np.array_equal(b[1:], b0[i][1:])
