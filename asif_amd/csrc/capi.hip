@@ -42,6 +42,9 @@ struct asif_hip_ctx {
 	// ASIFimplicitRB::learning_data_: one device buffer holding both networks (nullptr until set)
 	double *d_learn;
 	DevOptions::Learn learn;
+	// per-step return codes of asif_hip_rollout_batch's stream-ordered path
+	int32_t *r_rc;
+	int64_t r_cap;
 };
 
 extern "C" int asif_hip_version(void) { return ASIF_HIP_VERSION; }
@@ -325,6 +328,8 @@ extern "C" int asif_hip_create(asif_hip_ctx **out, int model, int variant, const
 	c->rb = nullptr;
 	c->d_learn = nullptr;
 	std::memset(&c->learn, 0, sizeof(c->learn));
+	c->r_rc = nullptr;
+	c->r_cap = 0;
 	*out = c;
 	return ASIF_HIP_OK;
 }
@@ -715,6 +720,10 @@ extern "C" int asif_hip_destroy(asif_hip_ctx *ctx)
 		(void)hipSetDevice(ctx->device);
 		(void)hipFree(ctx->d_learn);
 	}
+	if (ctx->r_rc) {
+		(void)hipSetDevice(ctx->device);
+		(void)hipFree(ctx->r_rc);
+	}
 	if (ctx->s_rows) {
 		(void)hipSetDevice(ctx->device);
 		(void)hipFree(ctx->s_rows);
@@ -856,12 +865,39 @@ extern "C" int asif_hip_rollout_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx,
                                       double *ulog, int32_t *rclog, void *stream)
 {
 	if (!ctx || B < 0 || ldx < B || T < 0 || (B > 0 && (!x || !udes || !uact || !relax || !nfail))) return ASIF_HIP_EINVAL;
-	if (ctx->model != ASIF_HIP_MODEL_DOUBLE_INTEGRATOR || ctx->variant != ASIF_HIP_EXPLICIT) return ASIF_HIP_EUNSUPPORTED;
+	const bool fused = ctx->model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR && ctx->variant == ASIF_HIP_EXPLICIT;
+	const bool staged = !ctx->rz && !ctx->rb &&
+	                    (ctx->variant == ASIF_HIP_IMPLICIT || ctx->variant == ASIF_HIP_IMPLICIT_RB ||
+	                     ctx->variant == ASIF_HIP_IMPLICIT_TB);
+	if (!fused && !staged) return ASIF_HIP_EUNSUPPORTED;
 	if (B == 0 || T == 0) return ASIF_HIP_OK;
 	hipError_t e = hipSetDevice(ctx->device);
 	if (e != hipSuccess) return (int)e;
-	const RolloutArgs a = {B, ldx, T, dt, x, udes, uact, relax, nfail, xlog, ulog, rclog};
-	return launch_rollout_explicit_di(ctx->dev, ctx->solver, a, (hipStream_t)stream);
+	if (fused) {
+		const RolloutArgs a = {B, ldx, T, dt, x, udes, uact, relax, nfail, xlog, ulog, rclog};
+		return launch_rollout_explicit_di(ctx->dev, ctx->solver, a, (hipStream_t)stream);
+	}
+	// two-stage filters: T x (rows kernel, QP kernel, plant step) in stream order, nothing returns to the host
+	hipStream_t s = (hipStream_t)stream;
+	if (B > ctx->r_cap) {
+		if (ctx->r_rc) (void)hipFree(ctx->r_rc);
+		ctx->r_rc = nullptr;
+		ctx->r_cap = 0;
+		if ((e = hipMalloc((void **)&ctx->r_rc, sizeof(int32_t) * B)) != hipSuccess) return (int)e;
+		ctx->r_cap = B;
+	}
+	if ((e = hipMemsetAsync(nfail, 0, sizeof(int32_t) * B, s)) != hipSuccess) return (int)e;
+	const asif_hip_dims &d = ctx->dims;
+	for (int32_t t = 0; t < T; t++) {
+		FilterArgs a = {B, ldx, x, udes, uact, relax, ctx->r_rc, nullptr, d.ndiag, nullptr, nullptr, nullptr};
+		int r = run_filter(ctx, a, false, s);
+		if (r) return r;
+		r = launch_plant_step(ctx->model, ctx->dev, B, ldx, dt, x, uact, ctx->r_rc, nfail,
+		                      xlog ? xlog + (int64_t)t * d.nx * ldx : nullptr,
+		                      ulog ? ulog + (int64_t)t * d.nu * ldx : nullptr, rclog ? rclog + (int64_t)t * ldx : nullptr, s);
+		if (r) return r;
+	}
+	return ASIF_HIP_OK;
 }
 
 extern "C" int asif_hip_assemble_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, const double *x, double *A,

@@ -38,6 +38,10 @@ struct RolloutArgs {
 	int32_t *rclog;     // [T][ld], or nullptr
 };
 int launch_rollout_explicit_di(const DevOptions &o, const asif_hip_solver &S, const RolloutArgs &a, hipStream_t stream);
+// plant Euler step x += dt (f(x) + g(x) uact) between two filter calls of the two-stage filters (k_rollout.hip);
+// logs the state / input / rc of the call just made (nullptr to skip) and counts rc < 0 into nfail
+int launch_plant_step(int model, const DevOptions &o, int64_t B, int64_t ld, double dt, double *x, const double *uact,
+                      const int32_t *rc, int32_t *nfail, double *xlog, double *ulog, int32_t *rclog, hipStream_t s);
 
 // implicit backup-trajectory filter (class ASIFimplicit), model = InvertedPendulum.
 // Filter mode needs a.A / a.b to point at staging rows of (nc*nv + nc) * ld doubles.

@@ -261,9 +261,13 @@ int asif_hip_filter_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, const doubl
  * per step  rc = filter(x, uDes, uAct, relax)  (cold start, same arithmetic as asif_hip_filter_batch), then the
  * plant's forward-Euler step  x += dt (f(x) + g(x) uAct)  (:96-110); a failed filter call leaves uAct at its previous
  * value, as the example does.  x[nx][ldx] in/out, udes[nu][ldx] held over the rollout, uact[nu][ldx] in (input applied
- * if the first call fails) / out (last applied), relax[1][ldx] in/out, nfail[B] = steps with rc != 1.  Optional logs
- * (NULL to skip): xlog[T][nx][ldx] = state each filter call saw, ulog[T][nu][ldx] = input applied after it,
- * rclog[T][ldx].  Explicit filter on ASIF_HIP_MODEL_DOUBLE_INTEGRATOR only (ASIF_HIP_EUNSUPPORTED otherwise). */
+ * if the first call fails) / out (last applied), relax[nrelax][ldx] in/out, nfail[B] = steps with rc < 0.  Optional
+ * logs (NULL to skip): xlog[T][nx][ldx] = state each filter call saw, ulog[T][nu][ldx] = input applied after it,
+ * rclog[T][ldx].
+ * ASIF on ASIF_HIP_MODEL_DOUBLE_INTEGRATOR: one fused kernel for the whole rollout.  ASIFimplicit / ASIFimplicitRB /
+ * ASIFimplicitTB handles (examples/InvertedPendulum_Implicit.cpp:113-136 and the like): T x (rows kernel, QP kernel,
+ * plant-step kernel) queued on `stream` with no host round trip; a failed call applies what filter() wrote to uAct
+ * (the saturated backup controller), as those examples do.  Other handles: ASIF_HIP_EUNSUPPORTED. */
 int asif_hip_rollout_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, int32_t T, double dt, double *x,
                            const double *udes, double *uact, double *relax, int32_t *nfail, double *xlog,
                            double *ulog, int32_t *rclog, void *stream);
