@@ -29,22 +29,23 @@ struct BackupLoop {
 		const double uc = (u - middle) * o.twoOverRange;
 		const double xc = o.bevelStop;
 		const double yc = 1 - r;
-		uSat = u;
-		DuSat = 1;
-		if (uc >= o.bevelStop) {
-			uSat = ma;
-			DuSat = 0;
-		} else if (uc <= -o.bevelStop) {
-			uSat = mi;
-			DuSat = 0;
-		} else if (uc > o.bevelStart) {
-			const double s = sqrt(r * r - (uc - xc) * (uc - xc));
-			DuSat = (xc - uc) / s;
-			uSat = 0.5 * (s + yc) * range + middle;
-		} else if (uc < -o.bevelStart) {
-			const double s = sqrt(r * r - (uc + xc) * (uc + xc));
-			DuSat = (xc + uc) / s;
-			uSat = 0.5 * (-s - yc) * range + middle;
+		// four regions: linear, clamped high / low (selects), and the two bevels (sqrt + divide).  The bevels are
+		// a narrow band of u; they sit behind ONE wave-level branch so that the common step pays a compare and a
+		// not-taken scalar branch instead of four nested exec-mask sequences.
+		const bool hi = uc >= o.bevelStop, lo = uc <= -o.bevelStop;
+		uSat = hi ? ma : (lo ? mi : u);
+		DuSat = (hi || lo) ? 0.0 : 1.0;
+		const bool bevelUp = !hi && uc > o.bevelStart, bevelDn = !lo && uc < -o.bevelStart;
+		if (__any(bevelUp || bevelDn)) {
+			if (bevelUp) {
+				const double s = sqrt(r * r - (uc - xc) * (uc - xc));
+				DuSat = (xc - uc) / s;
+				uSat = 0.5 * (s + yc) * range + middle;
+			} else if (bevelDn) {
+				const double s = sqrt(r * r - (uc + xc) * (uc + xc));
+				DuSat = (xc + uc) / s;
+				uSat = 0.5 * (-s - yc) * range + middle;
+			}
 		}
 	}
 
@@ -73,12 +74,24 @@ struct BackupLoop {
 		}
 		saturateSoft(o, us, uSat, DuSat);
 		M::dynamicsAndGradients(o, x, f, g, Df, Dg);
+		if constexpr (M::kInputOnLastState) {
+			// g = e_last, Dg = 0: the general expression below with its constant factors folded by hand
+			// (the compiler may not fold x*0 or 0+x for doubles)
 #pragma unroll
-		for (int i = 0; i < NX; i++) {
+			for (int i = 0; i < NX; i++) {
 #pragma unroll
-			for (int j = 0; j < NX; j++)
-				DfCL[i + j * NX] = Df[i + j * NX] + (Dg[i + j * NX] * uSat + g[i] * DuSat * Du[j]);
-			fCL[i] = g[i] * uSat + f[i];
+				for (int j = 0; j < NX; j++)
+					DfCL[i + j * NX] = (i == NX - 1) ? Df[i + j * NX] + DuSat * Du[j] : Df[i + j * NX];
+				fCL[i] = (i == NX - 1) ? uSat + f[i] : f[i];
+			}
+		} else {
+#pragma unroll
+			for (int i = 0; i < NX; i++) {
+#pragma unroll
+				for (int j = 0; j < NX; j++)
+					DfCL[i + j * NX] = Df[i + j * NX] + (Dg[i + j * NX] * uSat + g[i] * DuSat * Du[j]);
+				fCL[i] = g[i] * uSat + f[i];
+			}
 		}
 	}
 
