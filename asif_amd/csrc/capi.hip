@@ -26,6 +26,8 @@ struct asif_hip_ctx {
 	int64_t s_cap;
 	int32_t *s_code;
 	int64_t s_code_cap;
+	double *s_ckpt; // block checkpoints of the implicit rows kernel
+	int64_t s_ckpt_cap;
 	// realizable filter: kernel polytope + device-built tables (nullptr for the other variants)
 	struct Realizable {
 		asif_hip_realizable_options opts;
@@ -324,6 +326,8 @@ extern "C" int asif_hip_create(asif_hip_ctx **out, int model, int variant, const
 	c->s_cap = 0;
 	c->s_code = nullptr;
 	c->s_code_cap = 0;
+	c->s_ckpt = nullptr;
+	c->s_ckpt_cap = 0;
 	c->rz = nullptr;
 	c->rb = nullptr;
 	c->d_learn = nullptr;
@@ -732,6 +736,10 @@ extern "C" int asif_hip_destroy(asif_hip_ctx *ctx)
 		(void)hipSetDevice(ctx->device);
 		(void)hipFree(ctx->s_code);
 	}
+	if (ctx->s_ckpt) {
+		(void)hipSetDevice(ctx->device);
+		(void)hipFree(ctx->s_ckpt);
+	}
 	if (ctx->d_in) {
 		(void)hipSetDevice(ctx->device);
 		(void)hipFree(ctx->d_in);
@@ -790,6 +798,26 @@ static int stage_rows(asif_hip_ctx *ctx, FilterArgs &a)
 	return 0;
 }
 
+// The implicit rows kernel parks one state per block of kTrajBlock trajectory samples in HBM (pass 1) and
+// re-integrates the few blocks that hold the critical samples (pass 2); sized per handle, grown on demand.
+static int stage_ckpt(asif_hip_ctx *ctx, FilterArgs &a)
+{
+	const int mb = ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM ? InvertedPendulum::kTrajBlock
+	                                                              : DoubleIntegratorImplicit::kTrajBlock;
+	const int64_t nblk = (ctx->dims.npBT + mb - 1) / mb;
+	const int64_t need = nblk * (ctx->dims.nx + ctx->dims.nx * ctx->dims.nx + 2) * a.ld;
+	if (need > ctx->s_ckpt_cap) {
+		if (ctx->s_ckpt) (void)hipFree(ctx->s_ckpt);
+		ctx->s_ckpt = nullptr;
+		ctx->s_ckpt_cap = 0;
+		hipError_t e = hipMalloc((void **)&ctx->s_ckpt, sizeof(double) * need);
+		if (e != hipSuccess) return (int)e;
+		ctx->s_ckpt_cap = need;
+	}
+	a.ckpt = ctx->s_ckpt;
+	return 0;
+}
+
 static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipStream_t stream)
 {
 	if (ctx->variant == ASIF_HIP_REALIZABLE)
@@ -810,6 +838,7 @@ static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipSt
 			int r = stage_rows(ctx, a);
 			if (r) return r;
 		}
+		if (int r = stage_ckpt(ctx, a)) return r;
 		if (ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM)
 			return launch_implicit_ip(dev, ctx->solver, a, assemble_only, stream, true);
 		if (ctx->model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT)
@@ -821,6 +850,7 @@ static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipSt
 			int r = stage_rows(ctx, a);
 			if (r) return r;
 		}
+		if (int r = stage_ckpt(ctx, a)) return r;
 		return launch_implicit_ip(ctx->dev, ctx->solver, a, assemble_only, stream);
 	}
 	if (ctx->model == ASIF_HIP_MODEL_SEGWAY && ctx->variant == ASIF_HIP_IMPLICIT_TB) {
@@ -835,6 +865,7 @@ static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipSt
 			int r = stage_rows(ctx, a);
 			if (r) return r;
 		}
+		if (int r = stage_ckpt(ctx, a)) return r;
 		return launch_implicit_di(ctx->dev, ctx->solver, a, assemble_only, stream);
 	}
 	if (ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM_TB && ctx->variant == ASIF_HIP_IMPLICIT_TB) {

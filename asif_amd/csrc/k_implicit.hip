@@ -83,12 +83,24 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 		z[k] = x0[k];
 		z[NX + k * (NX + 1)] = 1.0; // Q(0) = I, :417-425
 	}
-	TopK<K> top;
-	top.init();
-	typename BackupLoop<M>::Hold hold = {0.0, 0.0};
+	// ---- pass 1: the whole trajectory, nothing kept per sample.  Per block of MB consecutive samples: the state at
+	// its first sample goes to HBM (a.ckpt, [block][CK][ld], coalesced), the smallest margin of the block feeds a
+	// running selection of the K blocks with the smallest minima (ties -> earlier block).  Every one of the K
+	// most critical SAMPLES (value, then index) lies in one of those K blocks: a block outside them is preceded
+	// by K blocks whose first minimum is a distinct sample ordered before every sample of it.
+	// The per-sample selection network this replaces ran on nearly every step (some lane of the wave inserts)
+	// and cost 35 % of the kernel.
+	constexpr int MB = M::kTrajBlock, CK = NZ + 2;
+	typedef typename BackupLoop<M>::Hold Hold;
+	TopK<K> topB;
+	topB.init();
+	Hold hold = {0.0, 0.0};
 	double zDbg[NZ]; // the sample feeding the networks when n_debug selects one (:590-605)
 #pragma unroll
 	for (int k = 0; k < NZ; k++) zDbg[k] = z[k];
+	double bmin = __builtin_huge_val();
+	double *ck = a.ckpt + i;
+	const int64_t ldc = a.ld;
 #pragma unroll 1
 	for (int s = 0; s < o.npBT; s++) {
 		if (s > 0) BackupLoop<M>::template eulerStepT<RB>(o, z, hold, (double)(unsigned)s * o.trajDt);
@@ -96,20 +108,70 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 #pragma unroll
 			for (int k = 0; k < NZ; k++) zDbg[k] = z[k];
 		}
+		if (s % MB == 0) { // wave-uniform
+			const int blk = s / MB;
+			if (s > 0) {
+				if (__any(bmin < topB.key[K - 1])) topB.insert(bmin, blk - 1);
+				bmin = __builtin_huge_val();
+			}
+			double *c = ck + (int64_t)blk * CK * ldc;
+#pragma unroll
+			for (int k = 0; k < NZ; k++) c[k * ldc] = z[k];
+			c[NZ * ldc] = hold.u;
+			c[(NZ + 1) * ldc] = hold.tLast;
+		}
 		double xs[NX];
 #pragma unroll
 		for (int k = 0; k < NX; k++) xs[k] = z[k];
-		// insertions are rare after the first K samples: keep them behind a wave-uniform branch so the
-		// K-entry shift network is not if-converted into every step
-		const double hm = M::safetyMin(o, xs);
-		if (__any(hm < top.key[K - 1])) {
-			const int slot = top.insert(hm, s);
-			if (slot >= 0) {
+		bmin = fmin(bmin, M::safetyMin(o, xs));
+	}
+	if (__any(bmin < topB.key[K - 1])) topB.insert(bmin, (o.npBT - 1) / MB);
+	double zEnd[NZ];
 #pragma unroll
-				for (int k = 0; k < NZ; k++) pay[(slot * NZ + k) * 64 + lane] = z[k];
+	for (int k = 0; k < NZ; k++) zEnd[k] = z[k];
+
+	// ---- pass 2: re-integrate the selected blocks from their checkpoints, in increasing block order so that
+	// samples arrive in increasing index (the selection's tie rule: earlier sample first), and run the exact
+	// per-sample selection with the states parked in LDS -- at most K*MB of the npBT steps.
+	TopK<K> top;
+	top.init();
+	int cur = -1;
+#pragma unroll 1
+	for (int j = 0; j < K; j++) {
+		int nb = 0x7fffffff;
+#pragma unroll
+		for (int p = 0; p < K; p++) {
+			const int v = topB.idx[p];
+			nb = (v > cur && v < nb) ? v : nb;
+		}
+		const bool have = nb != 0x7fffffff;
+		if (!__any(have)) break;
+		cur = have ? nb : cur;
+		const int blk = have ? nb : 0;
+		const double *c = ck + (int64_t)blk * CK * ldc;
+#pragma unroll
+		for (int k = 0; k < NZ; k++) z[k] = c[k * ldc];
+		hold.u = c[NZ * ldc];
+		hold.tLast = c[(NZ + 1) * ldc];
+#pragma unroll 1
+		for (int t = 0; t < MB; t++) {
+			const int s = blk * MB + t;
+			if (t > 0) BackupLoop<M>::template eulerStepT<RB>(o, z, hold, (double)(unsigned)s * o.trajDt);
+			double xs[NX];
+#pragma unroll
+			for (int k = 0; k < NX; k++) xs[k] = z[k];
+			const double hm = (have && s < o.npBT) ? M::safetyMin(o, xs) : __builtin_huge_val();
+			if (__any(hm < top.key[K - 1])) {
+				const int slot = top.insert(hm, s);
+				if (slot >= 0) {
+#pragma unroll
+					for (int k = 0; k < NZ; k++) pay[(slot * NZ + k) * 64 + lane] = z[k];
+				}
 			}
 		}
 	}
+#pragma unroll
+	for (int k = 0; k < NZ; k++) z[k] = zEnd[k];
 	if (!live) return;
 	const int64_t ld = a.ld;
 	double dhIndex[NX], Lf00 = 0.0, Lg00 = 0.0; // Dh_index_[0..nx), Lfh[0], Lgh[0]

@@ -17,6 +17,8 @@ struct FilterArgs {
 	// assemble-only mode: rows out, no solve
 	double *A, *b;
 	int32_t *code;
+	// implicit / implicit-RB: block checkpoints of the backup trajectory, [ceil(npBT / kTrajBlock)][nx + nx*nx + 2][ld]
+	double *ckpt;
 };
 
 // explicit CBF filter (class ASIF), model = DoubleIntegrator
