@@ -35,11 +35,13 @@ def run(**kw):
     torch.cuda.synchronize()
     ms = C.c_float(); hip.hipEventElapsedTime(C.byref(ms), ev[0], ev[1])
     return ms.value / n * 1e3
-for name, kw in [("default", {}), ("presolve (assembly+clip)", dict(presolve=1)), ("max_iter 0 (assembly+scale+factor)", dict(max_iter=0)),
-                 ("scaling 0, max_iter 0", dict(max_iter=0, scaling_iters=0)),
-                 ("polish 0, max_iter 2 (2 its + residual check)", dict(polish=0, max_iter=2)),
-                 ("rounds 0, max_iter 2 (one finish pass)", dict(active_set_rounds=0, max_iter=2)),
+for name, kw in [("default (finish-first)", {}), ("presolve (assembly+clip)", dict(presolve=1)),
+                 ("max_iter 0 (assembly+scale+factor, no finish)", dict(max_iter=0)),
+                 ("max_iter 0, no scaling", dict(max_iter=0, scaling_iters=-1)),
+                 ("no scaling", dict(scaling_iters=-1)),
+                 ("rounds 1", dict(active_set_rounds=1, max_iter=2)), ("rounds 2", dict(active_set_rounds=2, max_iter=2)),
+                 ("rounds 3", dict(active_set_rounds=3, max_iter=2)), ("rounds 4", dict(active_set_rounds=4, max_iter=2)),
+                 ("rounds 6", dict(active_set_rounds=6, max_iter=2)),
                  ("refine 1", dict(refine_steps=1)), ("refine 0", dict(refine_steps=0, max_iter=2)),
-                 ("scaling 1", dict(scaling_iters=1)), ("adaptive_rho 0", dict(adaptive_rho=0)),
-                 ("check_interval 1", dict(check_interval=1))]:
+                 ("polish 1", dict(polish=1))]:
     print(f"{name:48s} {run(**kw):7.2f} us")
