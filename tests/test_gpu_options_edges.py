@@ -141,3 +141,36 @@ def test_argument_validation(hip):
     t = torch.zeros((2, 4), dtype=torch.float64, device=dev)
     with pytest.raises(hip.AsifHipError):
         bad.filter(t, t[:1], t[:1].clone(), t[:1].clone(), torch.zeros(4, dtype=torch.int32, device=dev))
+
+
+@pytest.mark.parametrize("cfg,B", [(2, 300000), (2, 1000), (5, 270001), (9, 5000)])
+def test_host_buffer_entry_equals_device_entry(hip, cfg, B):
+    """asif_hip_filter_batch_host (H2D, kernels, D2H; large batches of the single-kernel filters in chunks on two
+    streams) must give bit for bit what asif_hip_filter_batch gives on resident buffers, untouched slots included."""
+    import ctypes as C
+    import torch
+    from asif_amd import workloads
+    model, variant, _ = hip.CONFIGS[cfg]
+    flt = hip.Filter(model, variant)
+    d = flt.dims
+    x, u = workloads.make_batch(cfg, B)
+    dev = torch.device("cuda:0")
+    tx, tu = torch.from_numpy(x).to(dev), torch.from_numpy(u).to(dev)
+    uact = torch.full((d.nu, B), 7.0, dtype=torch.float64, device=dev)
+    relax = torch.full((d.nrelax, B), -7.0, dtype=torch.float64, device=dev)
+    rc = torch.zeros(B, dtype=torch.int32, device=dev)
+    flt.filter(tx, tu, uact, relax, rc)
+    torch.cuda.synchronize()
+    for pinned in (False, True):
+        hx, hu = torch.from_numpy(x.copy()), torch.from_numpy(u.copy())
+        hua = torch.full((d.nu, B), 7.0, dtype=torch.float64)
+        hrl = torch.full((d.nrelax, B), -7.0, dtype=torch.float64)
+        hrc = torch.zeros(B, dtype=torch.int32)
+        bufs = [hx, hu, hua, hrl, hrc]
+        if pinned:
+            bufs = [t.pin_memory() for t in bufs]
+        hip.check(flt.lib.asif_hip_filter_batch_host(flt.handle, B, *[C.c_void_p(t.data_ptr()) for t in bufs]))
+        assert np.array_equal(bufs[4].numpy(), rc.cpu().numpy())
+        assert np.array_equal(bufs[2].numpy(), uact.cpu().numpy())
+        assert np.array_equal(bufs[3].numpy(), relax.cpu().numpy())
+    flt.close()
