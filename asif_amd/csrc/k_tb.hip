@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o, FilterArgs a)
 					for (int k = 0; k < NZ; k++) pay[(slot * NZ + k) * 64 + lane] = z[k];
 				}
 			}
-			if (M::backupSetValue(o, xs) >= 0.0) {
+			if (M::backupSetInside(o, xs)) {
 				hit = true;
 				done = true;
 				idxHit = s;

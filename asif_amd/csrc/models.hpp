@@ -319,6 +319,7 @@ struct InvertedPendulumTB {
 		DDh[0] = 0.; DDh[1] = 0.; DDh[2] = 0.; DDh[3] = 0.;
 	}
 	__device__ static double backupSetValue(const DevOptions &, const double (&x)[NX]) { return x[0] - kPi / 2. + 0.1; }
+	__device__ static bool backupSetInside(const DevOptions &o, const double (&x)[NX]) { return backupSetValue(o, x) >= 0.0; }
 	// :76-85  u = K (vDes - omega)
 	__device__ static void backupController(const DevOptions &, const double (&x)[NX], double (&u)[NU], double (&Du)[NU * NX])
 	{
@@ -391,6 +392,31 @@ struct Segway {
 			v -= q * q;
 		}
 		return v;
+	}
+	// sign test of the value above, once per trajectory sample (the hit test, src/asif_implicit_tb.cpp:505-528).
+	// Screened: the same sum with reciprocal multiplies (four FP64 divisions less on the dependent chain of the
+	// loop) decides whenever it is further from zero than its own rounding can reach; the rare lane that is not
+	// gets the exact expression behind one wave-level branch, so the decision is always the exact one.
+	__device__ static bool backupSetInside(const DevOptions &o, const double (&x)[NX])
+	{
+		double v = 0.05 * 0.05, mag = 0.05 * 0.05;
+#pragma unroll
+		for (int i = 0; i < NX; i++) {
+			const double q = x[i] * (1.0 / xb(i)); // 1/xb folds to a constant
+			v -= q * q;
+			mag += q * q;
+		}
+		bool in = v >= 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+		const bool close = !(fabs(v) > 1e-13 * mag);
+		if (__any(close)) {
+			if (close) in = backupSetValue(o, x) >= 0.0;
+		}
+#else
+		(void)mag;
+		in = backupSetValue(o, x) >= 0.0;
+#endif
+		return in;
 	}
 	// :56-68  u = K (x + x_eq)
 	__device__ static void backupController(const DevOptions &, const double (&x)[NX], double (&u)[NU], double (&Du)[NU * NX])
@@ -478,11 +504,15 @@ struct Segway {
 		                   8.3593271361634187;
 #pragma unroll
 		for (int i = 0; i < NX * NU * NX; i++) Dg[i] = 0.0;
-		Dg[9] = -(c1 * 0.1118494602519098 - s1 * 0.80343863413287053) / d26 +
-		        1.0 / (d26 * d26) * (c2 * 0.59146430898882 - c1 * s1 * 4.1662750547697547) *
+		// the example divides by d26, d26^2, d4 and d4^2 (:205-210); d4 is t23's denominator, so one reciprocal of
+		// d26 and t23 serve all four (each quotient within an ulp of the divided form; the rows are compared at 1e-9)
+		(void)d4;
+		const double r26 = 1.0 / d26;
+		Dg[9] = -(c1 * 0.1118494602519098 - s1 * 0.80343863413287053) * r26 +
+		        (r26 * r26) * (c2 * 0.59146430898882 - c1 * s1 * 4.1662750547697547) *
 		            ((c1 * 0.80343863413287053 + s1 * 0.1118494602519098) + 2.2990706749044238);
-		Dg[11] = (c1 * 1.1471739513016379 - s1 * 8.24039624751662) / d4 -
-		         1.0 / (d4 * d4) * (c2 * 1.18292861797764 - s2 * 4.1662750547697547) *
+		Dg[11] = (c1 * 1.1471739513016379 - s1 * 8.24039624751662) * t23 -
+		         (t23 * t23) * (c2 * 1.18292861797764 - s2 * 4.1662750547697547) *
 		             ((c1 * 8.24039624751662 + s1 * 1.1471739513016379) + 11.33189235811229);
 	}
 };
