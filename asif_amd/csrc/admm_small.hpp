@@ -647,7 +647,9 @@ struct AdmmSmall {
 		iters = 0;
 		stat_rounds = 0;
 		stat_farkas = 0;
-		bool fact_ok = set_rho_and_factor(S_.rho, S_.sigma);
+		// the KKT factor of the iterations is formed when the first iteration is due: a wave whose every lane is
+		// decided by the finish-first attempt never needs it
+		bool fact_ok = true, factored = false;
 		const double cinv = pow2_inv(cs);
 		int it = 0;
 		double penalty = 1.0 / kPolishDelta; // of the finish's working-set solves; per problem, see finish()
@@ -659,6 +661,10 @@ struct AdmmSmall {
 		while (it < S_.max_iter) {
 			if (__all(status != 0)) break; // wave-uniform: every lane has latched its result
 			if (!pre) {
+				if (!factored) {
+					fact_ok = set_rho_and_factor(S_.rho, S_.sigma);
+					factored = true;
+				}
 #pragma unroll 1
 				for (int k = 0; k < K; k++) iterate(S_.sigma, S_.alpha);
 				it += K;
