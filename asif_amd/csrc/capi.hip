@@ -802,8 +802,14 @@ static int stage_rows(asif_hip_ctx *ctx, FilterArgs &a)
 // re-integrates the few blocks that hold the critical samples (pass 2); sized per handle, grown on demand.
 static int stage_ckpt(asif_hip_ctx *ctx, FilterArgs &a)
 {
-	const int mb = ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM ? InvertedPendulum::kTrajBlock
-	                                                              : DoubleIntegratorImplicit::kTrajBlock;
+	int mb;
+	switch (ctx->model) {
+	case ASIF_HIP_MODEL_INVERTED_PENDULUM: mb = InvertedPendulum::kTrajBlock; break;
+	case ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT: mb = DoubleIntegratorImplicit::kTrajBlock; break;
+	case ASIF_HIP_MODEL_SEGWAY: mb = Segway::kTrajBlock; break;
+	case ASIF_HIP_MODEL_INVERTED_PENDULUM_TB: mb = InvertedPendulumTB::kTrajBlock; break;
+	default: return ASIF_HIP_EINVAL;
+	}
 	const int64_t nblk = (ctx->dims.npBT + mb - 1) / mb;
 	const int64_t need = nblk * (ctx->dims.nx + ctx->dims.nx * ctx->dims.nx + 2) * a.ld;
 	if (need > ctx->s_ckpt_cap) {
@@ -858,6 +864,7 @@ static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipSt
 			int r = stage_rows(ctx, a);
 			if (r) return r;
 		}
+		if (int r = stage_ckpt(ctx, a)) return r;
 		return launch_tb_segway(ctx->dev, ctx->solver, a, assemble_only, stream);
 	}
 	if (ctx->model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT && ctx->variant == ASIF_HIP_IMPLICIT) {
@@ -873,6 +880,7 @@ static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipSt
 			int r = stage_rows(ctx, a);
 			if (r) return r;
 		}
+		if (int r = stage_ckpt(ctx, a)) return r;
 		return launch_tb_pendulum(ctx->dev, ctx->solver, a, assemble_only, stream);
 	}
 	if (ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST && ctx->variant == ASIF_HIP_ROBUST)

@@ -43,15 +43,20 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o, FilterArgs a)
 		z[k] = x0[k];
 		z[NX + k * (NX + 1)] = 1.0;
 	}
-	TopK<K> top;
-	top.init();
-	{
-		const int slot = top.insert(M::safetyMin(o, x0), 0);
+	// ---- pass 1: integrate to the first sample inside the backup set, nothing kept per sample.  Per block of MB
+	// samples the state at its first sample goes to HBM and the block's smallest margin feeds a running selection of
+	// the K blocks with the smallest minima (ties -> earlier block): the K most critical samples of [0, idxHit]
+	// all lie in those blocks (see k_implicit.hip).  The per-sample selection this replaces (branch, K-entry
+	// network, NZ LDS writes) ran on most steps: 10 % of the segway kernel, 24 % of the pendulum's.
+	constexpr int MB = M::kTrajBlock;
+	TopK<K> topB;
+	topB.init();
+	double *ck = a.ckpt + i;
 #pragma unroll
-		for (int k = 0; k < NZ; k++) pay[(slot * NZ + k) * 64 + lane] = z[k];
-	}
+	for (int k = 0; k < NZ; k++) ck[k * ld] = z[k]; // block 0 starts at sample 0
+	double bmin = M::safetyMin(o, x0);
 	bool done = inside || !live, hit = false;
-	int idxHit = 0;
+	int idxHit = 0, sLast = 0;
 	double t = 0.0, tHit = 0.0;
 #pragma unroll 1
 	for (int s = 1; s < o.npBT; s++) {
@@ -59,17 +64,18 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o, FilterArgs a)
 		if (!done) {
 			BackupLoop<M>::eulerStep(o, z);
 			t = t + o.trajDt; // backTraj_[i].first accumulates, :475
+			sLast = s;
+			if (s % MB == 0) { // wave-uniform: close the previous block, open the next
+				if (__any(bmin < topB.key[K - 1])) topB.insert(bmin, s / MB - 1);
+				bmin = __builtin_huge_val();
+				double *c = ck + (int64_t)(s / MB) * NZ * ld;
+#pragma unroll
+				for (int k = 0; k < NZ; k++) c[k * ld] = z[k];
+			}
 			double xs[NX];
 #pragma unroll
 			for (int k = 0; k < NX; k++) xs[k] = z[k];
-			const double hm = M::safetyMin(o, xs);
-			if (hm < top.key[K - 1]) { // rare after the first K samples
-				const int slot = top.insert(hm, s);
-				if (slot >= 0) {
-#pragma unroll
-					for (int k = 0; k < NZ; k++) pay[(slot * NZ + k) * 64 + lane] = z[k];
-				}
-			}
+			bmin = fmin(bmin, M::safetyMin(o, xs));
 			if (M::backupSetInside(o, xs)) {
 				hit = true;
 				done = true;
@@ -78,6 +84,50 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o, FilterArgs a)
 			}
 		}
 	}
+	if (__any(bmin < topB.key[K - 1])) topB.insert(bmin, sLast / MB); // every lane's last (possibly partial) block
+	double zHit[NZ]; // the rows below are written for the state at idxHit
+#pragma unroll
+	for (int k = 0; k < NZ; k++) zHit[k] = z[k];
+
+	// ---- pass 2: re-integrate the selected blocks in increasing order, exact per-sample selection with the states
+	// parked in LDS; samples beyond the lane's last one (its hit) do not take part
+	TopK<K> top;
+	top.init();
+	int cur = -1;
+#pragma unroll 1
+	for (int j = 0; j < K; j++) {
+		int nb = 0x7fffffff;
+#pragma unroll
+		for (int p = 0; p < K; p++) {
+			const int v = topB.idx[p];
+			nb = (v > cur && v < nb) ? v : nb;
+		}
+		const bool have = nb != 0x7fffffff;
+		if (!__any(have)) break;
+		cur = have ? nb : cur;
+		const int blk = have ? nb : 0;
+		const double *c = ck + (int64_t)blk * NZ * ld;
+#pragma unroll
+		for (int k = 0; k < NZ; k++) z[k] = c[k * ld];
+#pragma unroll 1
+		for (int tt = 0; tt < MB; tt++) {
+			const int s = blk * MB + tt;
+			if (tt > 0) BackupLoop<M>::eulerStep(o, z);
+			double xs[NX];
+#pragma unroll
+			for (int k = 0; k < NX; k++) xs[k] = z[k];
+			const double hm = (have && s <= sLast) ? M::safetyMin(o, xs) : __builtin_huge_val();
+			if (__any(hm < top.key[K - 1])) {
+				const int slot = top.insert(hm, s);
+				if (slot >= 0) {
+#pragma unroll
+					for (int k = 0; k < NZ; k++) pay[(slot * NZ + k) * 64 + lane] = z[k];
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < NZ; k++) z[k] = zHit[k];
 	if (!live) return;
 
 	const int code = inside ? 2 : (hit ? 1 : -3);

@@ -293,6 +293,7 @@ struct DoubleIntegratorImplicit {
 // Dynamics and their gradients are the pendulum's (:67-74, :87-94).
 struct InvertedPendulumTB {
 	static constexpr int NX = 2, NU = 1, NPSS = 4, NPBS = 1, NPBTSS = 4;
+	static constexpr int kTrajBlock = 32; // 11 551-sample trajectory, 4 critical samples (measured: 16 = 32 < 64 < 128)
 	// g = e_last and Dg = 0 for every state: lets the backup loop drop the generic formula's products with
 	// those constants (x*0, x*1, 0+x) -- same values, ~10 fewer FP64 issues per Euler step
 	static constexpr bool kInputOnLastState = true;
@@ -345,6 +346,7 @@ struct InvertedPendulumTB {
 // model and is reproduced as shipped.
 struct Segway {
 	static constexpr int NX = 4, NU = 1, NPSS = 4, NPBS = 1, NPBTSS = 4;
+	static constexpr int kTrajBlock = 4; // 316-sample trajectory, 4 critical samples (measured: 4 < 8 < 2 < 16)
 	static constexpr bool kInputOnLastState = false; // g depends on the pitch
 
 	__device__ static double xb(int i) { return i < 2 ? 3.0 : (i == 2 ? kPi / 6 : kPi); }
