@@ -263,8 +263,10 @@ def main():
     for k in range(args.steps):
         step()
     hip.hipEventRecord(ev[1], sptr)
+    torch.cuda.synchronize()  # this rank's K steps are done: stop its clock, then meet the others
+    t1 = time.perf_counter()
     grp.barrier()
-    elapsed = grp.max_over_ranks(time.perf_counter() - t0, device=dev if (grp.world > 1 and not rehearsal) else None)
+    elapsed = grp.max_over_ranks(t1 - t0, device=dev if (grp.world > 1 and not rehearsal) else None)
     ms = C.c_float()
     assert hip.hipEventElapsedTime(C.byref(ms), ev[0], ev[1]) == 0
     for e in ev:
