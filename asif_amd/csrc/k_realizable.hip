@@ -174,11 +174,21 @@ __device__ __forceinline__ void fold_row(double a, double c, double &lo, double 
 }
 
 // KB = barrier rows carried in registers (>= npSSmax) = rows of the in-register QP
-template <int KB>
+// LDSREC: the seven scan fields of every facet record are staged in LDS (64 B per facet) by the block's wave and
+// read back with wave-uniform ds_reads, which return in order and so can be kept several records deep in flight;
+// the scalar-load form (used when the kernel polytope is too large for LDS) has to drain its whole queue at
+// every wait (SMEM returns out of order) and spent ~0.2 us of load latency per facet per launch.
+template <int KB, bool LDSREC>
 __global__ __launch_bounds__(64) void realizable_filter_kernel(RzDev z, asif_hip_solver S, FilterArgs a,
                                                                bool assemble_only)
 {
 	constexpr int NV = 2, RPL = KB;
+	extern __shared__ double srec[]; // [nF][8] when LDSREC
+	if (LDSREC) {
+		for (int k = threadIdx.x; k < z.nF * 8; k += 64)
+			srec[k] = (k & 7) < 7 ? z.facetRec[(size_t)(k >> 3) * kRzRec + (k & 7)] : 0.0;
+		__syncthreads();
+	}
 	const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int64_t i = tid;
 	const bool live = i < a.B;
@@ -201,19 +211,29 @@ __global__ __launch_bounds__(64) void realizable_filter_kernel(RzDev z, asif_hip
 #pragma clang fp contract(off)
 		const double xm0 = x0 - z.unc[0], xp0 = x0 + z.unc[0], xm1 = x1 - z.unc[1], xp1 = x1 + z.unc[1];
 		// One facet, branch-free.  `valid` is wave-uniform (false only for the padding slot of an odd facet count).
-		auto facet = [&](const double (&r)[7], const int fi, const bool valid) {
+		auto facet = [&](const double (&r)[7], const int fiu, const bool valid) {
+			// The facet index is wave-uniform (an SGPR).  Selecting it into per-lane registers as `c ? fi : old` makes
+			// the compiler emit an exec-mask sequence per select (v_cmp -> s_and_saveexec -> masked v_mov from the
+			// SGPR): three of them per facet, ~0.15 us per facet per launch in this one-wave-per-SIMD loop.  A copy
+			// in a VGPR turns them into plain v_cndmask.
+			int fi;
+			asm("v_mov_b32 %0, %1" : "=v"(fi) : "s"(fiu));
 			double h = 1.;
 			h -= r[5] * x0;
 			h -= r[6] * x1;
 			h = valid ? h : __builtin_huge_val();
 			anyNeg = anyNeg | (h < 0.);
 			if constexpr (KB == 2) {
-				// two smallest, strict < keeps the lower facet index on ties
-				const bool c1 = h < hmin[0], c2 = h < hmin[1];
-				hidx[1] = c1 ? hidx[0] : (c2 ? fi : hidx[1]);
+				// two smallest, strict < keeps the lower facet index on ties: one compare-exchange against each slot,
+				// written as independent selects (a nested ?: here compiles to exec-mask branches)
+				const bool c1 = h < hmin[0];
+				const int hiI = c1 ? hidx[0] : fi;     // index travelling on to slot 1
+				const double hiH = fmax(hmin[0], h);     // its margin
 				hidx[0] = c1 ? fi : hidx[0];
-				hmin[1] = fmin(hmin[1], fmax(hmin[0], h));
 				hmin[0] = fmin(hmin[0], h);
+				const bool c2 = hiH < hmin[1];
+				hidx[1] = c2 ? hiI : hidx[1];
+				hmin[1] = fmin(hmin[1], hiH);
 			} else {
 				double hv = h;
 				int hi_ = fi;
@@ -252,14 +272,15 @@ __global__ __launch_bounds__(64) void realizable_filter_kernel(RzDev z, asif_hip
 #pragma unroll
 			for (int u = 0; u < 4; u++)
 #pragma unroll
-				for (int k = 0; k < 7; k++) r[u][k] = z.facetRec[(size_t)(fi + u) * kRzRec + k];
+				for (int k = 0; k < 7; k++)
+					r[u][k] = LDSREC ? srec[(fi + u) * 8 + k] : z.facetRec[(size_t)(fi + u) * kRzRec + k];
 #pragma unroll
 			for (int u = 0; u < 4; u++) facet(r[u], fi + u, true);
 		}
 		for (int fi = nF4; fi < z.nF; fi++) {
 			double r[7];
 #pragma unroll
-			for (int k = 0; k < 7; k++) r[k] = z.facetRec[(size_t)fi * kRzRec + k];
+			for (int k = 0; k < 7; k++) r[k] = LDSREC ? srec[fi * 8 + k] : z.facetRec[(size_t)fi * kRzRec + k];
 			facet(r, fi, true);
 		}
 	}
@@ -417,8 +438,15 @@ int launch_realizable(const RzDev &z, const asif_hip_solver &S0, const FilterArg
 	const asif_hip_solver S = resolve_scaling(S0, 2);
 	if (z.maxCrit > kRzMaxCrit || z.npSSmax > 4) return ASIF_HIP_EUNSUPPORTED;
 	const dim3 grid(grid_for(a.B, 1, 64)), block(64);
-	if (z.npSSmax <= 2) hipLaunchKernelGGL(realizable_filter_kernel<2>, grid, block, 0, stream, z, S, a, assemble_only);
-	else hipLaunchKernelGGL(realizable_filter_kernel<4>, grid, block, 0, stream, z, S, a, assemble_only);
+	const size_t recBytes = (size_t)z.nF * 8 * sizeof(double);
+	const bool lds = recBytes <= 48 * 1024;
+	if (z.npSSmax <= 2) {
+		if (lds) hipLaunchKernelGGL((realizable_filter_kernel<2, true>), grid, block, recBytes, stream, z, S, a, assemble_only);
+		else hipLaunchKernelGGL((realizable_filter_kernel<2, false>), grid, block, 0, stream, z, S, a, assemble_only);
+	} else {
+		if (lds) hipLaunchKernelGGL((realizable_filter_kernel<4, true>), grid, block, recBytes, stream, z, S, a, assemble_only);
+		else hipLaunchKernelGGL((realizable_filter_kernel<4, false>), grid, block, 0, stream, z, S, a, assemble_only);
+	}
 	return (int)hipGetLastError();
 }
 
