@@ -173,3 +173,27 @@ def test_plain_implicit_class_with_its_learned_residual(hip, oracle):
     ua, rl, rc = oracle.filter_batch(oracle.MODEL_IP, oracle.VAR_IMPLICIT, oo, np.ascontiguousarray(f["x"].T),
                                      np.ascontiguousarray(f["udes"].T), uact_init=np.full((B, 1), 7.0), nthreads=8)
     assert np.array_equal(f["rc"], rc) and np.abs(f["uact"][0] - ua[:, 0]).max() <= 1e-6
+
+
+def test_update_options_equals_fresh_handle(hip, oracle):
+    """updateOptions(options) (src/asif_implicit_robust.cpp:436-477) on a live handle: same rows as a handle created
+    with those options; the uploaded networks survive the update."""
+    import torch
+    B = 512
+    w = workloads.make_learning()
+    od, _, _ = _both_options(hip, oracle, 1, oracle.MODEL_IP)
+    flt = hip.Filter(1, RB, options=od)
+    flt.set_learning(w)
+    od2, _, _ = _both_options(hip, oracle, 1, oracle.MODEL_IP, x_unc=(0.05, 0.0), backContDt=0.004, relaxCost=20.0)
+    flt.update_options(od2)
+    x, _ = workloads.make_batch(CFG, B)
+    dev = torch.device("cuda:0")
+    d = flt.dims
+    A = torch.zeros((d.nc * d.nv, B), dtype=torch.float64, device=dev)
+    b = torch.zeros((d.nc, B), dtype=torch.float64, device=dev)
+    code = torch.zeros(B, dtype=torch.int32, device=dev)
+    flt.assemble(torch.from_numpy(x).to(dev), A, b, code)
+    torch.cuda.synchronize()
+    fresh = gpu_util.run_assemble(CFG, B, options=od2, learning=w, x=x)
+    assert np.array_equal(A.cpu().numpy(), fresh["A"]) and np.array_equal(b.cpu().numpy(), fresh["b"])
+    flt.close()
