@@ -209,3 +209,40 @@ def test_critical_sample_selection_on_plateaus_and_ties(hip, oracle):
         A, b, _, _ = oracle.assemble_batch(oracle.MODEL_IP, oracle.VAR_IMPLICIT, oo, np.ascontiguousarray(xs.T))
         np.testing.assert_allclose(out["A"].T, A, rtol=1e-9, atol=1e-11)
         np.testing.assert_allclose(out["b"].T, b, rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("cfg,B", [(2, 4096), (3, 256), (4, 1024), (5, 512)])
+def test_filter_call_is_graph_capturable(hip, cfg, B):
+    """Once a first call has sized the handle's staging buffers, a filter call only enqueues kernels on the
+    caller's stream: it can be captured into a HIP graph and replayed (streams and graphs instead of a
+    tracing compiler).  The replay on new inputs must equal a direct call bit for bit."""
+    from asif_amd import workloads
+    model, variant, _ = hip.CONFIGS[cfg]
+    flt = hip.Filter(model, variant)
+    d = flt.dims
+    dev = torch.device("cuda:0")
+    x, u = workloads.make_batch(cfg, B)
+    x2, u2 = workloads.make_batch(cfg, B, first=B)
+    tx, tu = torch.from_numpy(x).to(dev), torch.from_numpy(u).to(dev)
+    uact = torch.zeros((d.nu, B), dtype=torch.float64, device=dev)
+    relax = torch.zeros((d.nrelax, B), dtype=torch.float64, device=dev)
+    rc = torch.zeros(B, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        flt.filter(tx, tu, uact, relax, rc)  # sizes the staging buffers
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        flt.filter(tx, tu, uact, relax, rc)
+    tx.copy_(torch.from_numpy(x2))
+    tu.copy_(torch.from_numpy(u2))
+    uact.zero_()
+    relax.zero_()
+    rc.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    got = (uact.cpu().numpy().copy(), relax.cpu().numpy().copy(), rc.cpu().numpy().copy())
+    ref = gpu_util.run_filter(cfg, B, x=x2, udes=u2)
+    assert np.array_equal(got[2], ref["rc"]) and np.array_equal(got[0], ref["uact"]) and np.array_equal(got[1], ref["relax"])
+    flt.close()
