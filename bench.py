@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--presolve", type=int, default=0,
                     help="asif_hip_solver.presolve (config 2: closed-form clip instead of the in-kernel ADMM; default 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
     args = ap.parse_args()
 
     # ASIF_BENCH_REHEARSAL=1: rehearse the N>1 code path on a one-GPU box (gloo rendezvous, every rank
@@ -332,7 +333,7 @@ def main():
         out["parity"] = parity
     elif grp.rank == 0:
         out["cpu_baseline"] = None
-    if grp.rank == 0 and grp.world == 1:
+    if grp.rank == 0 and grp.world == 1 and not args.no_pcie:
         out["pcie_inclusive"] = pcie_inclusive(flt, x, udes, rc_host, uact)
     if grp.rank == 0:
         print(json.dumps(out))
