@@ -26,16 +26,23 @@ private:
 class AAF {
 public:
 	static constexpr int kCap = 48;
-	AAF(double v0 = 0) : c_(v0), n_(0), overflow_(false) {}
-	AAF(interval iv) : c_((iv.right() + iv.left()) / 2), n_(1), overflow_(false)
+	AAF(double v0 = 0) : c_(v0), n_(0), overflow_(false), special_(kAffine) {}
+	AAF(interval iv) : c_((iv.right() + iv.left()) / 2), n_(1), overflow_(false), special_(kAffine)
 	{
 		idx_[0] = ++last();
 		v_[0] = (iv.right() - iv.left()) / 2;
+		if (iv.right() - iv.left() == HUGE_VAL) { // aa_aafcommon.cpp:81-100: an unbounded interval
+			c_ = 0;
+			v_[0] = HUGE_VAL;
+			special_ = kInfinite;
+		}
 	}
 	AAF(double lo, double hi) : AAF(interval(lo, hi)) {}
 
 	double get_center() const { return c_; }
 	unsigned get_length() const { return (unsigned)n_; }
+	double get_coeff(unsigned k) const { return v_[k]; }     // as libaffa's AAF::get_coeff / get_index
+	unsigned get_index(unsigned k) const { return idx_[k]; }
 	bool overflowed() const { return overflow_; }
 	double rad() const
 	{
@@ -43,9 +50,10 @@ public:
 		for (int i = 0; i < n_; i++) s += std::fabs(v_[i]);
 		return s;
 	}
-	interval convert() const
+	interval convert() const // aa_aafcommon.cpp:217-226: indeterminate forms convert to the whole line
 	{
 		const double r = rad();
+		if ((special_ & (kInfinite | kNan)) || r == HUGE_VAL) return interval(-HUGE_VAL, HUGE_VAL);
 		return interval(c_ - r, c_ + r);
 	}
 	static void set_default(unsigned v = 0) { last() = v; }
@@ -76,6 +84,8 @@ public:
 	}
 	friend AAF inv(const AAF &p)
 	{
+		if (p.special_ == kNan) return nanForm(); // aa_aafapprox.cpp:155-179
+		if (p.special_ == kInfinite) return AAF(interval(-HUGE_VAL, HUGE_VAL));
 		const interval iv = p.convert();
 		double a = iv.left(), b = iv.right();
 		if (a <= 0 && b >= 0) return AAF(interval(-HUGE_VAL, HUGE_VAL));
@@ -90,6 +100,8 @@ public:
 	friend AAF sin(const AAF &p)
 	{
 		const int NPTS = 8;
+		if (p.special_ == kNan) return nanForm(); // aa_aaftrigo.cpp:42-135
+		if (p.special_ == kInfinite) return AAF(interval(-1, 1));
 		const interval iv = p.convert();
 		const double a = iv.left(), b = iv.right(), w = b - a;
 		if (w >= 2 * (4 * std::atan(1.0))) return AAF(interval(-1, 1));
@@ -120,9 +132,24 @@ public:
 	}
 
 private:
+	enum { kAffine = 1, kInfinite = 2, kNan = 4 }; // AAF_TYPE, aa_util.h
+	static int binarySpecial(int a, int b)         // aa_util.h:31-44
+	{
+		if (a == kAffine && b == kAffine) return kAffine;
+		if (a == kNan || b == kNan) return kNan;
+		if (a == (kNan | kAffine) || b == (kNan | kAffine)) return kNan | kAffine;
+		return a | b;
+	}
+	static AAF nanForm()
+	{
+		AAF t(0.0);
+		t.special_ = kNan;
+		return t;
+	}
 	double c_;
 	int n_;
 	bool overflow_;
+	int special_;
 	unsigned idx_[kCap];
 	double v_[kCap];
 	static unsigned &last()
@@ -149,6 +176,7 @@ private:
 	{
 		AAF t(mode == 0 ? c_ + p.c_ : (mode == 1 ? c_ - p.c_ : 0.0));
 		t.overflow_ = overflow_ || p.overflow_;
+		t.special_ = binarySpecial(special_, p.special_);
 		int ia = 0, ib = 0;
 		while (ia < n_ || ib < p.n_) {
 			if (t.n_ >= kCap) { t.overflow_ = true; break; }
