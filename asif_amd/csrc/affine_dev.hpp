@@ -48,6 +48,10 @@ __device__ inline void af_interval(AfCtx &cx, Af &r, double lo, double hi)
 	r.idx[0] = ++cx.last;
 	r.c = (hi + lo) / 2;
 	r.v[0] = (hi - lo) / 2;
+	if (hi - lo == __builtin_huge_val()) { // unbounded interval (inv of a form straddling zero), aa_aafcommon.cpp:81-100
+		r.c = 0;
+		r.v[0] = __builtin_huge_val();
+	}
 }
 
 __device__ inline double af_rad(const Af &a)
@@ -62,6 +66,10 @@ __device__ inline void af_convert(const Af &a, double &lo, double &hi)
 	const double r = af_rad(a);
 	lo = a.c - r;
 	hi = a.c + r;
+	if (r == __builtin_huge_val()) { // indeterminate form: the whole line, aa_aafcommon.cpp:217-226
+		lo = -__builtin_huge_val();
+		hi = __builtin_huge_val();
+	}
 }
 
 // mode 0: a+b, 1: a-b, 2: a.c*vb + b.c*va.  Returns the merged length or -1 on overflow.
