@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- QP solves/s of the batched CBF-QP filter() hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5|6] [--batch B] [--kernel 100Hz]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2..10] [--batch B] [--kernel 100Hz]
+                    [--presolve 1] [--polish 0|1|2] [--no-cpu-baseline] [--no-pcie]
 
 One "step" = one pass of the filter (constraint assembly + in-kernel ADMM solve + saturation + return
 code) over one batch of synthetic states that is already resident in HBM when the timed region starts.
