@@ -39,7 +39,7 @@ EXPORTS = [
     "asif_hip_filter_batch_host", "asif_hip_default_realizable_options", "asif_hip_create_realizable",
     "asif_hip_update_realizable_options", "asif_hip_realizable_tables", "asif_hip_default_robust_data_options",
     "asif_hip_create_robust_data", "asif_hip_update_robust_data_options", "asif_hip_rollout_batch",
-    "asif_hip_set_learning",
+    "asif_hip_set_learning", "asif_hip_affine_replay",
 ]
 
 MODEL_DOUBLE_INTEGRATOR_SAMPLED = 4

@@ -66,7 +66,9 @@ __device__ inline void af_convert(const Af &a, double &lo, double &hi)
 	const double r = af_rad(a);
 	lo = a.c - r;
 	hi = a.c + r;
-	if (r == __builtin_huge_val()) { // indeterminate form: the whole line, aa_aafcommon.cpp:217-226
+	// indeterminate form (unbounded, or NaN coefficients, which only descendants of an unbounded form carry --
+	// libaffa tracks those with its AAF_TYPE flags): the whole line, aa_aafcommon.cpp:217-226
+	if (!(r < __builtin_huge_val())) {
 		lo = -__builtin_huge_val();
 		hi = __builtin_huge_val();
 	}

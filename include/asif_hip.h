@@ -46,7 +46,7 @@ extern "C" {
 #endif
 
 #define ASIF_HIP_VERSION 120 /* 110: realizable / robust-data handles, solver.presolve, scaling_iters 0 = default;
-                              * 120: ASIF_HIP_IMPLICIT_RB (options grew at the end), asif_hip_set_learning */
+                              * 120: ASIF_HIP_IMPLICIT_RB (options grew at the end), asif_hip_set_learning, asif_hip_affine_replay */
 
 enum asif_hip_error {
 	ASIF_HIP_OK = 0,
@@ -275,6 +275,19 @@ int asif_hip_rollout_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, int32_t T,
 /* Rows only: A[(nc*nv)][ldx], b[nc][ldx], code[B] (1; TB: 2 trivial rows, -3 backup set unreached). */
 int asif_hip_assemble_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, const double *x, double *A, double *b,
                             int32_t *code, double *diag, void *stream);
+
+/* Self-test of the device affine arithmetic (asif_amd/csrc/affine_dev.hpp: libaffa's AAF operations as the robust and
+ * realizable rows use them, lib/libaffa/src/aa_aaf*.cpp).  Runs a register program in one lane and returns, per
+ * register, centre, symbol count, convert() bounds and the (index, coefficient) pairs ([nreg][16]).  HOST pointers.
+ * op: 0 const(imm0), 1 interval(imm0, imm1), 2 a+b, 3 a-b, 4 a*b, 5 a/b, 6 inv(a), 7 -a, 8 a*imm0, 9 sin(a), 10 copy a
+ * -- the codes of oracle/ref_affa_shim.cpp, so the golden programs of tests/golden/affa_programs.json replay as they
+ * are.  nreg <= 16; a form that would need more than 16 noise symbols returns ASIF_HIP_EUNSUPPORTED. */
+typedef struct asif_hip_affine_instr {
+	int32_t op, dst, a, b;
+	double imm0, imm1;
+} asif_hip_affine_instr;
+int asif_hip_affine_replay(int device, const asif_hip_affine_instr *prog, int32_t nprog, int32_t nreg, double *center,
+                           int32_t *n, double *lo, double *hi, uint32_t *idx, double *coef);
 
 /* B pre-assembled QPs of one shape.  Hd[nv][ld] (diagonal of H), c[nv][ld], A[(nc*nv)][ld], b[nc][ld],
  * lb[nv][ld], ub[nv][ld]; be: HOST array of nc flags shared by the batch (NULL = none);
