@@ -102,7 +102,8 @@ class Solver(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("rho", "sigma", "alpha", "eps_abs", "eps_rel", "eps_prim_inf",
                                           "eps_dual_inf", "adaptive_rho_tolerance")] + [
         (n, C.c_int32) for n in ("max_iter", "check_interval", "scaling_iters", "polish", "active_set_rounds",
-                                 "refine_steps", "adaptive_rho", "lanes_per_qp", "presolve", "warm_start")]
+                                 "refine_steps", "adaptive_rho", "lanes_per_qp", "presolve", "warm_start",
+                                 "adaptive_rho_interval")]
 
 
 class Dims(C.Structure):

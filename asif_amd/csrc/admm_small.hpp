@@ -22,6 +22,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "asif_hip.h"
+#include "qp_lane.hpp"
+#include "gi_small.hpp"
 
 namespace asif {
 
@@ -43,51 +45,6 @@ constexpr int kStatusDualInfInaccurate = 4;
 constexpr int kStatusMaxIter = -2;
 constexpr int kStatusPrimalInf = -3;
 constexpr int kStatusDualInf = -4;
-
-// Cross-lane exchange inside a group of G <= 16 consecutive lanes by DPP (data-parallel primitives:
-// the permutation rides on the VALU operand fetch, no LDS crossbar round trip like ds_bpermute).
-// Butterfly stage m: 1 -> quad_perm[1,0,3,2], 2 -> quad_perm[2,3,0,1]; after those two all four lanes
-// of a quad agree, so stage 4 may use row_half_mirror (i <-> 7-i) and stage 8 row_mirror (i <-> 15-i).
-template <int M>
-__device__ __forceinline__ int dpp_xchg(int v)
-{
-	constexpr int ctrl = M == 1 ? 0xB1 : (M == 2 ? 0x4E : (M == 4 ? 0x141 : 0x140));
-	return __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false);
-}
-template <int M>
-__device__ __forceinline__ double dpp_xchg(double v)
-{
-	const int lo = dpp_xchg<M>(__double2loint(v)), hi = dpp_xchg<M>(__double2hiint(v));
-	return __hiloint2double(hi, lo);
-}
-template <int G>
-__device__ __forceinline__ double gsum(double v)
-{
-	static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "lanes per QP");
-	if (G >= 2) v += dpp_xchg<1>(v);
-	if (G >= 4) v += dpp_xchg<2>(v);
-	if (G >= 8) v += dpp_xchg<4>(v);
-	if (G >= 16) v += dpp_xchg<8>(v);
-	return v;
-}
-template <int G>
-__device__ __forceinline__ double gmax(double v)
-{
-	if (G >= 2) v = fmax(v, dpp_xchg<1>(v));
-	if (G >= 4) v = fmax(v, dpp_xchg<2>(v));
-	if (G >= 8) v = fmax(v, dpp_xchg<4>(v));
-	if (G >= 16) v = fmax(v, dpp_xchg<8>(v));
-	return v;
-}
-template <int G>
-__device__ __forceinline__ int gand(int p)
-{
-	if (G >= 2) p &= dpp_xchg<1>(p);
-	if (G >= 4) p &= dpp_xchg<2>(p);
-	if (G >= 8) p &= dpp_xchg<4>(p);
-	if (G >= 16) p &= dpp_xchg<8>(p);
-	return p;
-}
 
 __device__ __forceinline__ double limit_scaling(double v)
 {
@@ -121,60 +78,6 @@ __device__ __forceinline__ double pow2_inv(double p)
 	int e;
 	(void)frexp(p, &e);
 	return ldexp(1.0, 1 - e);
-}
-
-// One QP as the filter classes hand it to QPWrapperAbstract (include/qpwrapper_abstract.h:30-43),
-// this lane's share of the rows only.
-template <int NV, int RPL>
-struct QpLaneData {
-	double Hd[NV], c[NV], lb[NV], ub[NV];
-	double A[RPL][NV], b[RPL];
-	bool eq[RPL];
-};
-
-// LDL' of a symmetric NV x NV matrix given by its lower triangle M[a][b], a >= b, in place:
-// on return M holds L (strictly lower) and Dinv = 1/d.  False if a pivot is not positive.
-template <int NV>
-__device__ __forceinline__ bool ldl_factor(double (&M)[NV][NV], double (&Dinv)[NV])
-{
-	bool ok = true;
-	double d[NV];
-#pragma unroll
-	for (int j = 0; j < NV; j++) {
-		double dj = M[j][j];
-#pragma unroll
-		for (int k = 0; k < j; k++) dj -= M[j][k] * M[j][k] * d[k];
-		ok = ok && (dj > 0.0);
-		d[j] = dj;
-		// pivots are positive and far from the denormal range: hardware reciprocal seed + two Newton
-		// steps instead of the full IEEE division sequence (scale / fixup handling not needed)
-		double di = __builtin_amdgcn_rcp(dj);
-		di = fma(fma(-dj, di, 1.0), di, di);
-		di = fma(fma(-dj, di, 1.0), di, di);
-		Dinv[j] = di;
-#pragma unroll
-		for (int i = j + 1; i < NV; i++) {
-			double s = M[i][j];
-#pragma unroll
-			for (int k = 0; k < j; k++) s -= M[i][k] * M[j][k] * d[k];
-			M[i][j] = s * di;
-		}
-	}
-	return ok;
-}
-template <int NV>
-__device__ __forceinline__ void ldl_solve(const double (&L)[NV][NV], const double (&Dinv)[NV], double (&v)[NV])
-{
-#pragma unroll
-	for (int i = 1; i < NV; i++)
-#pragma unroll
-		for (int k = 0; k < i; k++) v[i] -= L[i][k] * v[k];
-#pragma unroll
-	for (int i = 0; i < NV; i++) v[i] *= Dinv[i];
-#pragma unroll
-	for (int i = NV - 2; i >= 0; i--)
-#pragma unroll
-		for (int k = i + 1; k < NV; k++) v[i] -= L[k][i] * v[k];
 }
 
 template <int NV, int RPL, int G>
@@ -363,7 +266,7 @@ struct AdmmSmall {
 	//   return 0  undecided -> ADMM keeps iterating and the next check tries again.
 	// act: 0 inactive, -1 at lower bound, +1 at upper bound, 2 equality (always in, multiplier free).
 	// idl: penalty (1/delta) of the working-set solve; the caller raises it after an undecided attempt.
-	__device__ __forceinline__ int finish(double (&xp)[NV], int rounds, int refine, double idl, bool empty_start)
+	__device__ __forceinline__ int finish(double (&xp)[NV], int rounds, int refine, double idl)
 	{
 		int act[RPL], actb[NV];
 		double nu[RPL], nub[NV], rtb[NV];
@@ -383,11 +286,6 @@ struct AdmmSmall {
 			for (int r = 0; r < RPL; r++) act[r] = eqr[r] ? 2 : ws_act[r];
 #pragma unroll
 			for (int j = 0; j < NV; j++) actb[j] = clsb[j] > 0 ? 2 : ws_actb[j];
-		} else if (empty_start) { // before any iteration (z, y) carry no information: start from the equalities alone
-#pragma unroll
-			for (int r = 0; r < RPL; r++) act[r] = eqr[r] ? 2 : 0;
-#pragma unroll
-			for (int j = 0; j < NV; j++) actb[j] = clsb[j] > 0 ? 2 : 0;
 		}
 		ws_valid = false;
 #pragma unroll
@@ -631,44 +529,58 @@ struct AdmmSmall {
 	// Cold-start solve.  `status` follows QPWrapperOsqp::solve() (src/qpwrapper_osqp.cpp:225-238):
 	// 1 when solved, the raw OSQP-style code otherwise.  xout is unscaled.  Must be called by every
 	// lane of the wave (group reductions and the wave-uniform exit test).
-	// warm = true: the first finish attempt starts from the working set the previous solve() of this object ended
-	// with (if it ended at an optimum); iterates still start from zero.
+	// finish_first (asif_hip_solver::polish == 2): before any iteration the lane group runs the dual active-set
+	// method of gi_small.hpp on the unscaled problem; it decides strictly convex problems of this size outright
+	// (optimal point or proof of infeasibility) and the iterations below only run for what it leaves undecided.
+	// warm = true: the first finish attempt of the ITERATIONS starts from the working set the previous solve() of
+	// this object ended with (if the iterations ended it at an optimum); iterates still start from zero.
 	__device__ __forceinline__ void solve(const QpLaneData<NV, RPL> &in, const asif_hip_solver &S_, double (&xout)[NV],
 	                                      int &status, int &iters, bool warm = false, bool finish_first = false)
 	{
 		ws_valid = warm && ws_stored;
 		ws_stored = false;
-		load_and_scale(in, S_.scaling_iters);
-#pragma unroll
-		for (int j = 0; j < NV; j++) { x[j] = 0.0; zb[j] = 0.0; yb[j] = 0.0; dyb[j] = 0.0; dx[j] = 0.0; xout[j] = 0.0; }
-#pragma unroll
-		for (int r = 0; r < RPL; r++) { z[r] = 0.0; y[r] = 0.0; dy[r] = 0.0; }
 		status = 0;
 		iters = 0;
 		stat_rounds = 0;
 		stat_farkas = 0;
-		// the KKT factor of the iterations is formed when the first iteration is due: a wave whose every lane is
-		// decided by the finish-first attempt never needs it
-		bool fact_ok = true, factored = false;
+#pragma unroll
+		for (int j = 0; j < NV; j++) xout[j] = 0.0;
+		if constexpr (NV <= 3) {
+			if (finish_first && S_.polish != 0) {
+				double xg[NV];
+				int gsteps;
+				const int v = GiSmall<NV, RPL, G>::solve(in, (int)(threadIdx.x % G), 8 * NV + 4, xg, gsteps);
+				stat_rounds = gsteps;
+				if (v == kGiOptimal) {
+					status = kStatusSolved;
+#pragma unroll
+					for (int j = 0; j < NV; j++) xout[j] = xg[j];
+				} else if (v == kGiInfeasible) {
+					status = kStatusPrimalInf;
+				}
+				if (__all(status != 0)) return; // the usual case: nothing left for the iterations
+			}
+		}
+		load_and_scale(in, S_.scaling_iters);
+#pragma unroll
+		for (int j = 0; j < NV; j++) { x[j] = 0.0; zb[j] = 0.0; yb[j] = 0.0; dyb[j] = 0.0; dx[j] = 0.0; }
+#pragma unroll
+		for (int r = 0; r < RPL; r++) { z[r] = 0.0; y[r] = 0.0; dy[r] = 0.0; }
+		bool fact_ok = set_rho_and_factor(S_.rho, S_.sigma);
 		const double cinv = pow2_inv(cs);
 		int it = 0;
 		double penalty = 1.0 / kPolishDelta; // of the finish's working-set solves; per problem, see finish()
 		const int K = S_.check_interval > 0 ? S_.check_interval : 10;
-		// finish_first: one attempt of the active-set finish from the empty working set BEFORE the first iteration
-		// (a primal-dual active-set method on its own; for these QPs with 0-2 active rows it usually decides the
-		// problem, and the iterations only run for what it leaves undecided)
-		bool pre = finish_first && S_.polish != 0;
+		// rho is re-estimated every R iterations, NOT at every check: with checks every 1-2 iterations the estimate
+		// chases its own transient and a per-check update never settles (1.3 % of the feasible C2 problems ran into
+		// max_iter that way); OSQP ties it to a multiple of its 25-iteration check period
+		const int R = S_.adaptive_rho_interval > 0 ? S_.adaptive_rho_interval : 25;
+		int next_rho = R;
 		while (it < S_.max_iter) {
 			if (__all(status != 0)) break; // wave-uniform: every lane has latched its result
-			if (!pre) {
-				if (!factored) {
-					fact_ok = set_rho_and_factor(S_.rho, S_.sigma);
-					factored = true;
-				}
 #pragma unroll 1
-				for (int k = 0; k < K; k++) iterate(S_.sigma, S_.alpha);
-				it += K;
-			}
+			for (int k = 0; k < K; k++) iterate(S_.sigma, S_.alpha);
+			it += K;
 			const bool last = it >= S_.max_iter;
 
 			int st = 0;
@@ -677,20 +589,20 @@ struct AdmmSmall {
 			for (int j = 0; j < NV; j++) xs[j] = x[j];
 			if (S_.polish) {
 				double xp[NV];
-				const int v = finish(xp, S_.active_set_rounds, S_.refine_steps, penalty, pre);
+				const int v = finish(xp, S_.active_set_rounds, S_.refine_steps, penalty);
 				if (v == 1) {
 					st = kStatusSolved;
 #pragma unroll
 					for (int j = 0; j < NV; j++) xs[j] = xp[j];
 				} else if (v == 2) {
 					st = kStatusPrimalInf;
-				} else if (status == 0 && penalty < 1e14 && !pre) {
+				} else if (status == 0 && penalty < 1e14) {
 					penalty *= 1e3; // undecided: the next attempt, K iterations on, solves its working sets more stiffly
 				}
 			}
 			// The residual tests below are only needed by lanes the finish left undecided
 			// (wave-uniform branch: the block contains group reductions).
-			if (!pre && __any(st == 0 && status == 0)) {
+			if (__any(st == 0 && status == 0)) {
 				// ---- residual norms, unscaled (termination) and scaled (rho estimate)
 				double aty[NV], pri = 0.0, nz = 0.0, nax = 0.0, pri_s = 0.0, nz_s = 0.0, nax_s = 0.0;
 #pragma unroll
@@ -810,7 +722,8 @@ struct AdmmSmall {
 					}
 				}
 				// ---- rho adaptation (OSQP's estimate on the scaled residuals); lane-local refactor
-				if (S_.adaptive_rho && !last) {
+				if (S_.adaptive_rho && !last && it >= next_rho) {
+					next_rho = it + R;
 					const double pr = pri_s / (fmax(nz_s, nax_s) + 1e-10);
 					const double dr = dua_s / (fmax(nq_s, fmax(naty_s, npx_s)) + 1e-10);
 					double rn = rho * sqrt(pr / (dr + 1e-10));
@@ -819,14 +732,13 @@ struct AdmmSmall {
 						fact_ok = set_rho_and_factor(rn, S_.sigma) && fact_ok;
 				}
 			}
-			if (!st && !pre && (last || !fact_ok)) st = kStatusMaxIter;
+			if (!st && (last || !fact_ok)) st = kStatusMaxIter;
 			if (status == 0 && st != 0) { // latch the first verdict
 				status = st;
 				iters = it;
 #pragma unroll
 				for (int j = 0; j < NV; j++) xout[j] = D[j] * xs[j];
 			}
-			pre = false;
 		}
 		if (status == 0) { // max_iter == 0
 			status = kStatusMaxIter;

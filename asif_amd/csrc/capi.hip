@@ -166,13 +166,14 @@ extern "C" int asif_hip_default_solver(asif_hip_solver *s)
 	s->max_iter = 4000;
 	s->check_interval = 0; // 0 = the path's default (1 on the explicit path, 2 elsewhere)
 	s->scaling_iters = 0; // power-of-two Ruiz passes; 0 = the path's default (1 explicit / robust pendulum, 2 elsewhere, >= 4 wave kernel)
-	s->polish = 2; // finish at every check (1) + one attempt from the empty working set before the first iteration (2)
+	s->polish = 2; // finish at every check (1) + the dual active-set stage before the first iteration (2)
 	s->active_set_rounds = 12;
 	s->refine_steps = 2;
 	s->adaptive_rho = 1;
 	s->lanes_per_qp = 0;
 	s->presolve = 0;
 	s->warm_start = 1;
+	s->adaptive_rho_interval = 0; // 0 = 25 iterations
 	return ASIF_HIP_OK;
 }
 

@@ -1,0 +1,365 @@
+// gi_small.hpp -- dual active-set solve (Goldfarb & Idnani 1983) of the tiny strictly convex QPs of the
+// safety filter, entirely in registers:  nv <= 3 variables, diagonal cost, so every working-set system is
+// a closed-form solve of size <= 3.
+//
+// Where it sits: it is the "finish first" stage of AdmmSmall::solve (asif_hip_solver::polish == 2): one
+// attempt before the first ADMM iteration.  The ADMM iterations (admm_small.hpp) remain the general
+// method and take over for whatever this stage leaves undecided (cost without curvature, step budget,
+// numerically ambiguous dependence).  The reference sends the same problems through OSQP
+// (src/qpwrapper_osqp.cpp:217-239); form at the boundary (include/qpwrapper_abstract.h:11-15):
+//     min x'Hx + c'x   s.t.  A x >= b (== b where be),  lb <= x <= ub,   H diagonal, H > 0 here.
+//
+// Method.  Start at the unconstrained minimiser with an empty working set W (<= nv constraints, kept as
+// nv "slots" replicated in every lane of the lane group).  Repeat: pick the most violated constraint p
+// (equalities first); with N the normals in W and G = 2H,
+//     r = (N'G^-1 N)^-1 N'G^-1 n_p   (dual step direction),   z = G^-1 (n_p - N r)   (primal direction);
+// take the longest step that keeps the multipliers of W non-negative (t1) up to the step that makes p
+// active (t2); a blocking multiplier leaves W, a full step puts p into W.  If n_p depends linearly on W and no
+// multiplier blocks, the constraints of W + p are inconsistent: the QP is infeasible -- the verdict needs no
+// phase 1 and no separate certificate.  Finite for strictly convex problems; a step budget guards the
+// floating-point corner cases (result "undecided").
+//
+// Lane mapping as in admm_small.hpp: G lanes per QP, the NC general rows dealt round-robin (local row k of
+// lane g is row g + k G), variables / bounds / working set replicated.  Cross-lane traffic per step: one
+// max + one min (selection) and nv + 2 sums (the selected row), DPP butterflies.
+//
+// The file compiles for the host as well (G = 1 only): tests/host_gi_driver.cpp runs exactly this code on
+// the CPU against the oracle's exact enumeration.  That is a test harness, not a fallback: nothing in
+// libasif_hip.so calls it on the host.
+#pragma once
+#include "qp_lane.hpp"
+
+namespace asif {
+
+constexpr int kGiOptimal = 1;
+constexpr int kGiInfeasible = 2;
+constexpr int kGiUndecided = 0;
+
+template <int NV, int RPL, int G>
+struct GiSmall {
+	static_assert(NV >= 1 && NV <= 3, "closed-form working-set solves: nv <= 3");
+	static constexpr double kViolTol = 1e-12;  // a row counts as violated beyond this, relative to its own terms
+	static constexpr double kNoise = 4e-16;    // rounding level of one component of n_p - N r, relative to its terms
+	static constexpr double kActiveTol = 1e-9; // final check: working rows met to this relative accuracy
+	static constexpr int kIdLb = 1 << 16, kIdUb = 1 << 17;
+	static constexpr double kEqScore = 1e300;
+
+	// g: this lane's index in its group.  x: the optimum (when kGiOptimal is returned).  steps: iterations used.
+	ASIF_HD static int solve(const QpLaneData<NV, RPL> &in, int g, int max_steps, double (&x)[NV], int &steps)
+	{
+		double Pinv[NV];
+		bool convex = true;
+#pragma unroll
+		for (int j = 0; j < NV; j++) {
+			const double P = 2.0 * in.Hd[j];
+			convex = convex && (P > 0.0);
+			Pinv[j] = 1.0 / (convex ? P : 1.0);
+			x[j] = -in.c[j] * Pinv[j];
+		}
+		steps = 0;
+		if (!wave_all(convex)) return kGiUndecided; // wave-uniform exit: the loop below holds group reductions
+
+		// row ranking weights: 1 / |a_r| in the metric of the cost (any positive weights are correct; these make
+		// "most violated" mean "farthest away")
+		double w[RPL], wb[NV];
+#pragma unroll
+		for (int k = 0; k < RPL; k++) {
+			double s = 0.0;
+#pragma unroll
+			for (int j = 0; j < NV; j++) s += in.A[k][j] * in.A[k][j] * Pinv[j];
+			w[k] = s > 0.0 ? rank_rsqrt(s) : 1.0;
+		}
+#pragma unroll
+		for (int j = 0; j < NV; j++) wb[j] = rank_rsqrt(Pinv[j]);
+
+		// working set: slot s holds constraint  sn[s].x >= sb[s]  with multiplier su[s]; sid < 0: empty.
+		// ids: general row r -> r;  lower bound of variable j -> kIdLb + j;  upper bound -> kIdUb + j.
+		double sn[NV][NV], sb[NV], su[NV];
+		int sid[NV];
+		bool seq[NV];
+#pragma unroll
+		for (int s = 0; s < NV; s++) {
+			sid[s] = -1;
+			seq[s] = false;
+			sb[s] = 0.0;
+			su[s] = 0.0;
+#pragma unroll
+			for (int j = 0; j < NV; j++) sn[s][j] = 0.0;
+		}
+		bool rin[RPL]; // local row is in W
+		int bin[NV];   // bound of variable j in W: 0 no, -1 lower, +1 upper, 2 pinned (equality)
+		int bskip[NV]; // bit 0 / 1: lower / upper bound of variable j found met to rounding at a degenerate vertex
+#pragma unroll
+		for (int k = 0; k < RPL; k++) rin[k] = false;
+#pragma unroll
+		for (int j = 0; j < NV; j++) {
+			bin[j] = 0;
+			bskip[j] = 0;
+		}
+
+		// A pinned variable (lb == ub: the explicit class pins its relaxation variable, src/asif.cpp:88-91) is an
+		// equality the method would add first anyway; with a diagonal cost that step is known in closed form:
+		// x_j = lb_j, the other coordinates of the minimiser do not move, multiplier = d cost / d x_j there.
+		{
+			int used = 0;
+#pragma unroll
+			for (int j = 0; j < NV; j++) {
+				if (in.lb[j] == in.ub[j]) {
+#pragma unroll
+					for (int s = 0; s < NV; s++)
+						if (s == used) {
+							sid[s] = kIdLb + j;
+							seq[s] = true;
+							sb[s] = in.lb[j];
+							su[s] = 2.0 * in.Hd[j] * in.lb[j] + in.c[j];
+#pragma unroll
+							for (int k = 0; k < NV; k++) sn[s][k] = k == j ? 1.0 : 0.0;
+						}
+					used++;
+					x[j] = in.lb[j];
+					bin[j] = 2;
+				}
+			}
+		}
+
+		// candidate p:  cn.x >= cb, multiplier cu so far
+		double cn[NV], cb = 0.0, cu = 0.0;
+		int cid = -1;
+		bool ceq = false, have = false;
+#pragma unroll
+		for (int j = 0; j < NV; j++) cn[j] = 0.0;
+
+		int verdict = kGiUndecided;
+		bool done = false;
+#pragma unroll 1
+		for (int it = 0; it < max_steps; it++) {
+			if (wave_all(done)) break;
+			if (!done) steps++;
+			// ---- 1. selection: the most violated constraint outside W (used by lanes without a pending candidate).
+			// Everything below is written as selects: the lanes of a wave sit in different phases of the method, and
+			// exec-mask branches around a handful of instructions cost more than the instructions.
+			double best = 0.0;
+			int bid = 0x7fffffff;
+			// candidates are visited in increasing id, so "strictly better" keeps the lowest id among equals.
+			// (bitwise & | on bools on purpose: the short-circuit forms compile to exec-mask branches)
+			auto consider = [&](bool viol, double score, int id) {
+				const bool take = viol & (score > best);
+				best = take ? score : best;
+				bid = take ? id : bid;
+			};
+#pragma unroll
+			for (int k = 0; k < RPL; k++) {
+				double ax = 0.0, mag = fabs(in.b[k]);
+#pragma unroll
+				for (int j = 0; j < NV; j++) {
+					const double t = in.A[k][j] * x[j];
+					ax += t;
+					mag += fabs(t);
+				}
+				const double res = in.b[k] - ax; // > 0: violated from below
+				const double v = in.eq[k] ? fabs(res) : res;
+				consider(!rin[k] & (v > kViolTol * (1.0 + mag)), in.eq[k] ? kEqScore : v * w[k], g + k * G);
+			}
+#pragma unroll
+			for (int j = 0; j < NV; j++) {
+				const double lo = in.lb[j] - x[j], hi = x[j] - in.ub[j];
+				const double tlo = kViolTol * (1.0 + fabs(x[j]) + fabs(in.lb[j])), thi = kViolTol * (1.0 + fabs(x[j]) + fabs(in.ub[j]));
+				const bool pin = in.lb[j] == in.ub[j]; // pinned variable: one equality
+				const bool lo_free = ((bskip[j] & 1) == 0) & (pin ? bin[j] == 0 : bin[j] != -1);
+				consider(lo_free & ((pin ? fabs(lo) : lo) > tlo), pin ? kEqScore : lo * wb[j], kIdLb + j);
+				consider(!pin & (bin[j] != 1) & ((bskip[j] & 2) == 0) & (hi > thi), hi * wb[j], kIdUb + j);
+			}
+			const double gbest = gmax<G>(best);
+			const int gid = gmin_int<G>(best == gbest ? bid : 0x7fffffff);
+			const bool choosing = !have & !done;
+			const bool fresh = choosing & (gbest > 0.0);
+			verdict = (choosing & !fresh) ? kGiOptimal : verdict;
+			done = done | (choosing & !fresh);
+			cid = fresh ? gid : cid;
+			cu = fresh ? 0.0 : cu;
+			have = have | fresh;
+			if (wave_all(done)) break; // the selection found nothing anywhere: no step to take
+			{ // the candidate's data; a general row comes from its owning lane through a sum whose other terms are zero
+				double rn[NV], rb = 0.0;
+				int req = 0;
+#pragma unroll
+				for (int j = 0; j < NV; j++) rn[j] = 0.0;
+#pragma unroll
+				for (int k = 0; k < RPL; k++) {
+					const bool mine = (g + k * G) == cid;
+#pragma unroll
+					for (int j = 0; j < NV; j++) rn[j] = mine ? in.A[k][j] : rn[j];
+					rb = mine ? in.b[k] : rb;
+					req |= (mine & in.eq[k]) ? 1 : 0;
+				}
+#pragma unroll
+				for (int j = 0; j < NV; j++) rn[j] = gsum<G>(rn[j]);
+				rb = gsum<G>(rb);
+				req = gor<G>(req);
+				double fn[NV], fb = rb, ax = 0.0;
+				bool feq = req != 0;
+#pragma unroll
+				for (int j = 0; j < NV; j++) {
+					const bool isl = cid == kIdLb + j, isu = cid == kIdUb + j;
+					fn[j] = isl ? 1.0 : (isu ? -1.0 : rn[j]);
+					fb = isl ? in.lb[j] : (isu ? -in.ub[j] : fb);
+					feq = feq | (isl & (in.lb[j] == in.ub[j]));
+					ax += fn[j] * x[j];
+				}
+				const bool flip = feq & (ax > fb); // orient an equality so that it reads n.x >= b and is violated
+#pragma unroll
+				for (int j = 0; j < NV; j++) cn[j] = fresh ? (flip ? -fn[j] : fn[j]) : cn[j];
+				cb = fresh ? (flip ? -fb : fb) : cb;
+				ceq = fresh ? feq : ceq;
+			}
+			// ---- 2. step directions:  M r = d,  z = G^-1 (n_p - N r)
+			double M[NV][NV], Mi[NV], Mdiag[NV], r[NV], z[NV];
+			bool full = true;
+#pragma unroll
+			for (int s = 0; s < NV; s++) {
+				const bool vs = sid[s] >= 0;
+				full = full & vs;
+				double d = 0.0;
+#pragma unroll
+				for (int j = 0; j < NV; j++) d += sn[s][j] * cn[j] * Pinv[j];
+				r[s] = vs ? d : 0.0;
+#pragma unroll
+				for (int t = 0; t <= s; t++) {
+					double m = 0.0;
+#pragma unroll
+					for (int j = 0; j < NV; j++) m += sn[s][j] * sn[t][j] * Pinv[j];
+					M[s][t] = (vs & (sid[t] >= 0)) ? m : (s == t ? 1.0 : 0.0);
+				}
+				Mdiag[s] = M[s][s];
+			}
+			const bool spd = ldl_factor<NV>(M, Mi);
+			ldl_solve<NV>(M, Mi, r);
+			double zn = 0.0, nn = 0.0, cond = 1.0;
+#pragma unroll
+			for (int s = 0; s < NV; s++) cond = fmax(cond, Mdiag[s] * Mi[s]); // 1 / sin^2 of the sharpest angle inside W
+			// z component by component, each judged against the rounding of its own cancellation: a component at that
+			// level is zero (n_p lies in the span of W there), one clearly above it is data -- however small: a row
+			// [Lgh, h] with h = 1e-9 is NOT parallel to a bound on u, the relaxation variable just has to travel far
+			bool dependent = true, ambiguous = !spd;
+#pragma unroll
+			for (int j = 0; j < NV; j++) {
+				double t = cn[j], mag = 0.0;
+#pragma unroll
+				for (int s = 0; s < NV; s++) {
+					t -= sn[s][j] * r[s];
+					mag += fabs(sn[s][j] * r[s]);
+				}
+				const double noise = kNoise * (fabs(cn[j]) + cond * mag);
+				const bool zero = full | !(fabs(t) > 16.0 * noise); // nv normals in W span everything
+				ambiguous = ambiguous | (!zero & !(fabs(t) > 1e4 * noise)); // known to < 3 digits: give up
+				t = zero ? 0.0 : t;
+				dependent = dependent & zero;
+				z[j] = t * Pinv[j];
+				zn += t * z[j];
+				nn += cn[j] * cn[j] * Pinv[j];
+			}
+			// ---- 3. dual blocking: smallest su / r over the droppable slots with r > 0
+			double t1 = 1e300;
+			int kdrop = -1;
+#pragma unroll
+			for (int s = 0; s < NV; s++) {
+				const bool cand = (sid[s] >= 0) & !seq[s] & (r[s] > 0.0) & (r[s] * r[s] * Mdiag[s] > 1e-24 * nn);
+				const double ratio = su[s] / (cand ? r[s] : 1.0);
+				const bool take = cand & (ratio < t1);
+				t1 = take ? ratio : t1;
+				kdrop = take ? s : kdrop;
+			}
+			// ---- 4. the step
+			{
+				const bool active = have & !done;
+				double res = cb, rmag = fabs(cb);
+#pragma unroll
+				for (int j = 0; j < NV; j++) {
+					res -= cn[j] * x[j];
+					rmag += fabs(cn[j] * x[j]);
+				}
+				const bool amb = active & ambiguous; // verdict stays undecided
+				const bool dep = active & !ambiguous & dependent;
+				const bool indep = active & !ambiguous & !dependent;
+				const bool stuck = dep & (kdrop < 0); // n_p in span(W), no multiplier blocks
+				// W + p inconsistent -> infeasible; but when W pins the point and p misses it by rounding only (a
+				// degenerate vertex) p counts as met
+				const bool infeasible = stuck & (res > kActiveTol * (1.0 + rmag));
+				const bool skip = stuck & !infeasible;
+				const double t2 = res / (indep ? zn : 1.0);
+				const bool add = indep & (t2 <= t1);
+				const bool drop = (dep & (kdrop >= 0)) | (indep & !add);
+				const double t = add ? t2 : (drop ? t1 : 0.0);
+				verdict = infeasible ? kGiInfeasible : verdict;
+				done = done | amb | infeasible;
+#pragma unroll
+				for (int j = 0; j < NV; j++) x[j] = indep ? x[j] + t * z[j] : x[j];
+				cu = (drop | add) ? cu + t : cu;
+				const int cid_now = cid;
+#pragma unroll
+				for (int s = 0; s < NV; s++) {
+					const bool vs = sid[s] >= 0;
+					double u = (vs & (drop | add)) ? su[s] - t * r[s] : su[s];
+					u = (vs & !seq[s]) ? fmax(u, 0.0) : u;
+					su[s] = u;
+				}
+				// leave: slot kdrop
+				int gone = -1;
+#pragma unroll
+				for (int s = 0; s < NV; s++) {
+					const bool out = drop & (s == kdrop);
+					gone = out ? sid[s] : gone;
+					sid[s] = out ? -1 : sid[s];
+					su[s] = out ? 0.0 : su[s];
+#pragma unroll
+					for (int j = 0; j < NV; j++) sn[s][j] = out ? 0.0 : sn[s][j];
+				}
+				// join: first empty slot
+				bool placed = !add;
+#pragma unroll
+				for (int s = 0; s < NV; s++) {
+					const bool in_ = !placed & (sid[s] < 0);
+					placed = placed | in_;
+					sid[s] = in_ ? cid_now : sid[s];
+					seq[s] = in_ ? ceq : seq[s];
+					sb[s] = in_ ? cb : sb[s];
+					su[s] = in_ ? cu : su[s];
+#pragma unroll
+					for (int j = 0; j < NV; j++) sn[s][j] = in_ ? cn[j] : sn[s][j];
+				}
+				const bool settled = add | skip; // p is in W, or counts as met: stop offering it
+#pragma unroll
+				for (int k = 0; k < RPL; k++) {
+					const int id = g + k * G;
+					rin[k] = (settled & (id == cid_now)) ? true : ((drop & (id == gone)) ? false : rin[k]);
+				}
+#pragma unroll
+				for (int j = 0; j < NV; j++) {
+					bin[j] = (drop & ((gone == kIdLb + j) | (gone == kIdUb + j))) ? 0 : bin[j];
+					bin[j] = (add & (cid_now == kIdLb + j)) ? (ceq ? 2 : -1) : bin[j];
+					bin[j] = (add & (cid_now == kIdUb + j)) ? 1 : bin[j];
+					bskip[j] |= (skip & (cid_now == kIdLb + j)) ? 1 : 0;
+					bskip[j] |= (skip & (cid_now == kIdUb + j)) ? 2 : 0;
+				}
+				have = have & !settled;
+			}
+		}
+		if (!done) verdict = kGiUndecided;
+		// the working rows were excluded from the selection: make sure the updates kept them met
+		if (verdict == kGiOptimal) {
+#pragma unroll
+			for (int s = 0; s < NV; s++) {
+				double ax = 0.0, mag = fabs(sb[s]);
+#pragma unroll
+				for (int j = 0; j < NV; j++) {
+					ax += sn[s][j] * x[j];
+					mag += fabs(sn[s][j] * x[j]);
+				}
+				if (sid[s] >= 0 && fabs(ax - sb[s]) > kActiveTol * (1.0 + mag)) verdict = kGiUndecided;
+			}
+		}
+		return verdict;
+	}
+};
+
+} // namespace asif

@@ -119,7 +119,8 @@ inline asif_hip_solver resolve_scaling(const asif_hip_solver &S, int path_defaul
 	asif_hip_solver r = S;
 	if (r.scaling_iters == 0) r.scaling_iters = path_default;
 	else if (r.scaling_iters < 0) r.scaling_iters = 0;
-	if (r.check_interval <= 0) r.check_interval = check_default;
+	// without a finish a check only tests residuals: OSQP-ish period instead of the finish paths' 1-2 iterations
+	if (r.check_interval <= 0) r.check_interval = r.polish == 0 ? 10 : check_default;
 	return r;
 }
 

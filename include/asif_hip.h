@@ -45,8 +45,10 @@
 extern "C" {
 #endif
 
-#define ASIF_HIP_VERSION 120 /* 110: realizable / robust-data handles, solver.presolve, scaling_iters 0 = default;
-                              * 120: ASIF_HIP_IMPLICIT_RB (options grew at the end), asif_hip_set_learning, asif_hip_affine_replay */
+#define ASIF_HIP_VERSION 130 /* 110: realizable / robust-data handles, solver.presolve, scaling_iters 0 = default;
+                              * 120: ASIF_HIP_IMPLICIT_RB (options grew at the end), asif_hip_set_learning, asif_hip_affine_replay;
+                              * 130: solver.adaptive_rho_interval (struct grew at the end), polish == 2 is the dual active-set
+                              *      stage of gi_small.hpp */
 
 enum asif_hip_error {
 	ASIF_HIP_OK = 0,
@@ -132,8 +134,10 @@ typedef struct asif_hip_solver {
 	int32_t max_iter;
 	int32_t check_interval; /* termination check + polish attempt + rho adaptation every this many iterations; 0 = the path's default */
 	int32_t scaling_iters;  /* Ruiz equilibration passes; 0 = the path's default, negative = none */
-	int32_t polish;            /* 0 off; 1: run the active-set finish at every check; 2 (default): also once, from the
-	                            * empty working set, before the first iteration */
+	int32_t polish;            /* 0: plain ADMM, accuracy set by eps_*; 1: an active-set finish seeded by the iterates at every
+	                            * check; 2 (default): additionally, before the first iteration, one run of the in-register dual
+	                            * active-set method (gi_small.hpp, problems with nv <= 3 and H > 0), which decides such problems
+	                            * outright -- the iterations then only run for what it leaves undecided */
 	int32_t active_set_rounds; /* primal-dual working-set corrections per finish */
 	int32_t refine_steps;      /* refinement steps of each regularised working-set solve */
 	int32_t adaptive_rho;
@@ -148,6 +152,9 @@ typedef struct asif_hip_solver {
 	 * warm start OSQP gives the reference's closed loops.  The optimum does not depend on it; 0 makes a rollout
 	 * bitwise equal to T separate asif_hip_filter_batch calls. */
 	int32_t warm_start;
+	/* rho is re-estimated every this many iterations (OSQP: adaptive_rho_interval, a multiple of its check period);
+	 * 0 = 25.  Independent of check_interval: re-estimating at every check of a 1-2 iteration period never settles. */
+	int32_t adaptive_rho_interval;
 } asif_hip_solver;
 
 typedef struct asif_hip_dims {

@@ -1,0 +1,102 @@
+"""The product's in-register dual active-set solver (asif_amd/csrc/gi_small.hpp) compiled for the HOST with one
+lane per QP (tests/host_gi_driver.cpp) against the oracle's exact enumeration: same verdict on every instance of
+the configs' QPs and of randomised stress families (nearly parallel rows, pinned variables, equality rows, zero
+rows, degenerate vertices, crossed bounds), optimum to 1e-9.  CPU only; the device runs the same source."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_oracle_qp import _config_qps
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gi(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("gi") / "libgi_host.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                           "-I" + os.path.join(ROOT, "asif_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host_gi_driver.cpp"), "-o", so])
+    lib = C.CDLL(so)
+
+    def solve(nv, nc, Hd, c, A, b, lb, ub, be, max_steps=28):
+        B = c.shape[0]
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (Hd, c, A, b, lb, ub)]
+        sol = np.zeros((B, nv))
+        st = np.zeros(B, dtype=np.int32)
+        steps = np.zeros(B, dtype=np.int32)
+        bep = np.ascontiguousarray(be, dtype=np.uint8).ctypes.data_as(C.POINTER(C.c_uint8)) if be is not None else None
+        r = lib.gi_host_solve_batch(nv, nc, C.c_int64(B), *[a.ctypes.data_as(C.POINTER(C.c_double)) for a in arrs],
+                                    bep, max_steps, sol.ctypes.data_as(C.POINTER(C.c_double)),
+                                    st.ctypes.data_as(C.POINTER(C.c_int32)), steps.ctypes.data_as(C.POINTER(C.c_int32)))
+        assert r == 0
+        return sol, st, steps
+    return solve
+
+
+@pytest.mark.parametrize("cfg,B", [(2, 16384), (3, 1024), (4, 8192), (9, 2048)])
+def test_config_qps_decided_like_the_exact_solver(oracle, gi, cfg, B):
+    d, Hd, c, A, b, lb, ub, be = _config_qps(oracle, cfg, B)
+    ex, stex, _ = oracle.qp_solve_batch(d.nv, d.nc, Hd, c, A, b, lb, ub, be, oracle.SOLVER_EXACT)
+    sol, st, steps = gi(d.nv, d.nc, Hd, c, A, b, lb, ub, be)
+    assert (st == 0).sum() == 0, "undecided instances on a seeded workload"
+    assert np.array_equal(st == 1, stex == 1)
+    assert np.array_equal(st == 2, stex != 1)
+    ok = st == 1
+    assert np.abs(sol[ok] - ex[ok]).max() <= 1e-12
+    assert steps.max() <= 4
+
+
+def _family(rng, nv, nc, B, kind):
+    Hd = np.exp(rng.uniform(np.log(0.5), np.log(100), (B, nv)))
+    c = rng.normal(0, 3, (B, nv))
+    A = rng.normal(0, 1, (B, nv, nc))
+    b = rng.normal(-0.5, 1, (B, nc))
+    lb = -rng.uniform(0.5, 3, (B, nv))
+    ub = rng.uniform(0.5, 3, (B, nv))
+    be = np.zeros(nc, dtype=np.uint8)
+    if kind == "parallel":
+        eps = 10.0 ** rng.uniform(-7, -1, (B, 1, 1))
+        A[:, :, 1:2] = A[:, :, 0:1] * rng.uniform(0.5, 2, (B, 1, 1)) + eps * rng.normal(0, 1, (B, nv, 1))
+        A[:, :, 3:4] = -A[:, :, 2:3] + eps * rng.normal(0, 1, (B, nv, 1))
+    elif kind == "pinned":
+        ub[:, -1] = lb[:, -1] = rng.uniform(1, 6, B)
+    elif kind == "eqrow":
+        be[0] = 1
+    elif kind == "zero":
+        A[:, :, 0] = 0.0
+        b[:, 0] = rng.choice([-1e20, -1.0, 1.0], B)
+        A[:, 0, 1] = 0.0
+    elif kind == "degenerate":
+        p = rng.normal(0, 1, (B, nv))
+        b = np.einsum("bjr,bj->br", A, p)
+    elif kind == "crossed":
+        lb[:, 0], ub[:, 0] = ub[:, 0].copy(), lb[:, 0].copy()
+    return Hd, c, A.reshape(B, nv * nc), b, lb, ub, be
+
+
+@pytest.mark.parametrize("nv,nc", [(2, 4), (2, 18), (3, 17), (3, 41)])
+@pytest.mark.parametrize("kind", ["plain", "parallel", "pinned", "eqrow", "zero", "degenerate", "crossed"])
+def test_stress_families(oracle, gi, nv, nc, kind):
+    rng = np.random.default_rng(hash((nv, nc, kind)) % 2**32)
+    B = 4000
+    Hd, c, A, b, lb, ub, be = _family(rng, nv, nc, B, kind)
+    ex, stex, _ = oracle.qp_solve_batch(nv, nc, Hd, c, A, b, lb, ub, be, oracle.SOLVER_EXACT)
+    sol, st, steps = gi(nv, nc, Hd, c, A, b, lb, ub, be)
+    und = st == 0
+    # "undecided" hands the problem to the ADMM iterations; it must stay the exception and never be a wrong verdict
+    assert und.mean() <= 0.03, und.mean()
+    assert np.array_equal((st == 1)[~und], (stex == 1)[~und])
+    ok = (st == 1) & (stex == 1)
+    if ok.any():
+        assert (np.abs(sol[ok] - ex[ok]) / (1 + np.abs(ex[ok]))).max() <= 1e-9
+
+
+def test_cost_without_curvature_is_left_to_the_iterations(gi):
+    Hd = np.array([[1.0, 0.0]])
+    z = np.zeros((1, 2))
+    sol, st, steps = gi(2, 4, Hd, z, np.zeros((1, 8)), np.full((1, 4), -1e20), z - 1, z + 1, None)
+    assert st[0] == 0 and steps[0] == 0
