@@ -39,7 +39,7 @@ EXPORTS = [
     "asif_hip_filter_batch_host", "asif_hip_default_realizable_options", "asif_hip_create_realizable",
     "asif_hip_update_realizable_options", "asif_hip_realizable_tables", "asif_hip_default_robust_data_options",
     "asif_hip_create_robust_data", "asif_hip_update_robust_data_options", "asif_hip_rollout_batch",
-    "asif_hip_set_learning", "asif_hip_affine_replay",
+    "asif_hip_set_learning", "asif_hip_affine_replay", "asif_hip_qp_solve_batch_dense",
 ]
 
 MODEL_DOUBLE_INTEGRATOR_SAMPLED = 4
@@ -344,3 +344,17 @@ def qp_solve_batch(Hd, c, A, b, lb, ub, sol, status, iters=None, be=None, solver
     check(load().asif_hip_qp_solve_batch(device, C.byref(s), B, c.stride(0), nv, nc, _ptr(Hd), _ptr(c), _ptr(A),
                                          _ptr(b), _ptr(lb), _ptr(ub), bep, _ptr(sol), _ptr(status), _ptr(iters),
                                          _stream()))
+
+
+def qp_solve_batch_dense(H, c, A, b, lb, ub, sol, status, iters=None, be=None, solver=None, device=0):
+    """Same with a full cost matrix H [nv*nv,B] (column-major inside an instance, upper triangle read)."""
+    nv, B = c.shape
+    nc = b.shape[0]
+    s = solver if solver is not None else default_solver()
+    bep = None
+    if be is not None:
+        arr = (C.c_uint8 * nc)(*[int(v) for v in be])
+        bep = C.cast(arr, C.c_void_p)
+    check(load().asif_hip_qp_solve_batch_dense(device, C.byref(s), B, c.stride(0), nv, nc, _ptr(H), _ptr(c), _ptr(A),
+                                               _ptr(b), _ptr(lb), _ptr(ub), bep, _ptr(sol), _ptr(status),
+                                               _ptr(iters), _stream()))

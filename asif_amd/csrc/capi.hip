@@ -951,14 +951,14 @@ extern "C" int asif_hip_assemble_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx
 	return run_filter(ctx, a, true, (hipStream_t)stream);
 }
 
-extern "C" int asif_hip_qp_solve_batch(int device, const asif_hip_solver *solver, int64_t B, int64_t ld, int32_t nv,
-                                       int32_t nc, const double *Hd, const double *c, const double *A,
-                                       const double *b, const double *lb, const double *ub, const uint8_t *be,
-                                       double *sol, int32_t *status, int32_t *iters, void *stream)
+static int qp_solve_common(int device, const asif_hip_solver *solver, int64_t B, int64_t ld, int32_t nv, int32_t nc,
+                           const double *Hd, const double *H, const double *c, const double *A, const double *b,
+                           const double *lb, const double *ub, const uint8_t *be, double *sol, int32_t *status,
+                           int32_t *iters, void *stream)
 {
-	if (B < 0 || ld < B || nv < 1 || nc < 0 || nc > 64) return ASIF_HIP_EINVAL;
+	if (B < 0 || ld < B || nv < 1 || nc < 0 || nc > 128 || nv > 128) return ASIF_HIP_EINVAL;
 	if (B == 0) return ASIF_HIP_OK;
-	if (!Hd || !c || !A || !b || !lb || !ub || !sol || !status) return ASIF_HIP_EINVAL;
+	if ((!Hd && !H) || !c || (nc > 0 && (!A || !b)) || !lb || !ub || !sol || !status) return ASIF_HIP_EINVAL;
 	int r = check_device(device);
 	if (r) return r;
 	hipError_t e = hipSetDevice(device);
@@ -966,12 +966,30 @@ extern "C" int asif_hip_qp_solve_batch(int device, const asif_hip_solver *solver
 	asif_hip_solver S;
 	if (solver) S = *solver;
 	else asif_hip_default_solver(&S);
-	uint64_t mask = 0;
+	uint64_t mask = 0, mask2 = 0;
 	if (be)
 		for (int i = 0; i < nc; i++)
-			if (be[i]) mask |= (1ull << i);
-	QpArgs a = {B, ld, nv, nc, Hd, c, A, b, lb, ub, mask, sol, status, iters};
+			if (be[i]) (i < 64 ? mask : mask2) |= (1ull << (i & 63));
+	QpArgs a = {B, ld, nv, nc, Hd, c, A, b, lb, ub, mask, sol, status, iters, H, mask2};
 	return launch_qp_small(S, a, (hipStream_t)stream);
+}
+
+extern "C" int asif_hip_qp_solve_batch(int device, const asif_hip_solver *solver, int64_t B, int64_t ld, int32_t nv,
+                                       int32_t nc, const double *Hd, const double *c, const double *A,
+                                       const double *b, const double *lb, const double *ub, const uint8_t *be,
+                                       double *sol, int32_t *status, int32_t *iters, void *stream)
+{
+	if (!Hd) return B == 0 ? ASIF_HIP_OK : ASIF_HIP_EINVAL;
+	return qp_solve_common(device, solver, B, ld, nv, nc, Hd, nullptr, c, A, b, lb, ub, be, sol, status, iters, stream);
+}
+
+extern "C" int asif_hip_qp_solve_batch_dense(int device, const asif_hip_solver *solver, int64_t B, int64_t ld,
+                                             int32_t nv, int32_t nc, const double *H, const double *c, const double *A,
+                                             const double *b, const double *lb, const double *ub, const uint8_t *be,
+                                             double *sol, int32_t *status, int32_t *iters, void *stream)
+{
+	if (!H) return B == 0 ? ASIF_HIP_OK : ASIF_HIP_EINVAL;
+	return qp_solve_common(device, solver, B, ld, nv, nc, nullptr, H, c, A, b, lb, ub, be, sol, status, iters, stream);
 }
 
 extern "C" int asif_hip_filter_batch_host(asif_hip_ctx *ctx, int64_t B, const double *x, const double *udes,

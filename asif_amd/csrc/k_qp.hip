@@ -4,10 +4,12 @@
 // mapping reads whole 512-byte lines per wave instruction.
 #include "qp_kernel.hpp"
 #include "admm_wave.hpp"
+#include "qp_lds.hpp"
 
 namespace asif {
 
 int launch_qp_wave(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream);
+int launch_qp_lds(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream);
 
 struct GenericQpPolicy {
 	int64_t B, ld;
@@ -75,7 +77,9 @@ int launch_qp_small(const asif_hip_solver &S, const QpArgs &a, hipStream_t strea
 	if (a.B <= 0) return 0;
 	const GenericQpPolicy p = {a.B, a.ld, a.Hd, a.c, a.A, a.b, a.lb, a.ub, a.be_mask, a.sol, a.status, a.iters};
 	const int G = S.lanes_per_qp;
-	if (G == 64) return launch_qp_wave(S, a, stream); // explicitly ask for the wave-per-QP kernel
+	if (a.H || a.nc > 64) return launch_qp_lds(S, a, stream);   // full cost matrix / more rows than the masks of the
+	                                                             // in-register kernels hold: the LDS kernel
+	if (G == 64) return launch_qp_wave(S, a, stream); // explicitly ask for a wave-per-QP kernel
 	// shapes of the filter classes at the configs' sizes (C2 2x4, C3 3x41, C4 2x18)
 	if (a.nv == 2 && a.nc == 4) {
 		if (G == 0 || G == 1) return launch_policy<2, 4, 1>(S, p, stream);
@@ -118,14 +122,45 @@ static int launch_wave(const asif_hip_solver &S0, const QpArgs &a, hipStream_t s
 	return (int)hipGetLastError();
 }
 
-// any shape with nv <= 32 and nc + nv <= 64: one wavefront per QP, factor and iterates in LDS
+// One wavefront per QP.  polish == 0 asks for the plain OSQP-style ADMM of admm_wave.hpp (nv <= 32, nc + nv <= 64,
+// diagonal cost); everything else goes to the LDS kernel of qp_lds.hpp.
 int launch_qp_wave(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
 {
 	if (a.B <= 0) return 0;
-	if (a.nv < 1 || a.nv > 32 || a.nc + a.nv > 64 || a.B > 0x7fffffffLL) return ASIF_HIP_EUNSUPPORTED;
-	if (a.nv <= 8) return launch_wave<8>(S, a, stream);
-	if (a.nv <= 16) return launch_wave<16>(S, a, stream);
-	return launch_wave<32>(S, a, stream);
+	if (a.B > 0x7fffffffLL) return ASIF_HIP_EUNSUPPORTED;
+	if (S.polish == 0 && !a.H && a.nv >= 1 && a.nv <= 32 && a.nc + a.nv <= 64) {
+		if (a.nv <= 8) return launch_wave<8>(S, a, stream);
+		if (a.nv <= 16) return launch_wave<16>(S, a, stream);
+		return launch_wave<32>(S, a, stream);
+	}
+	return launch_qp_lds(S, a, stream);
+}
+
+template <int VPT, int RPT, bool FULLH>
+static int launch_lds(const asif_hip_solver &S0, const QpArgs &a, hipStream_t stream)
+{
+	asif_hip_solver S = S0;
+	if (S.scaling_iters == 0) S.scaling_iters = 4;
+	else if (S.scaling_iters < 0) S.scaling_iters = 0;
+	const size_t bytes = lds_doubles(a.nv, a.nc, VPT, RPT, FULLH) * sizeof(double);
+	if (bytes > 160 * 1024) return ASIF_HIP_EUNSUPPORTED;
+	auto kern = qp_lds_kernel<VPT, RPT, FULLH>;
+	if (bytes > 48 * 1024) {
+		hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+		if (e != hipSuccess) return (int)e;
+	}
+	hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(64), bytes, stream, S, a);
+	return (int)hipGetLastError();
+}
+
+// any shape with nv <= 128 and nc <= 128 whose LDS footprint fits 160 KB (86 x 65 with a full cost matrix: 148 KB)
+int launch_qp_lds(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
+{
+	if (a.B <= 0) return 0;
+	if (a.nv < 1 || a.nv > 128 || a.nc < 0 || a.nc > 128 || a.B > 0x7fffffffLL) return ASIF_HIP_EUNSUPPORTED;
+	const bool small = a.nv <= 64 && a.nc <= 64;
+	if (a.H) return small ? launch_lds<1, 1, true>(S, a, stream) : launch_lds<2, 2, true>(S, a, stream);
+	return small ? launch_lds<1, 1, false>(S, a, stream) : launch_lds<2, 2, false>(S, a, stream);
 }
 
 } // namespace asif

@@ -105,9 +105,11 @@ struct QpArgs {
 	int64_t B, ld;
 	int nv, nc;
 	const double *Hd, *c, *A, *b, *lb, *ub;
-	uint64_t be_mask;
+	uint64_t be_mask; // equality flags of rows 0..63
 	double *sol;
 	int32_t *status, *iters;
+	const double *H;   // full cost matrix [nv*nv][ld] (column-major, upper triangle read) or nullptr: Hd is used
+	uint64_t be_mask2; // rows 64..127
 };
 // pre-assembled QPs; returns ASIF_HIP_EUNSUPPORTED for shapes without a compiled kernel
 int launch_qp_small(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream);

@@ -298,11 +298,23 @@ int asif_hip_affine_replay(int device, const asif_hip_affine_instr *prog, int32_
 
 /* B pre-assembled QPs of one shape.  Hd[nv][ld] (diagonal of H), c[nv][ld], A[(nc*nv)][ld], b[nc][ld],
  * lb[nv][ld], ub[nv][ld]; be: HOST array of nc flags shared by the batch (NULL = none);
- * sol[nv][ld], status[B], iters[B] (may be NULL).  Cold start per instance. */
+ * sol[nv][ld], status[B], iters[B] (may be NULL).  Cold start per instance.  nv <= 128, nc <= 128.
+ * Kernel choice: the filter classes' small shapes (nv <= 3: 2x4, 2x18, 3x41, 3x17, two-variable shapes up to 48
+ * rows) run in registers (gi_small.hpp + admm_small.hpp); every other shape runs one wavefront per QP with the
+ * factor in LDS (qp_lds.hpp; solver.polish == 0 selects the plain ADMM of admm_wave.hpp where it fits) -- that
+ * includes what ASIFrobust / ASIFrealizable hand their solver: 18x12, 22x15, 38x29, 62x47, 86x65
+ * (src/asif_robust.cpp:21-22, src/asif_realizable.cpp:19-22).  ASIF_HIP_EUNSUPPORTED only beyond 160 KB of LDS. */
 int asif_hip_qp_solve_batch(int device, const asif_hip_solver *solver, int64_t B, int64_t ld, int32_t nv,
                             int32_t nc, const double *Hd, const double *c, const double *A, const double *b,
                             const double *lb, const double *ub, const uint8_t *be, double *sol,
                             int32_t *status, int32_t *iters, void *stream);
+/* Same with a full cost matrix: QPWrapperAbstract constructed with diagonalCost = false
+ * (src/qpwrapper_osqp.cpp:276-309: P = 2H, the upper triangle is what OSQP is handed, :136-153).
+ * H[(nv*nv)][ld], column-major inside an instance; entries (i, j), i <= j are read. */
+int asif_hip_qp_solve_batch_dense(int device, const asif_hip_solver *solver, int64_t B, int64_t ld, int32_t nv,
+                                  int32_t nc, const double *H, const double *c, const double *A, const double *b,
+                                  const double *lb, const double *ub, const uint8_t *be, double *sol,
+                                  int32_t *status, int32_t *iters, void *stream);
 
 /* Host-buffer convenience (pinned or pageable host memory, blocking): H2D, filter, D2H.  AoS->SoA is the
  * caller's business: same [component][ld] layout.  Used by the C++ class mirror for single agents. */

@@ -151,8 +151,8 @@ def test_realizable_class_single_agent_and_batch(hip, oracle, tmp_path):
 
 def test_robust_class_on_shipped_data(hip, oracle, tmp_path):
     """ASIF::ASIFrobust as examples/DoubleIntegrator_Robust.cpp builds it (npSSmax = 5 of the 100 shipped half-planes):
-    rows bit-identical to the oracle's; single-agent filter() solves the full 22 x 15 QP on the wave-per-QP kernel
-    (plain ADMM: 1e-4 here, the problem is badly conditioned near the boundary), filterBatch() the eliminated one."""
+    rows bit-identical to the oracle's; single-agent filter() solves the full 22 x 15 QP on the wave-per-QP LDS
+    kernel (every return code equal, 1e-6), filterBatch() the eliminated one."""
     exe = os.path.join(HOST, "di_robust")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", HOST, "-s"])
@@ -177,9 +177,8 @@ def test_robust_class_on_shipped_data(hip, oracle, tmp_path):
     assert np.array_equal(res[:, 6].astype(int), rc)                     # batch: every code
     ok = rc == 1
     assert np.abs(res[ok, 4] - ua[ok, 0]).max() <= 1e-6 and np.abs(res[ok, 5] - rl[ok, 0]).max() <= 1e-6
-    both = ok & (res[:, 3].astype(int) == 1)                              # single agent: where plain ADMM converged
-    assert both.sum() >= 0.8 * ok.sum()
-    assert np.abs(res[both, 1] - ua[both, 0]).max() <= 1e-4
+    assert np.array_equal(res[:, 3].astype(int), rc)                     # single agent: every code
+    assert np.abs(res[ok, 1] - ua[ok, 0]).max() <= 1e-6
 
 
 @pytest.mark.parametrize("plain", [False, True])

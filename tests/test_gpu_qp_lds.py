@@ -1,0 +1,165 @@
+"""The wave-per-QP LDS kernel (asif_amd/csrc/qp_lds.hpp) behind asif_hip_qp_solve_batch(_dense): the QPs the
+reference's own classes hand to their solver, multipliers and all -- ASIFrobust 18 x 12 (C5) and 22 x 15 (shipped
+half-planes), ASIFrealizable 38 x 29 / 62 x 47 / 86 x 65 -- plus full cost matrices (diagonalCost = false,
+src/qpwrapper_osqp.cpp:276-309), against the oracle's exact (u, delta).  Bar: status identical on EVERY instance,
+|u - u_ref| <= 1e-6 (north star 1e-5)."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_qp_generic import _config_qps, _solve
+
+pytestmark = pytest.mark.gpu
+
+U_TOL = 1e-6
+
+
+def _solve_dense(hip, H, c, A, b, lb, ub, be=None, **solver_kw):
+    B, nv = c.shape
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).to(dev)
+    sol = torch.zeros((nv, B), dtype=torch.float64, device=dev)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    iters = torch.zeros(B, dtype=torch.int32, device=dev)
+    hip.qp_solve_batch_dense(t(H), t(c), t(A), t(b), t(lb), t(ub), sol, status, iters, be=be,
+                             solver=hip.default_solver(**solver_kw))
+    torch.cuda.synchronize()
+    return sol.cpu().numpy().T, status.cpu().numpy(), iters.cpu().numpy()
+
+
+def test_robust_full_18x12_every_instance(hip, oracle):
+    B = 8192
+    d, Hd, c, A, b, lb, ub, be = _config_qps(oracle, 5, B)
+    assert (d.nv, d.nc) == (18, 12) and be.sum() == 8
+    model, variant = oracle.CONFIGS[5]
+    o = oracle.default_options(model, variant)
+    x, u = oracle.make_batch(5, B)
+    ua, rl, rc = oracle.filter_batch(model, variant, o, x, u, oracle.SOLVER_EXACT)
+    sol, st, it = _solve(hip, Hd, c, A, b, lb, ub, be)
+    assert np.all(rc == 1) and np.array_equal(st, rc)
+    assert np.abs(sol[:, 0].clip(o.lb[0], o.ub[0]) - ua[:, 0]).max() <= U_TOL
+    assert np.abs(sol[:, 1] - rl[:, 0]).max() <= U_TOL
+    assert sol[:, 2:].min() >= -1e-7  # multipliers stay in their cone
+    assert it.max() < 400
+
+
+def test_robust_data_22x15_every_status(hip, oracle):
+    hp = oracle.load_halfplanes()
+    z = oracle.RobustData(hp)
+    B = 2048
+    x, u = oracle.make_batch_robust_data(hp, B)
+    ua, rl, rc = z.filter(x, u)
+    A, b, code, sel = z.assemble(x)
+    Hd, c, lb, ub = (np.zeros((B, z.nv)) for _ in range(4))
+    for i in range(B):
+        Hd[i], c[i], lb[i], ub[i], be = z.qp_static(u[i])
+    sol, st, it = _solve(hip, Hd, c, A, b, lb, ub, be)
+    assert (rc == -1).sum() > 100
+    assert np.array_equal(st == 1, rc == 1), f"{((st == 1) != (rc == 1)).sum()} status mismatches"
+    assert np.all(st[rc != 1] == -3)  # primal infeasible, the raw OSQP-style code
+    ok = rc == 1
+    assert np.abs(sol[ok, 0].clip(-20, 20) - ua[ok, 0]).max() <= U_TOL
+    assert np.abs(sol[ok, 1] - rl[ok, 0]).max() <= U_TOL
+
+
+@pytest.mark.parametrize("kernel,shape", [("100Hz", (38, 29)), ("10Hz_50pt", (62, 47)), ("10Hz", (86, 65))])
+def test_realizable_full_problem(hip, oracle, kernel, shape):
+    """What ASIFrealizable::filter hands to QPsolver_ (src/asif_realizable.cpp:300-340): the full lifted problem."""
+    k = oracle.load_kernel(kernel)
+    z = oracle.Realizable(k)
+    assert (z.nv, z.nc) == shape
+    B = 768
+    x, u = oracle.make_batch_realizable(k, B)
+    ua, rl, rc = z.filter(x, u)
+    A, b, code, info = z.assemble(x)
+    keep = code == 1
+    x, u, ua, rc, A, b = x[keep], u[keep], ua[keep], rc[keep], A[keep], b[keep]
+    n = len(x)
+    Hd, c, lb, ub = (np.zeros((n, z.nv)) for _ in range(4))
+    for i in range(n):
+        Hd[i], c[i], lb[i], ub[i], be = z.qp_static(u[i])
+    sol, st, it = _solve(hip, Hd, c, A, b, lb, ub, be)
+    assert np.array_equal(st == 1, rc == 1), f"{((st == 1) != (rc == 1)).sum()} of {n} status mismatches"
+    ok = rc == 1
+    assert ok.sum() > 100
+    assert np.abs(sol[ok, 0].clip(-20, 20) - ua[ok, 0]).max() <= U_TOL
+
+
+def test_filter_shapes_on_the_lds_kernel(hip, oracle):
+    for cfg, B in ((2, 4096), (4, 2048), (3, 128)):
+        d, Hd, c, A, b, lb, ub, be = _config_qps(oracle, cfg, B)
+        ex, stex, _ = oracle.qp_solve_batch(d.nv, d.nc, Hd, c, A, b, lb, ub, be, oracle.SOLVER_EXACT)
+        sol, st, it = _solve(hip, Hd, c, A, b, lb, ub, be, lanes_per_qp=64)
+        assert np.array_equal(st == 1, stex == 1), cfg
+        assert np.all(st[stex != 1] == -3), cfg
+        ok = st == 1
+        assert np.abs(sol[ok, 0] - ex[ok, 0]).max() <= U_TOL, cfg
+
+
+def _random_dense(rng, B, nv, nc):
+    M = rng.normal(0, 1, (B, nv, nv))
+    H = np.einsum("bij,bkj->bik", M, M) / nv + 0.2 * np.eye(nv)
+    c = rng.normal(0, 2, (B, nv))
+    A = rng.normal(0, 1, (B, nv, nc))
+    x0 = rng.normal(0, 1, (B, nv))
+    b = np.einsum("bjr,bj->br", A, x0) - rng.uniform(0, 1, (B, nc))
+    lb = x0 - rng.uniform(0.1, 2, (B, nv))
+    ub = x0 + rng.uniform(0.1, 2, (B, nv))
+    return H, c, A, b, lb, ub
+
+
+@pytest.mark.parametrize("nv,nc", [(6, 9), (20, 30), (70, 70)])
+def test_full_cost_matrix_kkt(hip, nv, nc):
+    """diagonalCost = false: optimality checked directly -- feasibility, and stationarity 2Hx + c = A'mu + nu with
+    mu >= 0 on the active rows (non-negative least squares)."""
+    from scipy.optimize import nnls
+    rng = np.random.default_rng(nv * 100 + nc)
+    B = 64
+    H, c, A, b, lb, ub = _random_dense(rng, B, nv, nc)
+    Hcm = H.transpose(0, 2, 1).reshape(B, nv * nv)  # column-major per instance (H symmetric anyway)
+    sol, st, it = _solve_dense(hip, Hcm, c, A.reshape(B, nv * nc), b, lb, ub)
+    assert np.all(st == 1)
+    for i in range(B):
+        x = sol[i]
+        Am = A[i].T
+        assert (Am @ x - b[i]).min() >= -1e-8 and (x - lb[i]).min() >= -1e-8 and (ub[i] - x).min() >= -1e-8
+        grad = 2 * H[i] @ x + c[i]
+        cols = [Am[r] for r in np.where(Am @ x - b[i] <= 1e-7)[0]]
+        cols += [np.eye(nv)[j] for j in np.where(x - lb[i] <= 1e-7)[0]]
+        cols += [-np.eye(nv)[j] for j in np.where(ub[i] - x <= 1e-7)[0]]
+        if cols:
+            mu, res = nnls(np.array(cols).T, grad)
+            assert res <= 1e-6 * (1 + np.abs(grad).max()), (i, res)
+        else:
+            assert np.abs(grad).max() <= 1e-7
+
+
+def test_dense_entry_reads_the_upper_triangle_and_equals_the_diagonal_entry(hip, oracle):
+    d, Hd, c, A, b, lb, ub, be = _config_qps(oracle, 5, 256)
+    B, nv = c.shape
+    H = np.zeros((B, nv, nv))
+    H[:, np.arange(nv), np.arange(nv)] = Hd
+    H += np.tril(np.full((nv, nv), 123.0), -1)  # garbage below the diagonal must not be read (col-major: i > j)
+    Hcm = H.transpose(0, 2, 1).reshape(B, nv * nv)
+    s1, st1, _ = _solve(hip, Hd, c, A, b, lb, ub, be)
+    s2, st2, _ = _solve_dense(hip, Hcm, c, A, b, lb, ub, be)
+    assert np.array_equal(st1, st2)
+    assert np.abs(s1[:, :2] - s2[:, :2]).max() <= 1e-9
+
+
+def test_shape_limits(hip):
+    dev = torch.device("cuda:0")
+    B = 4
+    z = lambda r: torch.zeros((r, B), dtype=torch.float64, device=dev)
+    st = torch.zeros(B, dtype=torch.int32, device=dev)
+    with pytest.raises(hip.AsifHipError):  # beyond 128 variables
+        hip.qp_solve_batch(z(130) + 1, z(130), z(130 * 4), z(4), z(130) - 1, z(130) + 1, z(130), st)
+    with pytest.raises(hip.AsifHipError):  # 128 x 100: 235 KB of LDS
+        hip.qp_solve_batch(z(128) + 1, z(128), z(128 * 100), z(100), z(128) - 1, z(128) + 1, z(128), st)
+    # 100 x 60 with a diagonal cost fits in 131 KB (box-constrained least squares: the answer is the clipped centre)
+    nv, nc = 100, 60
+    c = torch.full((nv, B), -4.0, dtype=torch.float64, device=dev)
+    sol = z(nv)
+    hip.qp_solve_batch(z(nv) + 1, c, z(nc * nv), z(nc) - 1e20, z(nv) - 1, z(nv) + 1, sol, st)
+    torch.cuda.synchronize()
+    assert np.all(st.cpu().numpy() == 1) and np.abs(sol.cpu().numpy() - 1.0).max() <= 1e-9
