@@ -956,7 +956,8 @@ static int qp_solve_common(int device, const asif_hip_solver *solver, int64_t B,
                            const double *lb, const double *ub, const uint8_t *be, double *sol, int32_t *status,
                            int32_t *iters, void *stream)
 {
-	if (B < 0 || ld < B || nv < 1 || nc < 0 || nc > 128 || nv > 128) return ASIF_HIP_EINVAL;
+	if (B < 0 || ld < B || nv < 1 || nc < 0) return ASIF_HIP_EINVAL;
+	if (nc > 128 || nv > 128) return ASIF_HIP_EUNSUPPORTED;
 	if (B == 0) return ASIF_HIP_OK;
 	if ((!Hd && !H) || !c || (nc > 0 && (!A || !b)) || !lb || !ub || !sol || !status) return ASIF_HIP_EINVAL;
 	int r = check_device(device);

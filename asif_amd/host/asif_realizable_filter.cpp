@@ -16,11 +16,10 @@ ASIFrealizable::ASIFrealizable(const uint32_t nx, const uint32_t nu, const doubl
       nFacets_((uint32_t)kernel.facets.size()), npSS_(kernel.maxCriticalFacets * kernel.maxActiveConstraints),
       npSSmax_((npSSmax > nFacets_) ? nFacets_ : npSSmax),
       nv_((npSSmax_ > 0) ? (nu + npSS_ * 2 * (nu + 1) + 1) : (nu + npSS_ * 2 * (nu + 1))),
-      nc_(npSS_ * (nu + 2) + npSSmax_), nvRed_(npSSmax_ > 0 ? nu + 1 : nu), ncRed_(2 * npSS_ + npSSmax_),
-      dynamics_(dynamics), options_(), QPsolver_(new QPWrapperHip(nvRed_, ncRed_, diagonalCost)),
-      facetSolver_(new QPWrapperHip(nx, 2 * nx + 1, true)), A_(nc_ * nv_, 0.0), b_(nc_, 0.0), lb_(nv_, 0.0),
-      ub_(nv_, 0.0), Hr_(nvRed_ * nvRed_, 0.0), cr_(nvRed_, 0.0), Ar_(ncRed_ * nvRed_, 0.0), br_(ncRed_, 0.0),
-      lbr_(nvRed_, 0.0), ubr_(nvRed_, 0.0), A_facet_((2 * nx + 1) * nx, 0.0), b_facet_(2 * nx + 1, 0.0),
+      nc_(npSS_ * (nu + 2) + npSSmax_), dynamics_(dynamics), options_(),
+      QPsolver_(new QPWrapperHip(nv_, nc_, diagonalCost)), // the lifted problem itself, src/asif_realizable.cpp:48-53
+      facetSolver_(new QPWrapperHip(nx, 2 * nx + 1, true)), H_(nv_ * nv_, 0.0), c_(nv_, 0.0), A_(nc_ * nv_, 0.0),
+      b_(nc_, 0.0), lb_(nv_, 0.0), ub_(nv_, 0.0), A_facet_((2 * nx + 1) * nx, 0.0), b_facet_(2 * nx + 1, 0.0),
       batch_(nullptr), criticalFacets_(kernel.maxCriticalFacets), nCriticalFacets_(0)
 {
 	// facetSolver_ only answers "feasible or not" (:428-429).  When the facet grazes the uncertainty box its two
@@ -108,22 +107,18 @@ int32_t ASIFrealizable::initialize(const double lb[], const double ub[])
 		b_[row + nu_ + 1] = 1.0;
 		col += 2 * (nu_ + 1);
 	}
-	// reduced problem: H = diag(I, relaxCost) (:179-183), c = (-2 uDes, 0), u in [lb, ub], delta in [0, inf]
-	std::fill(Hr_.begin(), Hr_.end(), 0.0);
-	for (uint32_t j = 0; j < nu_; j++) {
-		Hr_[j + j * nvRed_] = 1.0;
-		lbr_[j] = lb[j];
-		ubr_[j] = ub[j];
-	}
-	if (npSSmax_ > 0) {
-		Hr_[nu_ + nu_ * nvRed_] = options_.relaxCost;
-		lbr_[nu_] = 0.0;
-		ubr_[nu_] = options_.inf;
-	}
+	// H = diag(I_nu, 0 ... 0, relaxCost) (:176-189)
+	std::fill(H_.begin(), H_.end(), 0.0);
+	for (uint32_t j = 0; j < nu_; j++) H_[j + j * nv_] = 1.0;
+	if (npSSmax_ > 0) H_[nv_ * nv_ - 1] = options_.relaxCost;
+	// rows of the groups: equalities except the first of each group (:233-236)
+	bool *be = new bool[nc_]();
+	for (uint32_t i = 0; i < npSS_ * (nu_ + 2); i++) be[i] = (i % (nu_ + 2)) != 0;
 	const std::vector<double> origin(nx_, 0.0);
 	updateConstraints(origin.data());
-	std::fill(cr_.begin(), cr_.end(), 0.0);
-	r = QPsolver_->initialize(Hr_.data(), cr_.data(), Ar_.data(), br_.data(), lbr_.data(), ubr_.data());
+	std::fill(c_.begin(), c_.end(), 0.0);
+	r = QPsolver_->initialize(H_.data(), c_.data(), A_.data(), b_.data(), lb_.data(), ub_.data(), be);
+	delete[] be;
 	return r != 0 ? r : 1;
 }
 
@@ -141,9 +136,8 @@ int32_t ASIFrealizable::filter(const double x[], const double uDes[], double uAc
 
 int32_t ASIFrealizable::filter(const double x[], const double uDes[], double uAct[], double relax[2])
 {
-	std::vector<double> c(nv_, 0.0);
-	for (uint32_t i = 0; i < nu_; i++) c[i] = -2.0 * uDes[i]; // updateCost, :686-697
-	return filter(x, nullptr, c.data(), uAct, relax);
+	for (uint32_t i = 0; i < nu_; i++) c_[i] = -2.0 * uDes[i]; // updateCost, :686-697
+	return filter(x, nullptr, c_.data(), uAct, relax);
 }
 
 int32_t ASIFrealizable::filter(const double x[], const double H[], const double c[], double uAct[])
@@ -156,23 +150,21 @@ int32_t ASIFrealizable::filter(const double x[], const double H[], const double 
 int32_t ASIFrealizable::filter(const double x[], const double H[], const double c[], double uAct[], double relax[2])
 {
 	if (updateConstraints(x) < 0) return -2;
-	for (uint32_t j = 0; j < nu_; j++) cr_[j] = c[j];
-	if (npSSmax_ > 0) cr_[nu_] = c[nv_ - 1];
-	if (H == nullptr) QPsolver_->updateCost(nullptr, cr_.data());
+	if (H == nullptr) QPsolver_->updateCost(nullptr, c);
 	else {
-		for (uint32_t j = 0; j < nu_; j++)
-			for (uint32_t i = 0; i < nu_; i++) Hr_[i + j * nvRed_] = H[i + j * nu_];
-		QPsolver_->updateCost(Hr_.data(), cr_.data());
+		for (uint32_t j = 0; j < nu_; j++) // updateH, :699-717: the nu x nu block
+			for (uint32_t i = 0; i < nu_; i++) H_[i + j * nv_] = H[i + j * nu_];
+		QPsolver_->updateCost(H_.data(), c);
 	}
-	QPsolver_->updateA(Ar_.data());
-	QPsolver_->updateb(br_.data());
+	QPsolver_->updateA(A_.data());
+	QPsolver_->updateb(b_.data());
 	const int32_t status = QPsolver_->solve();
 	if (status != (int32_t)QPWrapperAbstract::SOLVER_STATUS::FEASIBLE) return -1;
-	std::vector<double> sol(nvRed_);
+	std::vector<double> sol(nv_);
 	QPsolver_->getSolution(sol.data());
 	for (uint32_t j = 0; j < nu_; j++) uAct[j] = std::min(std::max(sol[j], lb_[j]), ub_[j]);
-	relax[0] = std::max(sol[0], 0.0); // solutionFull[nu]: l+_0 of group 0, smallest feasible value
-	relax[1] = npSSmax_ > 0 ? sol[nu_] : 0.0;
+	relax[0] = sol[nu_]; // a multiplier (l+_0 of group 0): the cost is zero on it, any feasible value is optimal (:346)
+	relax[1] = sol[nv_ - 1];
 	return 1;
 }
 
@@ -185,9 +177,9 @@ int32_t ASIFrealizable::updateOptions(const Options &options)
 // src/asif_realizable.cpp:365-373
 int32_t ASIFrealizable::updateOptions(void)
 {
-	if (npSSmax_ > 0) Hr_[nu_ + nu_ * nvRed_] = options_.relaxCost;
-	QPsolver_->updateBounds(lbr_.data(), nullptr);
-	QPsolver_->updateCost(Hr_.data(), cr_.data());
+	if (npSSmax_ > 0) H_[nv_ * nv_ - 1] = options_.relaxCost;
+	QPsolver_->updateBounds(lb_.data(), nullptr);
+	QPsolver_->updateCost(H_.data(), c_.data());
 	if (batch_) {
 		asif_hip_realizable_options o = batchOpts();
 		return asif_hip_update_realizable_options(batch_, &o) == 0 ? 1 : -1;
@@ -265,7 +257,7 @@ int32_t ASIFrealizable::updateConstraints(const double x[])
 			}
 		}
 	}
-	// rows of the critical groups, :509-527, and their eliminated form
+	// rows of the critical groups, :509-527
 	uint32_t col = nu_, s = 0;
 	for (uint32_t row = 0; row < npSS_ * (nu_ + 2); row += nu_ + 2, s++) {
 		const interval tg = Lgh[s].convert(), tf = Lfh[s].convert();
@@ -274,10 +266,6 @@ int32_t ASIFrealizable::updateConstraints(const double x[])
 		A_[row + (col + nu_) * nc_] = tf.left();
 		A_[row + (col + (nu_ + 1) + nu_) * nc_] = -tf.right();
 		col += 2 * (nu_ + 1);
-		Ar_[2 * s] = tg.left();
-		Ar_[2 * s + 1] = tg.right();
-		br_[2 * s] = -tf.left();
-		br_[2 * s + 1] = -tf.left();
 	}
 	// barrier rows, :530-600
 	if (npSSmax_ > 0) {
@@ -307,9 +295,6 @@ int32_t ASIFrealizable::updateConstraints(const double x[])
 			A_[row + 0 * nc_] = lgh;
 			A_[row + (nv_ - 1) * nc_] = 1.0;
 			b_[row] = -lfh - options_.relaxDes * (hBarrier_[i] - options_.relaxOffset);
-			Ar_[(2 * npSS_ + i) + 0 * ncRed_] = lgh;
-			Ar_[(2 * npSS_ + i) + nu_ * ncRed_] = 1.0;
-			br_[2 * npSS_ + i] = b_[row];
 		}
 	}
 	if (nCriticalFacets_ == 0 && std::any_of(hFull.begin(), hFull.end(), [](double v) { return v < 0.; })) return -1;

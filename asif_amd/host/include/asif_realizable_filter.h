@@ -79,13 +79,11 @@ protected:
 	std::vector<double> uncertaintyBounds_;
 	kernel_t kernel_;
 	const uint32_t nFacets_, npSS_, npSSmax_, nv_, nc_;
-	const uint32_t nvRed_, ncRed_; // the multiplier-eliminated problem QPsolver_ sees
 	DynamicsFn dynamics_;
 	Options options_;
 	QPWrapperAbstract *QPsolver_;
 	QPWrapperAbstract *facetSolver_;
-	std::vector<double> A_, b_, lb_, ub_;            // full rows / bounds of the reference's QP
-	std::vector<double> Hr_, cr_, Ar_, br_, lbr_, ubr_; // reduced problem
+	std::vector<double> H_, c_, A_, b_, lb_, ub_; // the reference's QP, handed to QPsolver_ as it is (:300-340)
 	std::vector<double> A_facet_, b_facet_;
 	asif_hip_ctx *batch_;
 	asif_hip_realizable_options batchModel_;

@@ -1,6 +1,8 @@
-// qpwrapper_hip.h -- ASIF::QPWrapperHip: the reference's solver plug-in slot filled by the MI355X
-// in-kernel ADMM (replaces ASIF::QPWrapperOsqp, include/qpwrapper_osqp.h:9-61 / src/qpwrapper_osqp.cpp).
-// One solve() = asif_hip_qp_solve_batch with a batch of one; cold start every call.
+// qpwrapper_hip.h -- ASIF::QPWrapperHip: the reference's solver plug-in slot filled by the MI355X kernels
+// (replaces ASIF::QPWrapperOsqp, include/qpwrapper_osqp.h:9-61 / src/qpwrapper_osqp.cpp).
+// One solve() = asif_hip_qp_solve_batch(_dense) with a batch of one; cold start every call.  Any shape the
+// reference's classes construct a solver with is accepted (up to 128 variables / 128 rows within 160 KB of LDS:
+// ASIFrealizable's 86 x 65 included), diagonalCost = true or false.
 #pragma once
 #if __has_include("qpwrapper_abstract.h")
 #include "qpwrapper_abstract.h" // building inside the reference tree
@@ -15,10 +17,16 @@ namespace ASIF {
 
 class QPWrapperHip : public QPWrapperAbstract {
 public:
+	// what solve() returns when the call itself failed (no device, launch error): OSQP's "unsolved" value, so that
+	// it can never be mistaken for a solver verdict; lastError() then holds the asif_hip / HIP error code
+	static constexpr int32_t STATUS_UNSOLVED = -10;
+
 	QPWrapperHip(const uint32_t nv, const uint32_t nc, const bool diagonalCost, int device = 0);
 	virtual ~QPWrapperHip(void);
 
-	// 0 on success (like osqp_setup's exit flag, src/qpwrapper_osqp.cpp:121), otherwise an asif_hip error
+	// 0 on success (like osqp_setup's exit flag, src/qpwrapper_osqp.cpp:121), otherwise an asif_hip error (shape
+	// beyond the kernels, no device).  Like the reference (src/asif.cpp:101-105) it solves once and ignores the
+	// verdict of that solve: an infeasible problem at x0 is not a set-up failure.
 	virtual int32_t initialize(const double H[], const double c[], const double A[], const double b[],
 	                           const double lb[], const double ub[], const bool be[] = nullptr);
 	// nullptr = unchanged (src/qpwrapper_osqp.cpp:128,157,199,209); always return 1
@@ -26,30 +34,33 @@ public:
 	virtual int32_t updateA(const double A[]);
 	virtual int32_t updateb(const double b[]);
 	virtual int32_t updateBounds(const double lb[], const double ub[]);
-	// 1 (FEASIBLE) or the raw OSQP-style status (src/qpwrapper_osqp.cpp:225-238)
+	// 1 (FEASIBLE) or the raw OSQP-style status (src/qpwrapper_osqp.cpp:225-238): solver verdicts only
 	virtual int32_t solve(void);
 	virtual int32_t getSolution(double sol[]);
 
-	asif_hip_solver settings; // in-kernel ADMM settings (defaults from asif_hip_default_solver)
+	asif_hip_solver settings; // kernel settings (defaults from asif_hip_default_solver)
 	int32_t lastIterations(void) const { return iters_; }
+	int lastError(void) const { return error_; } // 0, a negative ASIF_HIP_E* code or a positive hipError_t
 
 private:
 	int device_;
-	std::vector<double> host_; // [Hd | c | A | b | lb | ub] staged contiguously
+	double *host_; // pinned: [H (nv or nv*nv) | c | A | b | lb | ub | sol | status, iterations]
 	std::vector<uint8_t> be8_;
-	std::vector<double> sol_;
-	double *dev_;
-	int32_t *devStatus_;
+	double *dev_;  // same layout on the device
+	void *stream_;
 	int32_t status_, iters_;
-	bool dirty_;
-	size_t offHd() const { return 0; }
-	size_t offC() const { return nv_; }
-	size_t offA() const { return 2 * (size_t)nv_; }
+	int error_;
+	size_t nH() const { return diagonalCost_ ? (size_t)nv_ : (size_t)nv_ * nv_; }
+	size_t offH() const { return 0; }
+	size_t offC() const { return nH(); }
+	size_t offA() const { return offC() + nv_; }
 	size_t offB() const { return offA() + (size_t)nc_ * nv_; }
 	size_t offLb() const { return offB() + nc_; }
 	size_t offUb() const { return offLb() + nv_; }
 	size_t offSol() const { return offUb() + nv_; }
-	size_t total() const { return offSol() + nv_; }
+	size_t offStatus() const { return offSol() + nv_; } // two int32 in one double slot
+	size_t total() const { return offStatus() + 1; }
+	int setup(void);
 };
 
 } // namespace ASIF

@@ -1,4 +1,5 @@
-// qpwrapper_hip.cpp -- see include/qpwrapper_hip.h.  Host glue only: staging buffers + one C-ABI call.
+// qpwrapper_hip.cpp -- see include/qpwrapper_hip.h.  Host glue only: one pinned staging block, one upload, one
+// C-ABI call, one download per solve().
 #include "qpwrapper_hip.h"
 #include <hip/hip_runtime_api.h>
 #include <cstring>
@@ -6,25 +7,41 @@
 namespace ASIF {
 
 QPWrapperHip::QPWrapperHip(const uint32_t nv, const uint32_t nc, const bool diagonalCost, int device)
-    : QPWrapperAbstract(nv, nc, diagonalCost), device_(device), dev_(nullptr), devStatus_(nullptr), status_(0),
-      iters_(0), dirty_(true)
+    : QPWrapperAbstract(nv, nc, diagonalCost), device_(device), host_(nullptr), dev_(nullptr), stream_(nullptr),
+      status_(0), iters_(0), error_(0)
 {
 	asif_hip_default_solver(&settings);
-	host_.assign(total(), 0.0);
 	be8_.assign(nc_ > 0 ? nc_ : 1, 0);
-	sol_.assign(nv_, 0.0);
 }
 
 QPWrapperHip::~QPWrapperHip(void)
 {
 	if (dev_) (void)hipFree(dev_);
-	if (devStatus_) (void)hipFree(devStatus_);
+	if (host_) (void)hipHostFree(host_);
+	if (stream_) (void)hipStreamDestroy((hipStream_t)stream_);
+}
+
+int QPWrapperHip::setup(void)
+{
+	if (host_) return 0;
+	hipError_t e = hipSetDevice(device_);
+	if (e != hipSuccess) return ASIF_HIP_ENODEVICE;
+	if ((e = hipHostMalloc((void **)&host_, sizeof(double) * total(), hipHostMallocDefault)) != hipSuccess) {
+		host_ = nullptr;
+		return ASIF_HIP_ENODEVICE;
+	}
+	std::memset(host_, 0, sizeof(double) * total());
+	if ((e = hipMalloc((void **)&dev_, sizeof(double) * total())) != hipSuccess) return (int)e;
+	hipStream_t s;
+	if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) return (int)e;
+	stream_ = (void *)s;
+	return 0;
 }
 
 int32_t QPWrapperHip::initialize(const double H[], const double c[], const double A[], const double b[],
                                  const double lb[], const double ub[], const bool be[])
 {
-	if (!diagonalCost_) return ASIF_HIP_EUNSUPPORTED; // every shipped configuration uses a diagonal cost
+	if ((error_ = setup()) != 0) return error_;
 	if (be != nullptr)
 		for (uint32_t i = 0; i < nc_; i++) be_[i] = be[i];
 	for (uint32_t i = 0; i < nc_; i++) be8_[i] = be_[i] ? 1 : 0;
@@ -32,70 +49,93 @@ int32_t QPWrapperHip::initialize(const double H[], const double c[], const doubl
 	updateA(A);
 	updateb(b);
 	updateBounds(lb, ub);
-	if (hipSetDevice(device_) != hipSuccess) return ASIF_HIP_ENODEVICE;
-	if (!dev_ && hipMalloc((void **)&dev_, sizeof(double) * total()) != hipSuccess) return ASIF_HIP_ENODEVICE;
-	if (!devStatus_ && hipMalloc((void **)&devStatus_, sizeof(int32_t) * 2) != hipSuccess) return ASIF_HIP_ENODEVICE;
-	// a first solve validates the shape against the compiled kernels (the reference also solves once
-	// at the end of every initialize(), e.g. src/asif.cpp:101-102)
-	const int32_t r = solve();
-	return (r == ASIF_HIP_EUNSUPPORTED || r == ASIF_HIP_ENODEVICE || r == ASIF_HIP_EINVAL) ? r : 0;
+	// the reference solves once at the end of every initialize() and ignores the outcome (src/asif.cpp:101-105);
+	// here that first solve also validates the shape against the kernels
+	(void)solve();
+	return error_;
 }
 
 int32_t QPWrapperHip::updateCost(const double H[], const double c[])
 {
-	if (H != nullptr)
-		for (uint32_t i = 0; i < nv_; i++) host_[offHd() + i] = H[i + i * nv_]; // diagonal only, :267-272
+	if (!host_ && setup() != 0) return 1;
+	if (H != nullptr) {
+		if (diagonalCost_) // only the diagonal is read, src/qpwrapper_osqp.cpp:267-272
+			for (uint32_t i = 0; i < nv_; i++) host_[offH() + i] = H[i + i * nv_];
+		else // the whole matrix, of which the kernel reads the upper triangle (:136-153,276-309)
+			std::memcpy(&host_[offH()], H, sizeof(double) * nv_ * nv_);
+	}
 	if (c != nullptr) std::memcpy(&host_[offC()], c, sizeof(double) * nv_);
-	dirty_ = true;
 	return 1;
 }
 
 int32_t QPWrapperHip::updateA(const double A[])
 {
+	if (!host_ && setup() != 0) return 1;
 	std::memcpy(&host_[offA()], A, sizeof(double) * nc_ * nv_);
-	dirty_ = true;
 	return 1;
 }
 
 int32_t QPWrapperHip::updateb(const double b[])
 {
+	if (!host_ && setup() != 0) return 1;
 	std::memcpy(&host_[offB()], b, sizeof(double) * nc_);
-	dirty_ = true;
 	return 1;
 }
 
 int32_t QPWrapperHip::updateBounds(const double lb[], const double ub[])
 {
+	if (!host_ && setup() != 0) return 1;
 	if (lb != nullptr) std::memcpy(&host_[offLb()], lb, sizeof(double) * nv_);
 	if (ub != nullptr) std::memcpy(&host_[offUb()], ub, sizeof(double) * nv_);
-	dirty_ = true;
 	return 1;
 }
 
 int32_t QPWrapperHip::solve(void)
 {
-	if (!dev_) return ASIF_HIP_ENODEVICE;
-	if (hipSetDevice(device_) != hipSuccess) return ASIF_HIP_ENODEVICE;
-	if (hipMemcpy(dev_, host_.data(), sizeof(double) * offSol(), hipMemcpyHostToDevice) != hipSuccess)
-		return ASIF_HIP_ENODEVICE;
+	if (!dev_) {
+		error_ = ASIF_HIP_ENODEVICE;
+		return STATUS_UNSOLVED;
+	}
+	hipStream_t s = (hipStream_t)stream_;
+	hipError_t e = hipSetDevice(device_);
+	if (e == hipSuccess) e = hipMemcpyAsync(dev_, host_, sizeof(double) * offSol(), hipMemcpyHostToDevice, s);
+	if (e != hipSuccess) {
+		error_ = (int)e;
+		return STATUS_UNSOLVED;
+	}
 	// batch of one: component k of the single instance sits at base[k] (ld = 1)
-	const int r = asif_hip_qp_solve_batch(device_, &settings, 1, 1, (int32_t)nv_, (int32_t)nc_, dev_ + offHd(),
-	                                      dev_ + offC(), dev_ + offA(), dev_ + offB(), dev_ + offLb(), dev_ + offUb(),
-	                                      be8_.data(), dev_ + offSol(), devStatus_, devStatus_ + 1, nullptr);
-	if (r != 0) return r;
+	int32_t *dst = (int32_t *)(dev_ + offStatus());
+	int r;
+	if (diagonalCost_)
+		r = asif_hip_qp_solve_batch(device_, &settings, 1, 1, (int32_t)nv_, (int32_t)nc_, dev_ + offH(), dev_ + offC(),
+		                            dev_ + offA(), dev_ + offB(), dev_ + offLb(), dev_ + offUb(), be8_.data(),
+		                            dev_ + offSol(), dst, dst + 1, stream_);
+	else
+		r = asif_hip_qp_solve_batch_dense(device_, &settings, 1, 1, (int32_t)nv_, (int32_t)nc_, dev_ + offH(),
+		                                  dev_ + offC(), dev_ + offA(), dev_ + offB(), dev_ + offLb(), dev_ + offUb(),
+		                                  be8_.data(), dev_ + offSol(), dst, dst + 1, stream_);
+	if (r != 0) {
+		error_ = r;
+		return STATUS_UNSOLVED;
+	}
+	e = hipMemcpyAsync(host_ + offSol(), dev_ + offSol(), sizeof(double) * (nv_ + 1), hipMemcpyDeviceToHost, s);
+	if (e == hipSuccess) e = hipStreamSynchronize(s);
+	if (e != hipSuccess) {
+		error_ = (int)e;
+		return STATUS_UNSOLVED;
+	}
 	int32_t st[2];
-	if (hipMemcpy(st, devStatus_, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return ASIF_HIP_ENODEVICE;
-	if (hipMemcpy(sol_.data(), dev_ + offSol(), sizeof(double) * nv_, hipMemcpyDeviceToHost) != hipSuccess)
-		return ASIF_HIP_ENODEVICE;
+	std::memcpy(st, host_ + offStatus(), sizeof(st));
 	status_ = st[0];
 	iters_ = st[1];
-	dirty_ = false;
+	error_ = 0;
 	return status_;
 }
 
 int32_t QPWrapperHip::getSolution(double sol[])
 {
-	for (uint32_t i = 0; i < nv_; i++) sol[i] = sol_[i];
+	if (host_)
+		for (uint32_t i = 0; i < nv_; i++) sol[i] = host_[offSol() + i];
 	return 1;
 }
 

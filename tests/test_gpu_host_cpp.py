@@ -110,7 +110,8 @@ def test_robust_class_single_agent_and_batch(hip, oracle):
 
 def test_realizable_class_single_agent_and_batch(hip, oracle, tmp_path):
     """ASIF::ASIFrealizable: facet search through facetSolver_ (2 x 5 QPs on the GPU), host affine arithmetic and
-    the full 29 x 38 rows must reproduce the oracle's rows bit for bit; single-agent filter() and filterBatch()
+    the full 29 x 38 rows must reproduce the oracle's rows bit for bit; single-agent filter() (the lifted 38 x 29
+    problem through QPWrapperHip, as src/asif_realizable.cpp:300-340 hands it to its solver) and filterBatch()
     against the oracle's exact optimum; rc 1 / -2 identical."""
     exe = os.path.join(HOST, "realizable_di")
     if not os.path.exists(exe):
@@ -142,9 +143,11 @@ def test_realizable_class_single_agent_and_batch(hip, oracle, tmp_path):
     assert np.array_equal(res[:, 4].astype(int), rc) and np.array_equal(res[:, 8].astype(int), rc)
     assert {1, -2} <= set(rc.tolist()) and (info[:, 0] > 0).sum() > 10
     ok = rc == 1
-    assert np.abs(res[ok, 1] - ua[ok, 0]).max() <= 1e-5      # single agent (wave-per-QP kernel, plain ADMM)
-    assert np.abs(res[ok, 3] - rl[ok, 1]).max() <= 1e-5
-    assert np.abs(res[ok, 2] - rl[ok, 0]).max() <= 1e-5
+    # single agent: QPsolver_ gets the full 38 x 29 problem as the reference's does (wave-per-QP LDS kernel)
+    assert np.abs(res[ok, 1] - ua[ok, 0]).max() <= 1e-6
+    assert np.abs(res[ok, 3] - rl[ok, 1]).max() <= 1e-6
+    # relax[0] = solutionFull[nu] is a multiplier with zero cost: any value from its smallest feasible one up is optimal
+    assert (res[ok, 2] - rl[ok, 0]).min() >= -1e-6
     assert np.abs(res[ok, 6] - ua[ok, 0]).max() <= 1e-6      # batch
     assert np.abs(res[ok, 7] - rl[ok, 1]).max() <= 1e-6
 
@@ -213,3 +216,25 @@ def test_implicit_rb_class_single_agent_and_batch(hip, oracle, plain):
         oracle.assemble(model, variant, o, x[i])
         dh, lf, lg = oracle.rb_last_learning()
         assert abs(rows[i, 7] - dh[0]) <= 1e-12 and abs(rows[i, 8] - lf) <= 1e-13 and abs(rows[i, 9] - lg[0]) <= 1e-13
+
+
+def test_qpwrapper_hip_contract(hip, tmp_path):
+    """ASIF::QPWrapperHip: full cost matrix, set-up vs solver verdicts kept apart (an infeasible first solve is not
+    a set-up failure; a shape beyond the kernels is), the reference's largest shape accepted."""
+    exe = str(tmp_path / "qpw")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(HOST, "include"),
+                           "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                           os.path.join(ROOT, "tests", "host_qpwrapper_driver.cpp"),
+                           os.path.join(HOST, "libasif_host.a"), "-L" + os.path.join(ROOT, "asif_amd"), "-lasif_hip",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "asif_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = {l.split()[0]: [float(v) for v in l.split()[1:]] for l in out.stdout.strip().split("\n")}
+    # min 2x0^2 + 2x0x1 + 3x1^2 - 2x0 - 6x1 on [0, 0.9]^2 with x0 + x1 >= 1: on that row the cost is 3x1^2 - 6x1,
+    # so x1 sits at its bound 0.9 and x0 = 0.1
+    assert r["dense"][:2] == [0, 1] and abs(r["dense"][2] - 0.1) <= 1e-8 and abs(r["dense"][3] - 0.9) <= 1e-8
+    assert r["infeasible_init"][0] == 0 and r["infeasible_init"][1] == -3 and r["infeasible_init"][2] == 0
+    assert r["infeasible_init"][3] == 1 and abs(r["infeasible_init"][4] - 1.0) <= 1e-8 and abs(r["infeasible_init"][5]) <= 1e-8
+    assert r["big"][:2] == [0, 1] and abs(r["big"][2] - 0.25) <= 1e-8 and abs(r["big"][3] - 0.25) <= 1e-8
+    assert r["toobig"][0] == -3 and r["toobig"][1] == -10 and r["toobig"][2] == -3  # ASIF_HIP_EUNSUPPORTED / STATUS_UNSOLVED
