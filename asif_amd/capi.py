@@ -40,6 +40,8 @@ EXPORTS = [
     "asif_hip_update_realizable_options", "asif_hip_realizable_tables", "asif_hip_default_robust_data_options",
     "asif_hip_create_robust_data", "asif_hip_update_robust_data_options", "asif_hip_rollout_batch",
     "asif_hip_set_learning", "asif_hip_affine_replay", "asif_hip_qp_solve_batch_dense",
+    "asif_hip_partition", "asif_hip_create_multi", "asif_hip_multi_destroy", "asif_hip_multi_size",
+    "asif_hip_multi_handle", "asif_hip_multi_update_options", "asif_hip_filter_batch_host_multi",
 ]
 
 MODEL_DOUBLE_INTEGRATOR_SAMPLED = 4
@@ -240,6 +242,50 @@ class Filter:
         B = x.shape[1]
         check(self.lib.asif_hip_assemble_batch(self.handle, B, x.stride(0), _ptr(x), _ptr(A), _ptr(b), _ptr(code),
                                                _ptr(diag), _stream()))
+
+
+def partition(B, nblocks, r):
+    """(first, count) of block r when B instances are cut into nblocks contiguous blocks (asif_hip_partition)."""
+    first, count = C.c_int64(), C.c_int64()
+    check(load().asif_hip_partition(C.c_int64(B), nblocks, r, C.byref(first), C.byref(count)))
+    return first.value, count.value
+
+
+class MultiFilter:
+    """The same filter on several GPUs of one node behind one call (asif_hip_create_multi): HOST buffers in, HOST
+    buffers out, contiguous blocks of the batch per device, no collective."""
+
+    def __init__(self, model, variant, devices, options=None, solver=None):
+        self.lib = load()
+        self.lib.asif_hip_multi_handle.restype = C.c_void_p
+        self.options = options if options is not None else default_options(model, variant)
+        self.solver = solver if solver is not None else default_solver()
+        devs = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        check(self.lib.asif_hip_create_multi(C.byref(h), model, variant, C.byref(self.options), C.byref(self.solver),
+                                             len(devices), devs))
+        self.handle = h
+        d = Dims()
+        check(self.lib.asif_hip_get_dims(C.c_void_p(self.lib.asif_hip_multi_handle(self.handle, 0)), C.byref(d)))
+        self.dims = d
+
+    def close(self):
+        if self.handle:
+            self.lib.asif_hip_multi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def filter_host(self, x, udes, uact, relax, rc):
+        """numpy arrays, C-contiguous: x [nx,B], udes [nu,B] -> uact [nu,B], relax [nrelax,B], rc int32[B], in place."""
+        B = x.shape[1]
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(self.lib.asif_hip_filter_batch_host_multi(self.handle, C.c_int64(B), p(x), p(udes), p(uact), p(relax),
+                                                        p(rc)))
 
 
 def default_realizable_options(model=MODEL_DOUBLE_INTEGRATOR_SAMPLED, **overrides):

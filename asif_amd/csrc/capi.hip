@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 using namespace asif;
@@ -993,12 +994,11 @@ extern "C" int asif_hip_qp_solve_batch_dense(int device, const asif_hip_solver *
 	return qp_solve_common(device, solver, B, ld, nv, nc, nullptr, H, c, A, b, lb, ub, be, sol, status, iters, stream);
 }
 
-extern "C" int asif_hip_filter_batch_host(asif_hip_ctx *ctx, int64_t B, const double *x, const double *udes,
-                                          double *uact, double *relax, int32_t *rc)
+// Host buffers, SoA with leading dimension ldh (>= B): component k of instance i at base[k * ldh + i].  Strided
+// component copies go as one 2-D copy per array; the device side is dense (ld = B).
+static int filter_host_strided(asif_hip_ctx *ctx, int64_t B, int64_t ldh, const double *x, const double *udes,
+                               double *uact, double *relax, int32_t *rc, hipStream_t s)
 {
-	if (!ctx || B < 0) return ASIF_HIP_EINVAL;
-	if (B == 0) return ASIF_HIP_OK;
-	if (!x || !udes || !uact || !relax || !rc) return ASIF_HIP_EINVAL;
 	hipError_t e = hipSetDevice(ctx->device);
 	if (e != hipSuccess) return (int)e;
 	const asif_hip_dims &d = ctx->dims;
@@ -1019,16 +1019,140 @@ extern "C" int asif_hip_filter_batch_host(asif_hip_ctx *ctx, int64_t B, const do
 	}
 	double *dx = ctx->d_in, *du = ctx->d_in + (int64_t)d.nx * B;
 	double *dua = ctx->d_out, *drl = ctx->d_out + (int64_t)d.nu * B;
-	hipStream_t s = nullptr;
-	if ((e = hipMemcpyAsync(dx, x, sizeof(double) * d.nx * B, hipMemcpyHostToDevice, s)) != hipSuccess) return (int)e;
-	if ((e = hipMemcpyAsync(du, udes, sizeof(double) * d.nu * B, hipMemcpyHostToDevice, s)) != hipSuccess) return (int)e;
+	const size_t w = sizeof(double) * B, hp = sizeof(double) * ldh;
+	auto up = [&](double *dst, const double *src, int rows) {
+		return hipMemcpy2DAsync(dst, w, src, hp, w, (size_t)rows, hipMemcpyHostToDevice, s);
+	};
+	auto down = [&](double *dst, const double *src, int rows) {
+		return hipMemcpy2DAsync(dst, hp, src, w, w, (size_t)rows, hipMemcpyDeviceToHost, s);
+	};
+	if ((e = up(dx, x, d.nx)) != hipSuccess) return (int)e;
+	if ((e = up(du, udes, d.nu)) != hipSuccess) return (int)e;
 	// slots the kernel leaves untouched must keep the caller's values
-	if ((e = hipMemcpyAsync(dua, uact, sizeof(double) * d.nu * B, hipMemcpyHostToDevice, s)) != hipSuccess) return (int)e;
-	if ((e = hipMemcpyAsync(drl, relax, sizeof(double) * d.nrelax * B, hipMemcpyHostToDevice, s)) != hipSuccess) return (int)e;
+	if ((e = up(dua, uact, d.nu)) != hipSuccess) return (int)e;
+	if ((e = up(drl, relax, d.nrelax)) != hipSuccess) return (int)e;
 	int r = asif_hip_filter_batch(ctx, B, B, dx, du, dua, drl, ctx->d_rc, nullptr, s);
 	if (r) return r;
-	if ((e = hipMemcpyAsync(uact, dua, sizeof(double) * d.nu * B, hipMemcpyDeviceToHost, s)) != hipSuccess) return (int)e;
-	if ((e = hipMemcpyAsync(relax, drl, sizeof(double) * d.nrelax * B, hipMemcpyDeviceToHost, s)) != hipSuccess) return (int)e;
+	if ((e = down(uact, dua, d.nu)) != hipSuccess) return (int)e;
+	if ((e = down(relax, drl, d.nrelax)) != hipSuccess) return (int)e;
 	if ((e = hipMemcpyAsync(rc, ctx->d_rc, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s)) != hipSuccess) return (int)e;
 	return (int)hipStreamSynchronize(s);
+}
+
+extern "C" int asif_hip_filter_batch_host(asif_hip_ctx *ctx, int64_t B, const double *x, const double *udes,
+                                          double *uact, double *relax, int32_t *rc)
+{
+	if (!ctx || B < 0) return ASIF_HIP_EINVAL;
+	if (B == 0) return ASIF_HIP_OK;
+	if (!x || !udes || !uact || !relax || !rc) return ASIF_HIP_EINVAL;
+	return filter_host_strided(ctx, B, B, x, udes, uact, relax, rc, nullptr);
+}
+
+// ---- several devices driven together: contiguous blocks of the batch, one host thread + stream
+// per handle, no collective -- the "gather" is the pointer offset of each block in the caller's arrays.
+struct asif_hip_multi {
+	std::vector<asif_hip_ctx *> h;
+	std::vector<hipStream_t> s;
+};
+
+extern "C" int asif_hip_partition(int64_t B, int32_t n, int32_t r, int64_t *first, int64_t *count)
+{
+	if (B < 0 || n < 1 || r < 0 || r >= n || !first || !count) return ASIF_HIP_EINVAL;
+	const int64_t q = B / n, rem = B % n; // remainder to the first blocks
+	*count = q + (r < rem ? 1 : 0);
+	*first = q * r + (r < rem ? r : rem);
+	return ASIF_HIP_OK;
+}
+
+extern "C" int asif_hip_multi_destroy(asif_hip_multi *m)
+{
+	if (!m) return ASIF_HIP_EINVAL;
+	for (size_t i = 0; i < m->h.size(); i++) {
+		if (m->s[i]) {
+			(void)hipSetDevice(m->h[i]->device);
+			(void)hipStreamDestroy(m->s[i]);
+		}
+		if (m->h[i]) asif_hip_destroy(m->h[i]);
+	}
+	delete m;
+	return ASIF_HIP_OK;
+}
+
+// adopts the handles (one per entry of the device list; a device may appear more than once)
+static int multi_adopt(asif_hip_multi **out, std::vector<asif_hip_ctx *> &hs)
+{
+	asif_hip_multi *m = new (std::nothrow) asif_hip_multi();
+	if (!m) return ASIF_HIP_EINVAL;
+	m->h = hs;
+	m->s.assign(hs.size(), nullptr);
+	for (size_t i = 0; i < hs.size(); i++) {
+		hipError_t e = hipSetDevice(hs[i]->device);
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->s[i], hipStreamNonBlocking);
+		if (e != hipSuccess) {
+			asif_hip_multi_destroy(m);
+			return (int)e;
+		}
+	}
+	*out = m;
+	return ASIF_HIP_OK;
+}
+
+extern "C" int asif_hip_create_multi(asif_hip_multi **out, int model, int variant, const asif_hip_options *opts,
+                                     const asif_hip_solver *solver, int32_t ndev, const int32_t *devs)
+{
+	if (!out || ndev < 1 || !devs) return ASIF_HIP_EINVAL;
+	*out = nullptr;
+	std::vector<asif_hip_ctx *> hs;
+	for (int i = 0; i < ndev; i++) {
+		asif_hip_ctx *c = nullptr;
+		const int r = asif_hip_create(&c, model, variant, opts, solver, devs[i]);
+		if (r) {
+			for (asif_hip_ctx *h : hs) asif_hip_destroy(h);
+			return r;
+		}
+		hs.push_back(c);
+	}
+	const int r = multi_adopt(out, hs);
+	if (r)
+		for (asif_hip_ctx *h : hs) asif_hip_destroy(h);
+	return r;
+}
+
+extern "C" int asif_hip_multi_size(const asif_hip_multi *m) { return m ? (int)m->h.size() : 0; }
+
+extern "C" asif_hip_ctx *asif_hip_multi_handle(asif_hip_multi *m, int32_t i)
+{
+	return (m && i >= 0 && (size_t)i < m->h.size()) ? m->h[i] : nullptr;
+}
+
+extern "C" int asif_hip_multi_update_options(asif_hip_multi *m, const asif_hip_options *opts)
+{
+	if (!m) return ASIF_HIP_EINVAL;
+	for (asif_hip_ctx *h : m->h)
+		if (int r = asif_hip_update_options(h, opts)) return r;
+	return ASIF_HIP_OK;
+}
+
+extern "C" int asif_hip_filter_batch_host_multi(asif_hip_multi *m, int64_t B, const double *x, const double *udes,
+                                                double *uact, double *relax, int32_t *rc)
+{
+	if (!m || m->h.empty() || B < 0) return ASIF_HIP_EINVAL;
+	if (B == 0) return ASIF_HIP_OK;
+	if (!x || !udes || !uact || !relax || !rc) return ASIF_HIP_EINVAL;
+	const int n = (int)m->h.size();
+	std::vector<int> res(n, 0);
+	std::vector<std::thread> th;
+	for (int r = 0; r < n; r++) {
+		int64_t first, count;
+		asif_hip_partition(B, n, r, &first, &count);
+		if (count == 0) continue;
+		th.emplace_back([=, &res]() {
+			res[r] = filter_host_strided(m->h[r], count, B, x + first, udes + first, uact + first, relax + first,
+			                             rc + first, m->s[r]);
+		});
+	}
+	for (std::thread &t : th) t.join();
+	for (int r = 0; r < n; r++)
+		if (res[r]) return res[r];
+	return ASIF_HIP_OK;
 }

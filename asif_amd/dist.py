@@ -1,6 +1,7 @@
-"""Multi-GPU plumbing: the batch axis shards embarrassingly, so the only distributed
+"""Multi-process plumbing of bench.py: the batch axis shards embarrassingly, so the only distributed
 pieces are the rendezvous, the barrier around the timed region and the max-over-ranks of the elapsed
-time.  There is no data-path collective.  backend "nccl" is RCCL on ROCm; tests use "gloo" on CPU.
+time.  There is no data-path collective and, with the default backend "gloo" (TCP on the host), no RCCL at all --
+north_star: "no RCCL collectives".  (In-process multi-GPU: asif_hip_filter_batch_host_multi in the library.)
 """
 import os
 
@@ -18,7 +19,7 @@ class Group:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            backend = backend or "nccl"
+            backend = backend or "gloo"
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
             dist.init_process_group(backend, rank=self.rank, world_size=self.world)

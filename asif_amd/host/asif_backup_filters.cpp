@@ -186,7 +186,7 @@ ASIFimplicit::ASIFimplicit(const uint32_t nx, const uint32_t nu, const uint32_t 
 ASIFimplicit::~ASIFimplicit(void)
 {
 	delete QPsolver_;
-	if (batch_) asif_hip_destroy(batch_);
+	if (batch_) asif_hip_multi_destroy(batch_);
 }
 
 int32_t ASIFimplicit::initialize(const double lb[], const double ub[])
@@ -303,7 +303,7 @@ int32_t ASIFimplicit::updateOptions(void)
 	if (batch_) {
 		asif_hip_options o;
 		fillOptions(o);
-		asif_hip_update_options(batch_, &o);
+		asif_hip_multi_update_options(batch_, &o);
 	}
 	return rc;
 }
@@ -403,11 +403,17 @@ void ASIFimplicit::fillOptions(asif_hip_options &o) const
 
 int32_t ASIFimplicit::bindDeviceModel(int model, int device)
 {
-	if (batch_) asif_hip_destroy(batch_);
+	const int32_t devs[1] = {device};
+	return bindDeviceModel(model, 1, devs);
+}
+
+int32_t ASIFimplicit::bindDeviceModel(int model, int32_t ndev, const int32_t devs[])
+{
+	if (batch_) asif_hip_multi_destroy(batch_);
 	batch_ = nullptr;
 	asif_hip_options o;
 	fillOptions(o);
-	int r = asif_hip_create(&batch_, model, deviceVariant(), &o, nullptr, device);
+	int r = asif_hip_create_multi(&batch_, model, deviceVariant(), &o, nullptr, ndev, devs);
 	if (r) return r;
 	if (options_.use_learning) {
 		const LearningData &d = learning_data_;
@@ -415,17 +421,18 @@ int32_t ASIFimplicit::bindDeviceModel(int model, int device)
 		                            d.d_act_hidden_2, d.d_drift_out, d.d_act_out, d.w_1_drift, d.w_2_drift, d.w_3_drift,
 		                            d.b_1_drift, d.b_2_drift, d.b_3_drift, d.w_1_act, d.w_2_act, d.w_3_act, d.b_1_act,
 		                            d.b_2_act, d.b_3_act};
-		r = asif_hip_set_learning(batch_, &L);
+		for (int i = 0; i < asif_hip_multi_size(batch_) && r == 0; i++)
+			r = asif_hip_set_learning(asif_hip_multi_handle(batch_, i), &L);
 		if (r) {
-			asif_hip_destroy(batch_);
+			asif_hip_multi_destroy(batch_);
 			batch_ = nullptr;
 			return r;
 		}
 	}
 	asif_hip_dims d;
-	asif_hip_get_dims(batch_, &d);
+	asif_hip_get_dims(asif_hip_multi_handle(batch_, 0), &d);
 	if ((uint32_t)d.nx != nx_ || (uint32_t)d.nu != nu_ || (uint32_t)d.nc != npTC_) {
-		asif_hip_destroy(batch_);
+		asif_hip_multi_destroy(batch_);
 		batch_ = nullptr;
 		return ASIF_HIP_EINVAL;
 	}
@@ -436,7 +443,7 @@ int32_t ASIFimplicit::filterBatch(int64_t B, const double x[], const double uDes
                                   int32_t rc[])
 {
 	if (!batch_) return ASIF_HIP_EINVAL;
-	return asif_hip_filter_batch_host(batch_, B, x, uDes, uAct, relax, rc);
+	return asif_hip_filter_batch_host_multi(batch_, B, x, uDes, uAct, relax, rc);
 }
 
 // =============================================================================== ASIFimplicitTB
@@ -465,7 +472,7 @@ ASIFimplicitTB::ASIFimplicitTB(const uint32_t nx, const uint32_t nu, const uint3
 ASIFimplicitTB::~ASIFimplicitTB(void)
 {
 	delete QPsolver_;
-	if (batch_) asif_hip_destroy(batch_);
+	if (batch_) asif_hip_multi_destroy(batch_);
 }
 
 int32_t ASIFimplicitTB::initialize(const double lb[], const double ub[])
@@ -589,7 +596,7 @@ int32_t ASIFimplicitTB::updateOptions(void)
 	if (batch_) {
 		asif_hip_options o;
 		fillOptions(o);
-		asif_hip_update_options(batch_, &o);
+		asif_hip_multi_update_options(batch_, &o);
 	}
 	return rc;
 }
@@ -738,17 +745,24 @@ void ASIFimplicitTB::fillOptions(asif_hip_options &o) const
 
 int32_t ASIFimplicitTB::bindDeviceModel(int model, int device)
 {
-	if (batch_) asif_hip_destroy(batch_);
+	const int32_t devs[1] = {device};
+	return bindDeviceModel(model, 1, devs);
+}
+
+// BASELINE.json config 4: the agents of one call spread over the GPUs of a node, no collective
+int32_t ASIFimplicitTB::bindDeviceModel(int model, int32_t ndev, const int32_t devs[])
+{
+	if (batch_) asif_hip_multi_destroy(batch_);
 	batch_ = nullptr;
 	asif_hip_options o;
 	fillOptions(o);
-	int r = asif_hip_create(&batch_, model, ASIF_HIP_IMPLICIT_TB, &o, nullptr, device);
+	int r = asif_hip_create_multi(&batch_, model, ASIF_HIP_IMPLICIT_TB, &o, nullptr, ndev, devs);
 	if (r) return r;
-	if (afterUpdate_) asif_hip_update_options(batch_, &o); // same trajectory length as the host object
+	if (afterUpdate_) asif_hip_multi_update_options(batch_, &o); // same trajectory length as the host object
 	asif_hip_dims d;
-	asif_hip_get_dims(batch_, &d);
+	asif_hip_get_dims(asif_hip_multi_handle(batch_, 0), &d);
 	if ((uint32_t)d.nx != nx_ || (uint32_t)d.nu != nu_ || (uint32_t)d.nc != npTC_) {
-		asif_hip_destroy(batch_);
+		asif_hip_multi_destroy(batch_);
 		batch_ = nullptr;
 		return ASIF_HIP_EINVAL;
 	}
@@ -759,7 +773,7 @@ int32_t ASIFimplicitTB::filterBatch(int64_t B, const double x[], const double uD
                                     int32_t rc[])
 {
 	if (!batch_) return ASIF_HIP_EINVAL;
-	return asif_hip_filter_batch_host(batch_, B, x, uDes, uAct, relax, rc);
+	return asif_hip_filter_batch_host_multi(batch_, B, x, uDes, uAct, relax, rc);
 }
 
 } // namespace ASIF

@@ -24,7 +24,7 @@ ASIF::ASIF(const uint32_t nx, const uint32_t nu, const uint32_t npSS, SafetySetF
 ASIF::~ASIF(void)
 {
 	delete QPsolver_;
-	if (batch_) asif_hip_destroy(batch_);
+	if (batch_) asif_hip_multi_destroy(batch_);
 }
 
 int32_t ASIF::initialize(const double lb[], const double ub[])
@@ -127,7 +127,7 @@ int32_t ASIF::updateOptions(void)
 			o.lb[j] = lb_[j];
 			o.ub[j] = ub_[j];
 		}
-		asif_hip_update_options(batch_, &o);
+		asif_hip_multi_update_options(batch_, &o);
 	}
 	return 1;
 }
@@ -177,8 +177,15 @@ void ASIF::inputSaturate(double u[])
 
 int32_t ASIF::bindDeviceModel(int model, int device)
 {
+	const int32_t devs[1] = {device};
+	return bindDeviceModel(model, 1, devs);
+}
+
+// several GPUs: filterBatch() cuts the batch into contiguous blocks, one per entry of devs (asif_hip_create_multi)
+int32_t ASIF::bindDeviceModel(int model, int32_t ndev, const int32_t devs[])
+{
 	if (batch_) {
-		asif_hip_destroy(batch_);
+		asif_hip_multi_destroy(batch_);
 		batch_ = nullptr;
 	}
 	asif_hip_options o;
@@ -192,12 +199,12 @@ int32_t ASIF::bindDeviceModel(int model, int device)
 		o.lb[j] = lb_[j];
 		o.ub[j] = ub_[j];
 	}
-	r = asif_hip_create(&batch_, model, ASIF_HIP_EXPLICIT, &o, nullptr, device);
+	r = asif_hip_create_multi(&batch_, model, ASIF_HIP_EXPLICIT, &o, nullptr, ndev, devs);
 	if (r) return r;
 	asif_hip_dims d;
-	asif_hip_get_dims(batch_, &d);
+	asif_hip_get_dims(asif_hip_multi_handle(batch_, 0), &d);
 	if ((uint32_t)d.nx != nx_ || (uint32_t)d.nu != nu_ || (uint32_t)d.nc != nc_) {
-		asif_hip_destroy(batch_);
+		asif_hip_multi_destroy(batch_);
 		batch_ = nullptr;
 		return ASIF_HIP_EINVAL;
 	}
@@ -207,7 +214,7 @@ int32_t ASIF::bindDeviceModel(int model, int device)
 int32_t ASIF::filterBatch(int64_t B, const double x[], const double uDes[], double uAct[], double relax[], int32_t rc[])
 {
 	if (!batch_) return ASIF_HIP_EINVAL;
-	return asif_hip_filter_batch_host(batch_, B, x, uDes, uAct, relax, rc);
+	return asif_hip_filter_batch_host_multi(batch_, B, x, uDes, uAct, relax, rc);
 }
 
 } // namespace ASIF

@@ -1,6 +1,6 @@
 // di_robust.cpp -- ASIF::ASIFrobust exactly as examples/DoubleIntegrator_Robust.cpp:17-90 sets it up (interval mass,
 // gain and friction, safety set = the half-planes of include/KernelData_*.h, npSSmax = 5), the half-planes read from
-// a text file ("N" then N lines "a0 a1"; tests write it from tests/golden/robust_halfplanes.json).
+// a text file ("N" then N lines "a0 a1"; tests write it from asif_amd/data/robust_halfplanes.json).
 // Single-agent filter() (host affine arithmetic, the full 22-variable QP on the GPU's wave-per-QP kernel) next to
 // filterBatch() on the same states, which are read from stdin as "x0 x1 uDes" lines.
 //   usage: di_robust halfplanes.txt < states.txt

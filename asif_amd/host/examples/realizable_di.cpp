@@ -1,6 +1,6 @@
 // realizable_di.cpp -- ASIF::ASIFrealizable on the model of examples/DoubleIntegrator_RealizableSampled.cpp:16-54
 // (interval mass, gain and friction) over a polytopic kernel read from a text file (the numbers of
-// include/RealizableKernelData_*.h; tests write it from tests/golden/realizable_kernels.json):
+// include/RealizableKernelData_*.h; tests write it from asif_amd/data/realizable_kernels.json):
 //     nVertices nFacets maxCriticalFacets maxActiveConstraints
 //     nVertices lines  x y
 //     nFacets lines    v0 v1  n0 n1  a_0 .. a_{maxActive-1}

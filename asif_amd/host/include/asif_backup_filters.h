@@ -105,6 +105,7 @@ public:
 
 	// with options.use_learning the weights of learning_data_ are uploaded too (fill it first)
 	int32_t bindDeviceModel(int asif_hip_model_id, int device = 0);
+	int32_t bindDeviceModel(int asif_hip_model_id, int32_t ndev, const int32_t devs[]); // one block of the batch per entry
 	int32_t filterBatch(int64_t B, const double x[], const double uDes[], double uAct[], double relax[], int32_t rc[]);
 
 protected:
@@ -120,7 +121,7 @@ protected:
 	QPWrapperAbstract *QPsolver_;
 	uint32_t npBT_;
 	std::vector<double> H_, c_, A_, b_, lb_, ub_;
-	asif_hip_ctx *batch_;
+	asif_hip_multi *batch_;
 };
 
 class ASIFimplicitTB : public BackupLoopHost {
@@ -163,6 +164,7 @@ public:
 	double TTS_, BTorthoBS_, hBackupEnd_, hSafetyNow_;
 
 	int32_t bindDeviceModel(int asif_hip_model_id, int device = 0);
+	int32_t bindDeviceModel(int asif_hip_model_id, int32_t ndev, const int32_t devs[]); // one block of the batch per entry
 	int32_t filterBatch(int64_t B, const double x[], const double uDes[], double uAct[], double relax[], int32_t rc[]);
 
 protected:
@@ -179,7 +181,7 @@ protected:
 	uint32_t npBT_;
 	bool afterUpdate_;
 	std::vector<double> H_, c_, A_, b_, lb_, ub_;
-	asif_hip_ctx *batch_;
+	asif_hip_multi *batch_;
 };
 
 } // namespace ASIF

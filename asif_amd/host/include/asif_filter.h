@@ -46,6 +46,7 @@ public:
 	// Binds the compiled device model that corresponds to the host callbacks (e.g.
 	// ASIF_HIP_MODEL_DOUBLE_INTEGRATOR for examples/DoubleIntegrator.cpp).  Returns 0 or an asif_hip error.
 	int32_t bindDeviceModel(int asif_hip_model_id, int device = 0);
+	int32_t bindDeviceModel(int asif_hip_model_id, int32_t ndev, const int32_t devs[]); // one block of the batch per entry
 	// B independent filter() calls on HOST structure-of-arrays buffers x[nx][B], uDes[nu][B] ->
 	// uAct[nu][B], relax[B], rc[B] (reference return codes; untouched slots stay untouched).
 	int32_t filterBatch(int64_t B, const double x[], const double uDes[], double uAct[], double relax[], int32_t rc[]);
@@ -63,7 +64,7 @@ protected:
 	QPWrapperAbstract *QPsolver_;
 	std::vector<double> H_, c_, A_, b_, lb_, ub_;
 	const double *LfhUser_, *LghUser_; // caller-owned overrides, retained like the reference (src/asif.cpp:137-139)
-	asif_hip_ctx *batch_;
+	asif_hip_multi *batch_;
 };
 
 } // namespace ASIF

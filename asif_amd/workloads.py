@@ -73,13 +73,12 @@ def make_learning(nx=2, nu=1, hidden=(16, 16), amp=0.2, bias=0.05, seed=11):
 
 
 def load_kernel(name="100Hz", path=None):
-    """Polytope data of the reference's include/RealizableKernelData_<name>.h (numbers only, kept as a JSON
-    fixture under tests/golden/realizable_kernels.json) as the dict asif_amd.capi.RealizableFilter takes."""
+    """Polytope data of the reference's include/RealizableKernelData_<name>.h (numbers only, the package's own
+    asif_amd/data/realizable_kernels.json) as the dict asif_amd.capi.RealizableFilter takes."""
     import json
     import os
     if path is None:
-        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
-                            "realizable_kernels.json")
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "realizable_kernels.json")
     with open(path) as f:
         k = json.load(f)["kernels"][name]
     return dict(vertices=np.array(k["vertices"], dtype=np.float64),
@@ -90,13 +89,12 @@ def load_kernel(name="100Hz", path=None):
 
 
 def load_halfplanes(name="70-135kg", path=None):
-    """SafetySetData of the reference's include/KernelData_<name>.h ([N,2] float64), kept as numbers under
-    tests/golden/robust_halfplanes.json."""
+    """SafetySetData of the reference's include/KernelData_<name>.h ([N,2] float64), kept as numbers in the
+    package's own asif_amd/data/robust_halfplanes.json."""
     import json
     import os
     if path is None:
-        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
-                            "robust_halfplanes.json")
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "robust_halfplanes.json")
     with open(path) as f:
         return np.array(json.load(f)["sets"][name], dtype=np.float64)
 

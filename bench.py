@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- QP solves/s of the batched CBF-QP filter() hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2..10] [--batch B] [--kernel 100Hz]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2..10|qp] [--batch B] [--kernel 100Hz]
                     [--presolve 1] [--polish 0|1|2] [--no-cpu-baseline] [--no-pcie]
+                    [--shape c2|c3|c4|c5full|rz38|rz62|rz86] [--lanes 64]       (with --config qp)
 
-One "step" = one pass of the filter (constraint assembly + in-kernel ADMM solve + saturation + return
+One "step" = one pass of the filter (constraint assembly + in-kernel solve + saturation + return
 code) over one batch of synthetic states that is already resident in HBM when the timed region starts.
+`value` is therefore KERNEL-ONLY (inputs and outputs in HBM); the transfer-inclusive rate of SURVEY 8(d)
+(H2D + kernels + D2H of the same batch from host buffers) is reported beside it as `pcie_inclusive`, never as `value`.
 Default workload: BASELINE.json configs[1] -- DoubleIntegrator explicit CBF, batch 65 536 per GPU.
-N > 1: one process per GPU (torchrun), the batch axis is sharded -- every rank owns its own slice of
-the seeded instance stream (weak scaling), no data-path collective; torch.distributed (RCCL) is used
-only for the barrier and the max-over-ranks of the elapsed time.
+N > 1: one process per GPU, the batch axis is sharded -- every rank owns its own slice of the seeded instance
+stream (weak scaling), no data-path collective and no RCCL at all: the barrier around the timed region and the
+max-over-ranks of the elapsed time go over a gloo (TCP, host) process group.  Started by torchrun (RANK / LOCAL_RANK /
+WORLD_SIZE in the environment) or, when those are absent and --gpus N > 1, by this script spawning its N ranks as
+child processes before anything touches a GPU.
+--config qp: asif_hip_qp_solve_batch on pre-assembled problems of one shape (SURVEY 8d's second byte model).
 
 Prints ONE JSON line on rank 0.
 """
@@ -28,6 +34,11 @@ sys.path.insert(0, ROOT)
 from asif_amd import capi, dist, workloads  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+SHADER_CLOCK_HZ = 2.4e9  # MI355X peak engine clock
+N_SIMD = 256 * 4
+VALU_ISSUE_CYCLES = 4    # one wave's FP64 / FP32 vector instruction occupies its SIMD's issue for 4 cycles
+                         # (MI355X_MICROARCH.md, row "vector-instruction ISSUE cost"; FP64 FMA: 16 lanes per cycle)
+PROFILE_ROUND = "r02"
 
 # algorithmic HBM bytes per instance of the state->input path: read 8(nx+nu), write 8(nu+nrelax)+4
 ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44, 6: 52, 7: 44, 8: 44, 9: 52, 10: 52}
@@ -56,6 +67,16 @@ def rb_options(lib_module, model, variant):
         o.x_unc[i] = v
     o.use_learning = 1
     return o
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def host_cores():
@@ -96,6 +117,7 @@ def cpu_baseline_handle(cfg, data_name, gpu_uact, gpu_rc, x, udes):
     ok = rc == 1
     err = float(np.abs(gpu_uact[0, :m][ok] - ue[ok, 0]).max()) if ok.any() else 0.0
     return ({"value": n / dt, "unit": "QP solves/s", "cores": cores, "kind": "port",
+             "cpu_model": cpu_model(), "single_thread_value": 1.0 / per,
              "sample": f"{n} instances of the same seeded workload, {what} restatement + OSQP-style ADMM on "
                        f"the full {z.nv}x{z.nc} QP (eps 1e-3, max_iter 2000, cold start, {per * 1e6:.1f} us per "
                        f"filter() on one core) over {cores} host threads"},
@@ -133,9 +155,10 @@ def cpu_baseline(cfg, gpu_uact, gpu_rc, x, udes):
     err = float(np.abs(gpu_uact[:, :m].T[ok] - ua[ok]).max()) if ok.any() else 0.0
     mism = int((rc != gpu_rc[:m]).sum())
     return ({"value": n / dt, "unit": "QP solves/s", "cores": cores, "kind": "port",
+             "cpu_model": cpu_model(), "single_thread_value": 1.0 / per,
              "sample": f"{n} instances of the same seeded workload, OSQP-style ADMM restatement "
                        f"(eps 1e-3, max_iter 2000, cold start, {per * 1e6:.2f} us per filter() on one core) "
-                       f"over {cores} host threads"},
+                       f"over {cores} host threads; OSQP itself is not in the image, this is the oracle's restatement"},
             {"max_abs_u_err_vs_exact": err, "rc_mismatches": mism, "checked_instances": m})
 
 
@@ -167,12 +190,219 @@ def pcie_inclusive(flt, x, udes, rc_dev, uact_dev, reps=20):
     return res
 
 
+def profile_numbers(tag):
+    """Counter-derived numbers of the committed rocprofv3 passes of this command (profiles/<round>/): PMC passes cannot
+    run inside this process.  Returns (traffic_bytes_per_step, sq summary dict or None, source string)."""
+    traffic, sq, src = None, None, None
+    base = os.path.join(ROOT, "profiles", PROFILE_ROUND)
+    f = os.path.join(base, f"{tag}_pmc_summary.json")
+    if os.path.isfile(f):
+        traffic = json.load(open(f)).get("traffic_bytes_per_step")
+        src = f"profiles/{PROFILE_ROUND}/{tag}_pmc_summary.json"
+    f = os.path.join(base, f"{tag}_sq_summary.json")
+    if os.path.isfile(f):
+        sq = json.load(open(f))
+    return traffic, sq, src
+
+
+def valu_roofline(sq, step_ms, tag):
+    """The bound that binds this path: vector-ALU issue.  issued wave-instructions (SQ_INSTS_VALU, all kernels of one
+    step, from the committed PMC pass) x 4 issue cycles / (SIMDs x shader cycles of the measured step)."""
+    if not sq or not sq.get("insts_valu_per_step") or step_ms <= 0:
+        return None
+    avail = N_SIMD * SHADER_CLOCK_HZ * step_ms * 1e-3
+    used = sq["insts_valu_per_step"] * VALU_ISSUE_CYCLES
+    return {"bound": "valu-issue", "insts_valu_per_step": sq["insts_valu_per_step"],
+            "waves_per_step": sq.get("waves_per_step"), "insts_valu_per_wave": sq.get("insts_valu_per_wave"),
+            "issue_cycles_per_inst": VALU_ISSUE_CYCLES, "simd_cycles_available": avail, "frac": used / avail,
+            "counters_source": f"profiles/{PROFILE_ROUND}/{tag}_sq_summary.json (rocprofv3 --pmc, separate pass of the "
+                               "same command); duration measured live",
+            "note": "frac = share of all SIMD issue slots of the chip used by vector instructions over the step; "
+                    "with one wave per SIMD a dependent FP64 chain issues at best every ~8 cycles, so ~0.5 is the "
+                    "ceiling of a latency-bound kernel at this batch size"}
+
+
+def spawn_ranks(n):
+    """--gpus N without a launcher: start the N ranks as fresh child processes (nothing has touched a GPU yet in this
+    one), hand them the torchrun environment, pass rank 0's JSON line through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = rc or pr.wait()
+    sys.exit(rc)
+
+
+QP_SHAPES = {  # --config qp: (filter config whose rows are solved, nv, nc, SURVEY 8(d) bytes per instance)
+    "c2": (2, 2, 4, 164), "c3": (3, 3, 41, 1436), "c4": (4, 2, 18, 500), "c5full": (5, 18, 12, 2548),
+}
+
+
+def qp_problem(cfg, B, dev, first=0):
+    """Pre-assembled QPs of a filter config, built with the product's own rows kernel (asif_hip_assemble_batch) and the
+    cost / bounds the class's initialize() / updateCost() set -- no oracle involved."""
+    model, variant, _ = capi.CONFIGS[cfg]
+    flt = capi.Filter(model, variant, device=dev.index)
+    d, o = flt.dims, flt.options
+    x, udes = workloads.make_batch(cfg, B, first=first)
+    tx = torch.from_numpy(x).to(dev)
+    A = torch.zeros((d.nc * d.nv, B), dtype=torch.float64, device=dev)
+    b = torch.zeros((d.nc, B), dtype=torch.float64, device=dev)
+    code = torch.zeros(B, dtype=torch.int32, device=dev)
+    flt.assemble(tx, A, b, code)
+    torch.cuda.synchronize()
+    flt.close()
+    keep = np.isin(code.cpu().numpy(), (1, 2))  # TB: instances that never reach the backup set have no QP
+    idx = np.where(keep)[0]
+    sel = torch.from_numpy(idx[np.arange(B) % len(idx)]).to(dev)  # tiled back up to B problems
+    A, b = A[:, sel].contiguous(), b[:, sel].contiguous()
+    u = torch.from_numpy(udes).to(dev)[:, sel]
+    nv = d.nv
+    Hd = torch.zeros((nv, B), dtype=torch.float64, device=dev)
+    c = torch.zeros((nv, B), dtype=torch.float64, device=dev)
+    lb = torch.zeros((nv, B), dtype=torch.float64, device=dev)
+    ub = torch.full((nv, B), o.inf, dtype=torch.float64, device=dev)
+    Hd[0], c[0], lb[0], ub[0] = 1.0, -2.0 * u[0], o.lb[0], o.ub[0]
+    be = None
+    if cfg == 2:    # src/asif.cpp:84-98: delta pinned
+        Hd[1], c[1], lb[1], ub[1] = o.relaxCost, -2.0 * o.relaxCost * o.relaxLb, o.relaxLb, o.relaxLb
+    elif cfg == 3:  # src/asif_implicit.cpp:237-254
+        Hd[1:3] = o.relaxCost
+        c[1], c[2] = -2.0 * o.relaxCost * o.relaxLb, -2.0 * o.relaxCost * o.relaxReachLb
+        lb[1], lb[2] = o.relaxLb, o.relaxReachLb
+    elif cfg == 4:  # src/asif_implicit_tb.cpp:198-210
+        Hd[1], c[1], lb[1] = o.relaxCost, -2.0 * o.relaxCost * o.relaxLb, o.relaxLb
+    elif cfg == 5:  # src/asif_robust.cpp:89-148: zero cost on the multipliers, two of three rows equalities
+        Hd[1], c[1], lb[1] = o.relaxCost, -2.0 * o.relaxCost * o.relaxLb, o.relaxLb
+        be = [(i % 3) != 0 for i in range(d.nc)]
+    return dict(Hd=Hd, c=c, A=A, b=b, lb=lb, ub=ub, be=be, x=x[:, idx[np.arange(B) % len(idx)]],
+                udes=udes[:, idx[np.arange(B) % len(idx)]], nv=nv, nc=d.nc)
+
+
+def bench_qp(args, grp, dev):
+    """asif_hip_qp_solve_batch on one shape: the QPWrapperAbstract path (initialize + solve + getSolution, cold start)
+    for a batch of pre-assembled problems resident in HBM.  Algorithmic bytes per instance:
+    read 8 (nv + nv + nc nv + nc + 2 nv), write 8 nv + 4."""
+    import ctypes as C
+    cfg, nv, nc, alg = QP_SHAPES[args.shape]
+    B = args.batch or {"c2": 65536, "c3": 16384, "c4": 32768, "c5full": 8192}[args.shape]
+    first, count = grp.shard(B)
+    q = qp_problem(cfg, count, dev, first)
+    assert alg == 8 * (nv + nv + nc * nv + nc + 2 * nv) + 8 * nv + 4
+    solver = capi.default_solver(lanes_per_qp=args.lanes)
+    if args.polish >= 0:
+        solver.polish = args.polish
+    sol = torch.zeros((nv, B), dtype=torch.float64, device=dev)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    iters = torch.zeros(B, dtype=torch.int32, device=dev)
+    bep = None
+    if q["be"] is not None:
+        arr = (C.c_uint8 * nc)(*[int(v) for v in q["be"]])
+        bep = C.cast(arr, C.c_void_p)
+    lib = capi.load()
+    stream = torch.cuda.current_stream()
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    call = (dev.index, C.byref(solver), C.c_int64(B), C.c_int64(q["c"].stride(0)), nv, nc, ptr(q["Hd"]), ptr(q["c"]),
+            ptr(q["A"]), ptr(q["b"]), ptr(q["lb"]), ptr(q["ub"]), bep, ptr(sol), ptr(status), ptr(iters),
+            C.c_void_p(stream.cuda_stream))
+
+    def step():
+        r = lib.asif_hip_qp_solve_batch(*call)
+        if r != 0:
+            capi.check(r)
+
+    for _ in range(args.warmup):
+        step()
+    grp.barrier()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+    hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+    ev = [C.c_void_p(), C.c_void_p()]
+    for e in ev:
+        assert hip.hipEventCreate(C.byref(e)) == 0
+    sptr = C.c_void_p(stream.cuda_stream)
+    t0 = time.perf_counter()
+    hip.hipEventRecord(ev[0], sptr)
+    for _ in range(args.steps):
+        step()
+    hip.hipEventRecord(ev[1], sptr)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    grp.barrier()
+    elapsed = grp.max_over_ranks(t1 - t0)
+    ms = C.c_float()
+    assert hip.hipEventElapsedTime(C.byref(ms), ev[0], ev[1]) == 0
+    step_ms = ms.value / max(args.steps, 1)
+    st = status.cpu().numpy()
+    it = iters.cpu().numpy()
+    kernel = ("wave-per-QP, plain ADMM (admm_wave.hpp)" if (args.lanes == 64 and solver.polish == 0)
+              else "wave-per-QP, factor in LDS (qp_lds.hpp)" if (args.lanes == 64 or nv > 3)
+              else "in-register (gi_small.hpp + admm_small.hpp)")
+    tag = f"qp_{args.shape}" + ("_wave" if args.lanes == 64 else "") + (f"_polish{solver.polish}" if args.polish >= 0 else "")
+    traffic, sq, src = profile_numbers(tag)
+    achieved = alg * B / (step_ms * 1e-3) / 1e9
+    out = {"metric": "QP solves/sec (asif_hip_qp_solve_batch, pre-assembled)", "value": B * grp.world * args.steps / elapsed,
+           "unit": "QP solves/s", "n_gpus": grp.world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"pre-assembled QPs of {WORKLOAD[cfg]}: nv={nv} nc={nc}", "batch_per_gpu": B,
+                      "kernel": kernel, "solver": {"polish": solver.polish, "iterations_mean": float(it.mean()),
+                                                   "iterations_max": int(it.max())},
+                      "status_histogram": {str(int(k)): int(v) for k, v in zip(*np.unique(st, return_counts=True))}},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                        "kernel_avg_us": step_ms * 1e3, "algorithmic_bytes_per_launch": alg * B,
+                        "algorithmic_bytes_per_instance": alg, "valu": valu_roofline(sq, step_ms, tag)},
+           "cpu_baseline": None}
+    if grp.rank == 0 and grp.world == 1 and not args.no_cpu_baseline:
+        # the oracle as checker + baseline: exact optimum of the same problems (u, delta), OSQP-style ADMM timed
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        O.build()
+        m = min(B, 2048)
+        host = {k: np.ascontiguousarray(q[k][:, :m].cpu().numpy().T) for k in ("Hd", "c", "A", "b", "lb", "ub")}
+        be = np.array(q["be"], dtype=np.uint8) if q["be"] is not None else None
+        t = time.perf_counter()
+        O.qp_solve_batch(nv, nc, host["Hd"], host["c"], host["A"], host["b"], host["lb"], host["ub"], be, O.SOLVER_ADMM)
+        per = (time.perf_counter() - t) / m
+        out["cpu_baseline"] = {"value": 1.0 / per, "unit": "QP solves/s", "cores": 1, "kind": "port",
+                               "cpu_model": cpu_model(), "single_thread_value": 1.0 / per,
+                               "sample": f"{m} of the same problems, OSQP-style ADMM restatement (eps 1e-3, max_iter 2000, "
+                                         f"cold start) on one host thread"}
+        if nv <= 3:
+            ex, stex, _ = O.qp_solve_batch(nv, nc, host["Hd"], host["c"], host["A"], host["b"], host["lb"], host["ub"], be,
+                                           O.SOLVER_EXACT)
+            ok = stex == 1
+            g = sol[:, :m].cpu().numpy().T
+            out["parity"] = {"status_mismatches": int(((st[:m] == 1) != ok).sum()),
+                             "max_abs_err_vs_exact": float(np.abs(g[ok] - ex[ok]).max()), "checked_instances": m}
+        else:
+            model, variant = O.CONFIGS[cfg]
+            ua, rl, rc = O.filter_batch(model, variant, O.default_options(model, variant),
+                                        np.ascontiguousarray(q["x"][:, :m].T), np.ascontiguousarray(q["udes"][:, :m].T))
+            g = sol[:, :m].cpu().numpy().T
+            out["parity"] = {"status_mismatches": int((st[:m] != rc).sum()),
+                             "max_abs_err_vs_exact": float(np.abs(g[:, 0] - ua[:, 0]).max()), "checked_instances": m}
+    if grp.rank == 0:
+        print(json.dumps(out))
+    grp.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--config", default="2", help="2..10: filter configs; qp: pre-assembled QPs (see --shape)")
+    ap.add_argument("--shape", default="c2", choices=sorted(QP_SHAPES), help="--config qp: which problems")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--kernel", default="100Hz", help="config 6: RealizableKernelData_<name> polytope")
@@ -186,15 +416,22 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
     args = ap.parse_args()
 
-    # ASIF_BENCH_REHEARSAL=1: rehearse the N>1 code path on a one-GPU box (gloo rendezvous, every rank
-    # on cuda:0); never set by the driver.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)  # does not return
+    if int(os.environ.get("WORLD_SIZE", "1")) != max(args.gpus, 1):
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: start it as "
+                 f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                 f"bench.py --gpus {args.gpus} ...` or without a launcher")
+    # ASIF_BENCH_REHEARSAL=1: rehearse the N>1 code path on a one-GPU box (every rank on cuda:0); never set by
+    # the driver.
     rehearsal = os.environ.get("ASIF_BENCH_REHEARSAL") == "1"
-    grp = dist.Group(backend="gloo" if rehearsal else "nccl")
-    if grp.world == 1:
-        torch.cuda.set_device(0)
+    grp = dist.Group(backend="gloo")  # barrier + max of the elapsed time over TCP on the host: no RCCL anywhere
     dev = torch.device("cuda", grp.local_rank if (grp.world > 1 and not rehearsal) else 0)
+    torch.cuda.set_device(dev)
+    if args.config == "qp":
+        return bench_qp(args, grp, dev)
 
-    cfg = args.config
+    cfg = int(args.config)
     solver = capi.default_solver(lanes_per_qp=args.lanes, presolve=args.presolve)
     if args.polish >= 0:
         solver.polish = args.polish
@@ -268,7 +505,7 @@ def main():
     torch.cuda.synchronize()  # this rank's K steps are done: stop its clock, then meet the others
     t1 = time.perf_counter()
     grp.barrier()
-    elapsed = grp.max_over_ranks(t1 - t0, device=dev if (grp.world > 1 and not rehearsal) else None)
+    elapsed = grp.max_over_ranks(t1 - t0)
     ms = C.c_float()
     assert hip.hipEventElapsedTime(C.byref(ms), ev[0], ev[1]) == 0
     for e in ev:
@@ -283,18 +520,23 @@ def main():
     rc_host = rc.cpu().numpy()
     solved_mask = np.isin(rc_host, (1, 2, -1))
     solved = int(solved_mask.sum())  # instances whose QP was solved (or found infeasible)
-    value = B * grp.world * args.steps / elapsed
+    # "QP solves" counts the instances whose filter() went through a QP (rc 1, 2, -1); TB instances that never reach the
+    # backup set (rc -3) are filtered without one and count only in instances_per_s
+    solved_all = grp.sum_over_ranks(solved)
+    value = solved_all * args.steps / elapsed
+    instances_per_s = B * grp.world * args.steps / elapsed
     alg_bytes = ALG_BYTES[cfg] * B
     achieved = alg_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
-    # HBM traffic per launch: rocprofv3 PMC passes cannot run inside this process; the number comes from
-    # the committed summary of the same command (profiles/, FETCH_SIZE x2 + WRITE_SIZE, in bytes)
-    traffic = None
+    # HBM traffic and instruction counts per step: rocprofv3 PMC passes cannot run inside this process; the numbers
+    # come from the committed summaries of the same command (profiles/<round>/) and are labelled as such
     tag = f"c{cfg}"
     if cfg == 2 and args.presolve:
         tag, default_b = "c2pre", 4194304  # the closed-form path was profiled at the HBM-bound batch size
-    pmc = os.path.join(ROOT, "profiles", "r01", f"{tag}_pmc_summary.json")
-    if B == default_b and os.path.isfile(pmc) and (cfg != REALIZABLE_CFG or args.kernel == "100Hz"):
-        traffic = json.load(open(pmc)).get("traffic_bytes_per_step")  # all kernels of one step
+    if args.polish >= 0 and args.polish != 2:
+        tag += f"polish{args.polish}"
+    traffic, sq, traffic_src = (None, None, None)
+    if B == default_b and (cfg != REALIZABLE_CFG or args.kernel == "100Hz"):
+        traffic, sq, traffic_src = profile_numbers(tag)
     out = {
         "metric": "QP solves/sec (batched filter())",
         "value": value,
@@ -311,18 +553,23 @@ def main():
         "config": {"workload": WORKLOAD[cfg], "batch_per_gpu": B, "sharding": "instances, no collective",
                    "lanes_per_qp": args.lanes or "default",
                    "presolve": args.presolve,
-                   # how the QPs were decided: the solver first tries a primal-dual active-set attempt from the empty
-                   # working set (polish 2), then OSQP-style ADMM iterations with the same attempt at every check
+                   # how the QPs were decided: polish 2 runs the in-register dual active-set stage first, then OSQP-style
+                   # ADMM iterations (with an active-set finish at every check) for what it leaves undecided
                    "solver": {"polish": solver.polish,
                               "admm_iterations_mean": float(iters_host[solved_mask].mean()) if solved else 0.0,
                               "admm_iterations_max": float(iters_host[solved_mask].max()) if solved else 0.0,
                               "decided_before_first_iteration": float((iters_host[solved_mask] == 0).mean()) if solved else 0.0},
                    "rc_histogram": {str(int(k)): int(v) for k, v in zip(*np.unique(rc_host, return_counts=True))},
-                   "qp_solved_fraction": solved / B},
+                   "qp_solved_fraction": solved / B,
+                   "value_definition": "kernel-only, inputs and outputs resident in HBM; instances whose filter() solved a "
+                                       "QP (rc 1, 2, -1) per second; transfer-inclusive rate: pcie_inclusive"},
+        "instances_per_s": instances_per_s,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel_avg_us": step_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "FP64-VALU/latency bound by design (44-60 algorithmic bytes per instance); see DESIGN.md"},
+                     "valu": valu_roofline(sq, step_ms, tag),
+                     "note": "HBM is the mandated roofline and not the one that binds: 44-60 algorithmic bytes against "
+                             "10^3-10^6 FP64 operations per instance; see `valu` and DESIGN.md"},
     }
     if grp.rank == 0 and grp.world == 1 and not args.no_cpu_baseline:
         if cfg in (REALIZABLE_CFG, ROBUST_DATA_CFG):

@@ -321,6 +321,25 @@ int asif_hip_qp_solve_batch_dense(int device, const asif_hip_solver *solver, int
 int asif_hip_filter_batch_host(asif_hip_ctx *ctx, int64_t B, const double *x, const double *udes, double *uact,
                                double *relax, int32_t *rc);
 
+/* ---- several GPUs of one node behind one call (BASELINE.json config 4: 262 144 agents over 8 GPUs) ----
+ * The batch is cut into contiguous blocks, one per entry of the device list (remainder to the first blocks:
+ * asif_hip_partition); every block is uploaded, filtered and downloaded by its own host thread on its own stream.
+ * Instances are independent, so there is no collective and no device-to-device traffic: the result arrays are the
+ * caller's, each block lands at its own offset.  Results are bitwise those of one handle.  A device may be listed
+ * more than once (two streams on one GPU).  asif_hip_create_multi = asif_hip_create once per entry. */
+typedef struct asif_hip_multi asif_hip_multi;
+int asif_hip_partition(int64_t B, int32_t nblocks, int32_t r, int64_t *first, int64_t *count); /* pure arithmetic */
+int asif_hip_create_multi(asif_hip_multi **out, int model, int variant, const asif_hip_options *opts,
+                          const asif_hip_solver *solver, int32_t ndev, const int32_t *devs);
+int asif_hip_multi_destroy(asif_hip_multi *m);
+int asif_hip_multi_size(const asif_hip_multi *m);
+asif_hip_ctx *asif_hip_multi_handle(asif_hip_multi *m, int32_t i); /* e.g. for asif_hip_get_dims / _set_learning */
+int asif_hip_multi_update_options(asif_hip_multi *m, const asif_hip_options *opts);
+/* = asif_hip_filter_batch_host over all handles: HOST buffers x[nx][B], udes[nu][B], uact[nu][B], relax[nrelax][B],
+ * rc[B] (pinned or pageable), blocking. */
+int asif_hip_filter_batch_host_multi(asif_hip_multi *m, int64_t B, const double *x, const double *udes, double *uact,
+                                     double *relax, int32_t *rc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate the realizable-filter fixtures.  Runs only where /root/reference exists.  TEST INFRASTRUCTURE.
 
-  tests/golden/realizable_kernels.json   the polytope DATA of include/RealizableKernelData_*.h (numbers only:
+  asif_amd/data/realizable_kernels.json   the polytope DATA of include/RealizableKernelData_*.h (numbers only:
                                          vertices, facet vertex indexes, normals, active sets, the two limits)
   tests/golden/affa_rz_facet_lie.json    interval Lie derivatives over every (facet, active constraint) pair
                                          and point-state dynamics midpoints, computed by the REFERENCE's libaffa
@@ -40,7 +40,7 @@ def main():
     rl = O.ref_lib()
     assert rl is not None, "oracle/_ref not built (reference tree missing?)"
     kernels = {n: parse_header(os.path.join(REF_INC, "RealizableKernelData_%s.h" % n)) for n in NAMES}
-    with open(os.path.join(GOLD, "realizable_kernels.json"), "w") as f:
+    with open(os.path.join(os.path.dirname(GOLD), "..", "asif_amd", "data", "realizable_kernels.json"), "w") as f:
         json.dump({"source": "include/RealizableKernelData_{%s}.h of the reference (data only)" % ",".join(NAMES),
                    "generator": "oracle/gen_realizable_golden.py", "kernels": kernels}, f)
     d = O.RzDesc()

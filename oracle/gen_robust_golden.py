@@ -2,7 +2,7 @@
 """Fixtures for the robust filter on the data the reference ships.  Runs only where /root/reference exists.
 TEST INFRASTRUCTURE.
 
-  tests/golden/robust_halfplanes.json   SafetySetData of include/KernelData_{70-135kg,70-75kg}.h (numbers only)
+  asif_amd/data/robust_halfplanes.json   SafetySetData of include/KernelData_{70-135kg,70-75kg}.h (numbers only)
   tests/golden/affa_di_robust_lie.json  interval Lie derivatives of examples/DoubleIntegrator_Robust.cpp at seeded
                                         point states for the npSSmax = 5 smallest-h half-planes, computed by the
                                         REFERENCE's libaffa (oracle/_ref, ref_di_robust_lie)
@@ -38,7 +38,7 @@ def main():
     rl = O.ref_lib()
     assert rl is not None, "oracle/_ref not built (reference tree missing?)"
     sets = {n: parse_header(os.path.join(REF_INC, "KernelData_%s.h" % n)) for n in NAMES}
-    with open(os.path.join(GOLD, "robust_halfplanes.json"), "w") as f:
+    with open(os.path.join(os.path.dirname(GOLD), "..", "asif_amd", "data", "robust_halfplanes.json"), "w") as f:
         json.dump({"source": "SafetySetData of include/KernelData_{%s}.h of the reference (data only)" % ",".join(NAMES),
                    "generator": "oracle/gen_robust_golden.py", "sets": sets}, f)
     d = O.RbDesc()

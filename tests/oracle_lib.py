@@ -271,9 +271,10 @@ class RzDesc(C.Structure):
 
 
 def load_kernel(name):
-    """Kernel polytope data of include/RealizableKernelData_<name>.h, from tests/golden/realizable_kernels.json."""
+    """Kernel polytope data of include/RealizableKernelData_<name>.h, from asif_amd/data/realizable_kernels.json
+    (model input data, the same file the product reads)."""
     import json
-    with open(os.path.join(ROOT, "tests", "golden", "realizable_kernels.json")) as f:
+    with open(os.path.join(ROOT, "asif_amd", "data", "realizable_kernels.json")) as f:
         k = json.load(f)["kernels"][name]
     return dict(vertices=np.array(k["vertices"], dtype=np.float64),
                 facetVertices=np.array(k["facetVertices"], dtype=np.int32),
@@ -393,9 +394,9 @@ class RbDesc(C.Structure):
 
 
 def load_halfplanes(name="70-135kg"):
-    """SafetySetData of include/KernelData_<name>.h ([N,2]), from tests/golden/robust_halfplanes.json."""
+    """SafetySetData of include/KernelData_<name>.h ([N,2]), from asif_amd/data/robust_halfplanes.json."""
     import json
-    with open(os.path.join(ROOT, "tests", "golden", "robust_halfplanes.json")) as f:
+    with open(os.path.join(ROOT, "asif_amd", "data", "robust_halfplanes.json")) as f:
         return np.array(json.load(f)["sets"][name], dtype=np.float64)
 
 

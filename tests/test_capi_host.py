@@ -78,3 +78,26 @@ def test_bad_arguments_are_rejected(capi):
     h = C.c_void_p()
     assert lib.asif_hip_create(C.byref(h), 0, 3, None, None, 0) != 0  # DoubleIntegrator has no robust variant
     assert not h.value
+
+
+def test_partition_arithmetic(capi):
+    """asif_hip_partition: contiguous blocks, remainder to the first ones, every instance exactly once."""
+    for B in (0, 1, 7, 8, 9, 65536, 262144, 262147):
+        for n in (1, 2, 3, 4, 8):
+            cuts = [capi.partition(B, n, r) for r in range(n)]
+            assert cuts[0][0] == 0 and sum(c for _, c in cuts) == B
+            for r in range(1, n):
+                assert cuts[r][0] == cuts[r - 1][0] + cuts[r - 1][1]
+            sizes = [c for _, c in cuts]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    assert capi.partition(262144, 8, 3) == (3 * 32768, 32768)  # BASELINE.json config 4
+    with pytest.raises(capi.AsifHipError):
+        capi.partition(10, 2, 2)
+
+
+def test_multi_create_without_gpu_fails_loudly(capi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.AsifHipError):
+        capi.MultiFilter(capi.MODEL_DOUBLE_INTEGRATOR, capi.EXPLICIT, [0, 1])

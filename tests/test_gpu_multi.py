@@ -1,0 +1,65 @@
+"""Several devices behind one call (asif_hip_filter_batch_host_multi): blocks of the batch on their own
+handles, host threads and streams.  On the one-GPU box the device list names device 0 several times -- the code path
+is the one an 8-GPU node takes (separate handles, threads, streams, staging, offsets); the result must be bitwise
+the single-handle result.  An N-GPU run proper needs an N-GPU node: unmeasured until the driver has one."""
+import numpy as np
+import pytest
+import torch
+
+import gpu_util
+from asif_amd import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_single(hip, cfg, x, udes, uact0, relax0):
+    model, variant, _ = hip.CONFIGS[cfg]
+    flt = hip.Filter(model, variant)
+    d = flt.dims
+    B = x.shape[1]
+    uact = np.full((d.nu, B), uact0)
+    relax = np.full((d.nrelax, B), relax0)
+    rc = np.zeros(B, dtype=np.int32)
+    import ctypes as C
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    hip.check(flt.lib.asif_hip_filter_batch_host(flt.handle, C.c_int64(B), p(x), p(udes), p(uact), p(relax), p(rc)))
+    flt.close()
+    return uact, relax, rc
+
+
+@pytest.mark.parametrize("cfg,B,ndev", [(2, 65536, 2), (2, 10007, 3), (4, 4099, 4), (3, 130, 2)])
+def test_multi_equals_single_bitwise(hip, cfg, B, ndev):
+    x, udes = workloads.make_batch(cfg, B)
+    x, udes = np.ascontiguousarray(x), np.ascontiguousarray(udes)
+    ua1, rl1, rc1 = _host_single(hip, cfg, x, udes, 7.0, -7.0)
+    model, variant, _ = hip.CONFIGS[cfg]
+    m = hip.MultiFilter(model, variant, [0] * ndev)
+    d = m.dims
+    ua = np.full((d.nu, B), 7.0)
+    rl = np.full((d.nrelax, B), -7.0)
+    rc = np.zeros(B, dtype=np.int32)
+    m.filter_host(x, udes, ua, rl, rc)
+    m.close()
+    assert np.array_equal(rc, rc1) and np.array_equal(ua, ua1) and np.array_equal(rl, rl1)
+    assert len(np.unique(rc)) >= 2  # more than one branch exercised, untouched slots included above
+
+
+def test_multi_matches_device_pointer_path(hip, oracle):
+    B = 8192
+    out = gpu_util.run_filter(2, B)
+    m = hip.MultiFilter(hip.MODEL_DOUBLE_INTEGRATOR, hip.EXPLICIT, [0, 0])
+    ua = np.zeros((1, B))
+    rl = np.zeros((1, B))
+    rc = np.zeros(B, dtype=np.int32)
+    m.filter_host(np.ascontiguousarray(out["x"]), np.ascontiguousarray(out["udes"]), ua, rl, rc)
+    m.close()
+    assert np.array_equal(rc, out["rc"]) and np.array_equal(ua, out["uact"])
+
+
+def test_more_blocks_than_instances(hip):
+    x, udes = workloads.make_batch(2, 3)
+    m = hip.MultiFilter(hip.MODEL_DOUBLE_INTEGRATOR, hip.EXPLICIT, [0] * 5)
+    ua, rl, rc = np.zeros((1, 3)), np.zeros((1, 3)), np.zeros(3, dtype=np.int32)
+    m.filter_host(np.ascontiguousarray(x), np.ascontiguousarray(udes), ua, rl, rc)
+    m.close()
+    assert set(rc.tolist()) <= {1, -1} and np.all(rc != 0)

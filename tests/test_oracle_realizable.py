@@ -1,5 +1,5 @@
 """CPU tests of the realizable-filter oracle (oracle/or_realizable.c) against the fixtures made from the
-reference's libaffa and kernel data (tests/golden/affa_rz_facet_lie.json, realizable_kernels.json)."""
+reference's libaffa and kernel data (tests/golden/affa_rz_facet_lie.json; asif_amd/data/realizable_kernels.json)."""
 import json
 import os
 

@@ -20,9 +20,54 @@ def pmc(tag, name):
     files = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", f"pmc_{name}", "**", "*counter_collection.csv"),
                       recursive=True)
     agg = collections.defaultdict(list)
+    if not files:
+        return agg
     for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
         agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return agg
+
+
+def pmc_multi(tag, name):
+    """several counters in one pass: {kernel: {counter: mean per launch}}, launches per kernel"""
+    files = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", f"pmc_{name}", "**", "*counter_collection.csv"),
+                      recursive=True)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not files:
+        return {}
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
+
+
+def sq_summary(tag, out, calls_per_kernel):
+    """<tag>_sq_summary.json: SQ counters per launch per kernel, and per bench step (kernels weighted by how often
+    one step launches them, from the kernel trace of the same command)."""
+    sq = pmc_multi(tag, "sq")
+    sq2 = pmc_multi(tag, "sq2")
+    kernels = {}
+    for k in sq:
+        if "asif" not in k:
+            continue
+        kernels[k] = dict(sq[k])
+        kernels[k].update(sq2.get(k, {}))
+    if not kernels:
+        return
+    steps = max(calls_per_kernel.values()) if calls_per_kernel else 1
+    valu = waves = 0.0
+    for k, c in kernels.items():
+        per_step = 1.0
+        for name, calls in calls_per_kernel.items():
+            if name.split("(")[0].strip() in k or k.split("(")[0].strip() in name:
+                per_step = calls / steps
+        c["launches_per_step"] = per_step
+        valu += c.get("SQ_INSTS_VALU", 0.0) * per_step
+        waves += c.get("SQ_WAVES", 0.0) * per_step
+    with open(os.path.join(out, f"{tag}_sq_summary.json"), "w") as f:
+        json.dump({"command": "tools/prof_cfg.sh (rocprofv3 --pmc SQ_*, two passes of <= 6 counters, no trace domain)",
+                   "unit": "wave-level instruction counts / SQ cycles summed over the chip, mean per launch",
+                   "kernels": kernels, "insts_valu_per_step": valu, "waves_per_step": waves,
+                   "insts_valu_per_wave": valu / waves if waves else None}, f, indent=1)
+    print(tag, "SQ_INSTS_VALU per step", round(valu), "waves", round(waves), "per wave", round(valu / waves) if waves else None)
 
 
 def main():
@@ -33,10 +78,22 @@ def main():
         db = os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "trace", "t_results.db")
         with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
             subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "rocprof_db_stats.py"), db], stdout=f)
+        calls = {}
+        for r in csv.DictReader(open(os.path.join(out, f"{tag}_kernel_stats.csv"))):
+            if "asif" in r["Name"]:
+                calls[r["Name"]] = int(r["Calls"])
+        demangled = {}
+        for name, c in calls.items():
+            try:
+                d = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name.replace(".kd", "")], text=True).strip()
+            except Exception:
+                d = name
+            demangled[d] = c
+        sq_summary(tag, out, demangled)
         fetch, write = pmc(tag, "fetch"), pmc(tag, "write")
         kernels = {}
         for k in fetch:
-            if "asif" not in k:
+            if "asif" not in k or k not in write:
                 continue
             fk, wk = sum(fetch[k]) / len(fetch[k]), sum(write[k]) / len(write[k])
             kernels[k] = {"FETCH_SIZE_KB_per_launch_raw": fk, "WRITE_SIZE_KB_per_launch_raw": wk,
