@@ -22,7 +22,17 @@ class Group:
             backend = backend or "gloo"
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
-            dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+            # gloo announces its connections on stdout; bench.py's stdout carries exactly one JSON line
+            import sys
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
             self.dist = dist
             self.backend = backend
 
