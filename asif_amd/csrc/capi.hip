@@ -800,20 +800,23 @@ static int stage_rows(asif_hip_ctx *ctx, FilterArgs &a)
 	return 0;
 }
 
-// The implicit rows kernel parks one state per block of kTrajBlock trajectory samples in HBM (pass 1) and
-// re-integrates the few blocks that hold the critical samples (pass 2); sized per handle, grown on demand.
+// The trajectory kernels keep checkpoints of the backup trajectory in HBM (pass 1) and re-integrate the few blocks
+// that hold the critical samples from them (pass 2); sized per handle, grown on demand.  Small states (nx = 2: the
+// pendulum and double-integrator models) keep only the npBTSS selected checkpoints, [npBTSS][nz + 2][ld]; the segway
+// (20-double state, 4-sample blocks) keeps one per block, [blocks][nz][ld].
 static int stage_ckpt(asif_hip_ctx *ctx, FilterArgs &a)
 {
-	int mb;
+	const int64_t nz = ctx->dims.nx + ctx->dims.nx * ctx->dims.nx;
+	int64_t need;
 	switch (ctx->model) {
-	case ASIF_HIP_MODEL_INVERTED_PENDULUM: mb = InvertedPendulum::kTrajBlock; break;
-	case ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT: mb = DoubleIntegratorImplicit::kTrajBlock; break;
-	case ASIF_HIP_MODEL_SEGWAY: mb = Segway::kTrajBlock; break;
-	case ASIF_HIP_MODEL_INVERTED_PENDULUM_TB: mb = InvertedPendulumTB::kTrajBlock; break;
+	case ASIF_HIP_MODEL_INVERTED_PENDULUM:
+	case ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT:
+	case ASIF_HIP_MODEL_INVERTED_PENDULUM_TB: need = (int64_t)ctx->dims.npBTSS * (nz + 2) * a.ld; break;
+	case ASIF_HIP_MODEL_SEGWAY:
+		need = ((ctx->dims.npBT + Segway::kTrajBlock - 1) / Segway::kTrajBlock) * (nz + 2) * a.ld;
+		break;
 	default: return ASIF_HIP_EINVAL;
 	}
-	const int64_t nblk = (ctx->dims.npBT + mb - 1) / mb;
-	const int64_t need = nblk * (ctx->dims.nx + ctx->dims.nx * ctx->dims.nx + 2) * a.ld;
 	if (need > ctx->s_ckpt_cap) {
 		if (ctx->s_ckpt) (void)hipFree(ctx->s_ckpt);
 		ctx->s_ckpt = nullptr;

@@ -83,11 +83,14 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 		z[k] = x0[k];
 		z[NX + k * (NX + 1)] = 1.0; // Q(0) = I, :417-425
 	}
-	// ---- pass 1: the whole trajectory, nothing kept per sample.  Per block of MB consecutive samples: the state at
-	// its first sample goes to HBM (a.ckpt, [block][CK][ld], coalesced), the smallest margin of the block feeds a
-	// running selection of the K blocks with the smallest minima (ties -> earlier block).  Every one of the K
-	// most critical SAMPLES (value, then index) lies in one of those K blocks: a block outside them is preceded
-	// by K blocks whose first minimum is a distinct sample ordered before every sample of it.
+	// ---- pass 1: the whole trajectory, nothing kept per sample.  Per block of MB consecutive samples the smallest
+	// margin of the block feeds a running selection of the K blocks with the smallest minima (ties -> earlier
+	// block).  Every one of the K most critical SAMPLES (value, then index) lies in one of those K blocks: a block
+	// outside them is preceded by K blocks whose first minimum is a distinct sample ordered before every sample of it.
+	// The state at a block's first sample is held in registers over the block and goes to HBM only when the block
+	// enters the selection, into the slot of the entry it displaces: a.ckpt is [K][CK][ld] -- K checkpoints per
+	// instance (640 B for the pendulum) instead of one per block (20 KB), written a handful of times per trajectory
+	// instead of once per block.
 	// The per-sample selection network this replaces ran on nearly every step (some lane of the wave inserts)
 	// and cost 35 % of the kernel.
 	constexpr int MB = M::kTrajBlock, CK = NZ + 2;
@@ -101,6 +104,22 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 	double bmin = __builtin_huge_val();
 	double *ck = a.ckpt + i;
 	const int64_t ldc = a.ld;
+	double zs[NZ]; // state (and hold) at the first sample of the current block
+	Hold hs = hold;
+#pragma unroll
+	for (int k = 0; k < NZ; k++) zs[k] = z[k];
+	auto commit = [&](int blk) { // close block blk: keep its checkpoint if it is among the K most critical so far
+		if (__any(bmin < topB.key[K - 1])) {
+			const int slot = topB.insert(bmin, blk);
+			if (slot >= 0) {
+				double *c = ck + (int64_t)slot * CK * ldc;
+#pragma unroll
+				for (int k = 0; k < NZ; k++) c[k * ldc] = zs[k];
+				c[NZ * ldc] = hs.u;
+				c[(NZ + 1) * ldc] = hs.tLast;
+			}
+		}
+	};
 #pragma unroll 1
 	for (int s = 0; s < o.npBT; s++) {
 		if (s > 0) BackupLoop<M>::template eulerStepT<RB>(o, z, hold, (double)(unsigned)s * o.trajDt);
@@ -108,24 +127,19 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 #pragma unroll
 			for (int k = 0; k < NZ; k++) zDbg[k] = z[k];
 		}
-		if (s % MB == 0) { // wave-uniform
-			const int blk = s / MB;
-			if (s > 0) {
-				if (__any(bmin < topB.key[K - 1])) topB.insert(bmin, blk - 1);
-				bmin = __builtin_huge_val();
-			}
-			double *c = ck + (int64_t)blk * CK * ldc;
+		if (s % MB == 0 && s > 0) { // wave-uniform
+			commit(s / MB - 1);
+			bmin = __builtin_huge_val();
 #pragma unroll
-			for (int k = 0; k < NZ; k++) c[k * ldc] = z[k];
-			c[NZ * ldc] = hold.u;
-			c[(NZ + 1) * ldc] = hold.tLast;
+			for (int k = 0; k < NZ; k++) zs[k] = z[k];
+			hs = hold;
 		}
 		double xs[NX];
 #pragma unroll
 		for (int k = 0; k < NX; k++) xs[k] = z[k];
 		bmin = fmin(bmin, M::safetyMin(o, xs));
 	}
-	if (__any(bmin < topB.key[K - 1])) topB.insert(bmin, (o.npBT - 1) / MB);
+	commit((o.npBT - 1) / MB);
 	double zEnd[NZ];
 #pragma unroll
 	for (int k = 0; k < NZ; k++) zEnd[k] = z[k];
@@ -138,17 +152,19 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 	int cur = -1;
 #pragma unroll 1
 	for (int j = 0; j < K; j++) {
-		int nb = 0x7fffffff;
+		int nb = 0x7fffffff, sl = 0;
 #pragma unroll
 		for (int p = 0; p < K; p++) {
 			const int v = topB.idx[p];
-			nb = (v > cur && v < nb) ? v : nb;
+			const bool better = v > cur && v < nb;
+			nb = better ? v : nb;
+			sl = better ? topB.slot[p] : sl;
 		}
 		const bool have = nb != 0x7fffffff;
 		if (!__any(have)) break;
 		cur = have ? nb : cur;
 		const int blk = have ? nb : 0;
-		const double *c = ck + (int64_t)blk * CK * ldc;
+		const double *c = ck + (int64_t)(have ? sl : 0) * CK * ldc;
 #pragma unroll
 		for (int k = 0; k < NZ; k++) z[k] = c[k * ldc];
 		hold.u = c[NZ * ldc];
@@ -181,7 +197,12 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 #pragma unroll 1
 	for (int k = 0; k < K; k++) {
 		double zk[NZ], xs[NX], h[NP], Dh[NP * NX];
-		const int slot = top.slot[k];
+		int slot = 0, sidx = 0; // entry k of the selection, picked with selects: a dynamic index would spill the arrays
+#pragma unroll
+		for (int p = 0; p < K; p++) {
+			slot = p == k ? top.slot[p] : slot;
+			sidx = p == k ? top.idx[p] : sidx;
+		}
 #pragma unroll
 		for (int c = 0; c < NZ; c++) zk[c] = pay[(slot * NZ + c) * 64 + lane];
 #pragma unroll
@@ -217,7 +238,7 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 			a.A[(int64_t)(row + 2 * NC) * ld + i] = 0.0;
 			a.b[(int64_t)row * ld + i] = -Lf;
 		}
-		if (a.diag) a.diag[(int64_t)k * ld + i] = (double)top.idx[k];
+		if (a.diag) a.diag[(int64_t)k * ld + i] = (double)sidx;
 	}
 	// backup-set row at the end of the trajectory
 	{

@@ -48,13 +48,35 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o, FilterArgs a)
 	// the K blocks with the smallest minima (ties -> earlier block): the K most critical samples of [0, idxHit]
 	// all lie in those blocks (see k_implicit.hip).  The per-sample selection this replaces (branch, K-entry
 	// network, NZ LDS writes) ran on most steps: 10 % of the segway kernel, 24 % of the pendulum's.
+	// Small states (NZ <= 8) keep the block-start state in registers over the block and store it only when the
+	// block enters the selection, into the displaced entry's slot: a.ckpt is [K][NZ][ld]; the segway's 20-double
+	// state would not fit the register budget and keeps one checkpoint per block, [blocks][NZ][ld].
 	constexpr int MB = M::kTrajBlock;
+	constexpr bool BYSLOT = NZ <= 8;
 	TopK<K> topB;
 	topB.init();
 	double *ck = a.ckpt + i;
+	double zs[BYSLOT ? NZ : 1];
+	if constexpr (BYSLOT) {
 #pragma unroll
-	for (int k = 0; k < NZ; k++) ck[k * ld] = z[k]; // block 0 starts at sample 0
+		for (int k = 0; k < NZ; k++) zs[k] = z[k];
+	} else {
+#pragma unroll
+		for (int k = 0; k < NZ; k++) ck[k * ld] = z[k]; // block 0 starts at sample 0
+	}
 	double bmin = M::safetyMin(o, x0);
+	auto commit = [&](int blk) { // close block blk
+		if (__any(bmin < topB.key[K - 1])) {
+			const int slot = topB.insert(bmin, blk);
+			if constexpr (BYSLOT) {
+				if (slot >= 0) {
+					double *c = ck + (int64_t)slot * NZ * ld;
+#pragma unroll
+					for (int k = 0; k < NZ; k++) c[k * ld] = zs[k];
+				}
+			}
+		}
+	};
 	bool done = inside || !live, hit = false;
 	int idxHit = 0, sLast = 0;
 	double t = 0.0, tHit = 0.0;
@@ -66,11 +88,16 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o, FilterArgs a)
 			t = t + o.trajDt; // backTraj_[i].first accumulates, :475
 			sLast = s;
 			if (s % MB == 0) { // wave-uniform: close the previous block, open the next
-				if (__any(bmin < topB.key[K - 1])) topB.insert(bmin, s / MB - 1);
+				commit(s / MB - 1);
 				bmin = __builtin_huge_val();
-				double *c = ck + (int64_t)(s / MB) * NZ * ld;
+				if constexpr (BYSLOT) {
 #pragma unroll
-				for (int k = 0; k < NZ; k++) c[k * ld] = z[k];
+					for (int k = 0; k < NZ; k++) zs[k] = z[k];
+				} else {
+					double *c = ck + (int64_t)(s / MB) * NZ * ld;
+#pragma unroll
+					for (int k = 0; k < NZ; k++) c[k * ld] = z[k];
+				}
 			}
 			double xs[NX];
 #pragma unroll
@@ -84,7 +111,7 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o, FilterArgs a)
 			}
 		}
 	}
-	if (__any(bmin < topB.key[K - 1])) topB.insert(bmin, sLast / MB); // every lane's last (possibly partial) block
+	commit(sLast / MB); // every lane's last (possibly partial) block
 	double zHit[NZ]; // the rows below are written for the state at idxHit
 #pragma unroll
 	for (int k = 0; k < NZ; k++) zHit[k] = z[k];
@@ -96,17 +123,19 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o, FilterArgs a)
 	int cur = -1;
 #pragma unroll 1
 	for (int j = 0; j < K; j++) {
-		int nb = 0x7fffffff;
+		int nb = 0x7fffffff, sl = 0;
 #pragma unroll
 		for (int p = 0; p < K; p++) {
 			const int v = topB.idx[p];
-			nb = (v > cur && v < nb) ? v : nb;
+			const bool better = v > cur && v < nb;
+			nb = better ? v : nb;
+			sl = better ? topB.slot[p] : sl;
 		}
 		const bool have = nb != 0x7fffffff;
 		if (!__any(have)) break;
 		cur = have ? nb : cur;
 		const int blk = have ? nb : 0;
-		const double *c = ck + (int64_t)blk * NZ * ld;
+		const double *c = ck + (int64_t)(BYSLOT ? (have ? sl : 0) : blk) * NZ * ld;
 #pragma unroll
 		for (int k = 0; k < NZ; k++) z[k] = c[k * ld];
 #pragma unroll 1
@@ -157,7 +186,9 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o, FilterArgs a)
 				continue;
 			}
 			double zk[NZ], xs[NX], h[NP], Dh[NP * NX];
-			const int slot = top.slot[k];
+			int slot = 0; // entry k of the selection, picked with selects: a dynamic index would spill the array
+#pragma unroll
+			for (int p = 0; p < K; p++) slot = p == k ? top.slot[p] : slot;
 #pragma unroll
 			for (int c = 0; c < NZ; c++) zk[c] = pay[(slot * NZ + c) * 64 + lane];
 #pragma unroll
@@ -257,7 +288,7 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o, FilterArgs a)
 		a.diag[0 * ld + i] = TTS;
 		a.diag[1 * ld + i] = ortho;
 		a.diag[2 * ld + i] = (double)idxHit;
-#pragma unroll 1
+#pragma unroll
 		for (int k = 0; k < K; k++) a.diag[(int64_t)(3 + k) * ld + i] = (code == 1 && k <= idxHit) ? (double)top.idx[k] : -1.0;
 	}
 }

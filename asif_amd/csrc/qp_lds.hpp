@@ -531,7 +531,6 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 			qa = wsum(qa);
 			a1 = wsum(a1);
 			// all rows (general, then bounds) side by side in LDS; this lane's breakpoints in (0, 1]
-			const int m = 64 * RPT + 64 * VPT;
 			double bp[2 * (RPT + VPT)];
 			int nb = 0;
 #pragma unroll
@@ -562,7 +561,11 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 			s.sync();
 			auto dphi = [&](double t) {
 				double f = qa + t * a1;
-				for (int i = 0; i < m; i++) {
+				for (int i = 0; i < nc; i++) { // general rows
+					const double st = s.ls_s[i] + t * s.ls_d[i];
+					f += s.ls_m[i] * s.ls_d[i] * (st - fmin(fmax(st, s.ls_l[i]), s.ls_u[i]));
+				}
+				for (int i = 64 * RPT; i < 64 * RPT + nv; i++) { // bounds
 					const double st = s.ls_s[i] + t * s.ls_d[i];
 					f += s.ls_m[i] * s.ls_d[i] * (st - fmin(fmax(st, s.ls_l[i]), s.ls_u[i]));
 				}

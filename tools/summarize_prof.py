@@ -57,7 +57,7 @@ def sq_summary(tag, out, calls_per_kernel):
     for k, c in kernels.items():
         per_step = 1.0
         for name, calls in calls_per_kernel.items():
-            if name.split("(")[0].strip() in k or k.split("(")[0].strip() in name:
+            if name.split("(")[0].strip() == k.split("(")[0].strip():
                 per_step = calls / steps
         c["launches_per_step"] = per_step
         valu += c.get("SQ_INSTS_VALU", 0.0) * per_step
@@ -85,7 +85,7 @@ def main():
         demangled = {}
         for name, c in calls.items():
             try:
-                d = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name.replace(".kd", "")], text=True).strip()
+                d = subprocess.check_output(["c++filt", name.replace(".kd", "")], text=True).strip()
             except Exception:
                 d = name
             demangled[d] = c
@@ -98,7 +98,13 @@ def main():
             fk, wk = sum(fetch[k]) / len(fetch[k]), sum(write[k]) / len(write[k])
             kernels[k] = {"FETCH_SIZE_KB_per_launch_raw": fk, "WRITE_SIZE_KB_per_launch_raw": wk,
                           "launches": len(fetch[k]), "traffic_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
-        total = sum(v["traffic_bytes_per_launch"] for v in kernels.values())
+        steps = max(demangled.values()) if demangled else 1
+        for k, v in kernels.items():
+            v["launches_per_step"] = 1.0
+            for name, c in demangled.items():
+                if name.split("(")[0].strip() == k.split("(")[0].strip():
+                    v["launches_per_step"] = c / steps
+        total = sum(v["traffic_bytes_per_launch"] * v["launches_per_step"] for v in kernels.values())
         with open(os.path.join(out, f"{tag}_pmc_summary.json"), "w") as f:
             json.dump({"command": "tools/prof_cfg.sh (rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE, separate passes)",
                        "correction": "counter unit KB; gfx950 FETCH_SIZE x2 for coalesced streaming reads; WRITE_SIZE exact",
