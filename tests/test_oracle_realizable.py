@@ -145,3 +145,37 @@ def test_filter_properties():
     ud = np.linspace(-19, 19, 8)[:, None]
     ua, relax, rc = z.filter(xin, ud)
     assert (rc == 1).all() and np.abs(ua - ud).max() < 1e-12 and np.abs(relax[:, 1]).max() < 1e-12
+
+
+def test_barrier_rows_are_lie_derivatives_of_the_smallest_margins(oracle):
+    """The barrier rows of ASIFrealizable (src/asif_realizable.cpp:530-600) checked without the oracle's own
+    arithmetic: with npSSmax = 4 rows per state, (f, g) are over-determined by  Lgh_i = -n_i . g,
+    -b_i - relaxDes (h_i - relaxOffset) = -n_i . f  -- they must be consistent across the four rows, g must be
+    (0, K/m) and f = (x1, -F x1 / m) inside the hull of the interval parameters (the reference takes midpoints of
+    affine forms), and the rows must belong to the four facets with the smallest margins h_i = 1 - n_i . x."""
+    k = oracle.load_kernel("100Hz")
+    z = oracle.Realizable(k, npSSmax=4)
+    d = z.desc
+    n = k["facetNormals"]
+    B = 200
+    x, u = oracle.make_batch_realizable(k, B)
+    A, b, code, info = z.assemble(x)
+    base = z.npSS * 3
+    for i in range(B):
+        Am = A[i].reshape(z.nv, z.nc).T
+        sel = info[i, 1 + z.maxCrit:1 + z.maxCrit + 4]
+        h = 1.0 - n @ x[i]
+        assert set(sel.tolist()) == set(np.argsort(h, kind="stable")[:4].tolist())
+        N = -n[sel]
+        lgh = Am[base:base + 4, 0]
+        lfh = -(b[i, base:base + 4] + d.relaxDes * (h[sel] - d.relaxOffset))
+        # g = (0, g1), f = (x1, f1): one scalar each, fixed by the row with the largest n_1 and checked on the others
+        j = int(np.argmax(np.abs(N[:, 1])))
+        g1 = lgh[j] / N[j, 1]
+        f1 = (lfh[j] - N[j, 0] * x[i, 1]) / N[j, 1]
+        assert np.abs(N[:, 1] * g1 - lgh).max() <= 1e-13
+        assert np.abs(N[:, 0] * x[i, 1] + N[:, 1] * f1 - lfh).max() <= 1e-11 * (1 + np.abs(lfh).max())
+        assert d.Klo / d.mMax - 1e-12 <= g1 <= d.Khi / d.mMin + 1e-12
+        lo, hi = sorted((-d.Flo * x[i, 1] / d.mMin, -d.Fhi * x[i, 1] / d.mMax))
+        assert lo - 1e-9 <= f1 <= hi + 1e-9
+        assert np.all(Am[base:base + 4, z.nv - 1] == 1.0)
