@@ -27,7 +27,10 @@ CONFIGS = {
     # not a BASELINE.json config: class ASIFimplicitRB on the pendulum model, workload of
     # asif_amd.workloads (x_unc = RB_X_UNC, seeded networks of make_learning())
     10: (MODEL_INVERTED_PENDULUM, 5, 16384),
+    # not a BASELINE.json config and not a reference example: class ASIF on the synthetic two-input model
+    11: (8, EXPLICIT, 65536),
 }
+MODEL_PLANAR_TWO_INPUT = 8
 IMPLICIT_RB = 5
 MODEL_INVERTED_PENDULUM_TB = 6
 MODEL_DOUBLE_INTEGRATOR_IMPLICIT = 7
@@ -42,6 +45,7 @@ EXPORTS = [
     "asif_hip_set_learning", "asif_hip_affine_replay", "asif_hip_qp_solve_batch_dense",
     "asif_hip_partition", "asif_hip_create_multi", "asif_hip_multi_destroy", "asif_hip_multi_size",
     "asif_hip_multi_handle", "asif_hip_multi_update_options", "asif_hip_filter_batch_host_multi",
+    "asif_hip_filter_batch_lie",
 ]
 
 MODEL_DOUBLE_INTEGRATOR_SAMPLED = 4
@@ -51,7 +55,7 @@ REALIZABLE = 4
 
 class RobustDataOptions(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("relaxCost", "relaxLb", "inf")] + [
-        ("lb", C.c_double * 1), ("ub", C.c_double * 1), ("npSSmax", C.c_int32)] + [
+        ("lb", C.c_double * 2), ("ub", C.c_double * 2), ("npSSmax", C.c_int32)] + [
         (n, C.c_double) for n in ("mMin", "mMax", "Klo", "Khi", "Flo", "Fhi")]
 
 
@@ -64,7 +68,7 @@ class KernelData(C.Structure):
 
 class RealizableOptions(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("relaxDes", "relaxOffset", "relaxCost", "inf")] + [
-        ("lb", C.c_double * 1), ("ub", C.c_double * 1), ("uncertaintyBounds", C.c_double * 4),
+        ("lb", C.c_double * 2), ("ub", C.c_double * 2), ("uncertaintyBounds", C.c_double * 4),
         ("npSSmax", C.c_int32)] + [(n, C.c_double) for n in ("mMin", "mMax", "Klo", "Khi", "Flo", "Fhi")]
 
 
@@ -72,10 +76,13 @@ class Options(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "relaxCost", "relaxLb", "relaxReachLb", "relaxTTS", "relaxMinOrtho", "backTrajHorizon",
         "backTrajExtend", "backTrajDt", "backTrajMinOrtho", "satSharpness", "inf")] + [
-        ("lb", C.c_double * 1), ("ub", C.c_double * 1), ("pMin", C.c_double), ("pMax", C.c_double),
+        ("lb", C.c_double * 2), ("ub", C.c_double * 2), ("pMin", C.c_double), ("pMax", C.c_double),
         ("nHalfPlanes", C.c_int32), ("halfPlanes", C.c_double * 16),
         # ASIFimplicitRB extras (include/asif_implicit_robust.h:24-37)
-        ("backContDt", C.c_double), ("x_unc", C.c_double * 4), ("n_debug", C.c_int32), ("use_learning", C.c_int32)]
+        ("backContDt", C.c_double), ("x_unc", C.c_double * 4), ("n_debug", C.c_int32), ("use_learning", C.c_int32),
+        # class ASIF's npSSmax; ASIFimplicit's USE_ODEINT build (integrator 1) and its tolerances
+        ("npSSmax", C.c_int32), ("integrator", C.c_int32), ("backTrajAbsTol", C.c_double),
+        ("backTrajRelTol", C.c_double)]
 
 
 class LearningData(C.Structure):
@@ -231,6 +238,12 @@ class Filter:
         B = x.shape[1]
         check(self.lib.asif_hip_filter_batch(self.handle, B, x.stride(0), _ptr(x), _ptr(udes), _ptr(uact),
                                              _ptr(relax), _ptr(rc), _ptr(diag), _stream()))
+
+    def filter_lie(self, x, udes, lfh, lgh, uact, relax, rc, diag=None):
+        """class ASIF with caller-supplied Lie derivatives lfh [nc,B], lgh [nc*nu,B] (src/asif.cpp:130-165)."""
+        B = x.shape[1]
+        check(self.lib.asif_hip_filter_batch_lie(self.handle, B, x.stride(0), _ptr(x), _ptr(udes), _ptr(lfh), _ptr(lgh),
+                                                 _ptr(uact), _ptr(relax), _ptr(rc), _ptr(diag), _stream()))
 
     def rollout(self, T, dt, x, udes, uact, relax, nfail, xlog=None, ulog=None, rclog=None):
         """T closed-loop steps (filter + plant Euler step) in one launch; x, uact, relax are updated in place."""

@@ -93,10 +93,18 @@ extern "C" int asif_hip_default_options(int model, int variant, asif_hip_options
 	o->pMin = o->pMax = 1.0;
 	o->backContDt = 0.01; // ASIFimplicitRB extras at their header defaults (include/asif_implicit_robust.h:26,31,37)
 	o->n_debug = -1;
+	o->npSSmax = -1;           // include/asif.h:28: every safety function
+	o->integrator = 0;         // forward Euler: the reference's default build (USE_ODEINT off, CMakeLists.txt:20)
+	o->backTrajAbsTol = 1.0e-6; // include/asif_implicit.h:29-30
+	o->backTrajRelTol = 1.0e-6;
 	switch (model) {
 	case ASIF_HIP_MODEL_DOUBLE_INTEGRATOR:
 		o->lb[0] = -1.0;
 		o->ub[0] = 1.0;
+		break;
+	case ASIF_HIP_MODEL_PLANAR_TWO_INPUT: // synthetic (no reference example has nu > 1): class defaults, |u_k| <= 1
+		o->lb[0] = o->lb[1] = -1.0;
+		o->ub[0] = o->ub[1] = 1.0;
 		break;
 	case ASIF_HIP_MODEL_INVERTED_PENDULUM:
 		o->lb[0] = -1.5;
@@ -209,12 +217,19 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 	dev.satMiddle = (o.ub[0] + o.lb[0]) / 2;
 	dev.twoOverRange = 2.0 / dev.satRange;
 
-	if (model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR && variant == ASIF_HIP_EXPLICIT) {
-		d.nx = 2; d.nu = 1; d.npSS = 4;
+	dev.integrator = o.integrator;
+	dev.trajAbsTol = o.backTrajAbsTol;
+	dev.trajRelTol = o.backTrajRelTol;
+	if ((model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR || model == ASIF_HIP_MODEL_PLANAR_TWO_INPUT) &&
+	    variant == ASIF_HIP_EXPLICIT) {
+		const bool p2 = model == ASIF_HIP_MODEL_PLANAR_TWO_INPUT;
+		d.nx = 2; d.nu = p2 ? 2 : 1; d.npSS = p2 ? 5 : 4;
 		d.nv = d.nu + 1;  // src/asif.cpp:19
-		d.nc = d.npSS;    // src/asif.cpp:21-22 (npSSmax = -1 clamps to npSS)
+		// src/asif.cpp:21-22: npSSmax = -1 (or anything beyond npSS) clamps to npSS
+		d.nc = (o.npSSmax > 0 && o.npSSmax < d.npSS) ? o.npSSmax : d.npSS;
+		dev.npKeep = d.nc;
 		d.nrelax = 1;
-		d.ndiag = 3; // working-set solves, certificate iterations, ADMM iterations
+		d.ndiag = d.npSS > 3 ? d.npSS : 3; // filter: working-set steps, -, ADMM iterations; assemble: kept safety functions
 		return ASIF_HIP_OK;
 	}
 	if ((model == ASIF_HIP_MODEL_INVERTED_PENDULUM || model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT) &&
@@ -836,6 +851,8 @@ static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipSt
 	if (ctx->rb) return launch_robust_data(ctx->rb->dev, ctx->solver, a, assemble_only, stream);
 	if (ctx->model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR && ctx->variant == ASIF_HIP_EXPLICIT)
 		return launch_explicit_di(ctx->dev, ctx->solver, a, assemble_only, stream);
+	if (ctx->model == ASIF_HIP_MODEL_PLANAR_TWO_INPUT && ctx->variant == ASIF_HIP_EXPLICIT)
+		return launch_explicit_p2(ctx->dev, ctx->solver, a, assemble_only, stream);
 	// ASIFimplicitRB, and ASIFimplicit with its learned residual switched on (src/asif_implicit.cpp:585-588):
 	// the latter runs the RB rows kernel with the hold off (backContDt = 0) and zero uncertainty, which is
 	// bitwise the plain kernel plus the residual
@@ -901,6 +918,20 @@ extern "C" int asif_hip_filter_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, 
 	hipError_t e = hipSetDevice(ctx->device);
 	if (e != hipSuccess) return (int)e;
 	FilterArgs a = {B, ldx, x, udes, uact, relax, rc, diag, ctx->dims.ndiag, nullptr, nullptr, nullptr};
+	return run_filter(ctx, a, false, (hipStream_t)stream);
+}
+
+extern "C" int asif_hip_filter_batch_lie(asif_hip_ctx *ctx, int64_t B, int64_t ldx, const double *x, const double *udes,
+                                         const double *lfh, const double *lgh, double *uact, double *relax, int32_t *rc,
+                                         double *diag, void *stream)
+{
+	if (!ctx || B < 0 || ldx < B || (B > 0 && (!x || !udes || !lfh || !lgh || !uact || !relax || !rc)))
+		return ASIF_HIP_EINVAL;
+	if (ctx->variant != ASIF_HIP_EXPLICIT || ctx->rz || ctx->rb) return ASIF_HIP_EINVAL;
+	if (B == 0) return ASIF_HIP_OK;
+	hipError_t e = hipSetDevice(ctx->device);
+	if (e != hipSuccess) return (int)e;
+	FilterArgs a = {B, ldx, x, udes, uact, relax, rc, diag, ctx->dims.ndiag, nullptr, nullptr, nullptr, nullptr, lfh, lgh};
 	return run_filter(ctx, a, false, (hipStream_t)stream);
 }
 

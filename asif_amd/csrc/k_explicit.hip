@@ -49,16 +49,46 @@ __global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_f
 			Lgh[r + j * NP] = t;
 		}
 	}
+	// npSSmax < npSS: only the rows of the smallest h are kept, in ascending order of h (src/asif.cpp:250-268);
+	// pos[r] = position of safety function r in that order (ties: lower index first), kept iff pos[r] < nkeep
+	const int nkeep = o.npKeep;
+	int pos[NP];
+#pragma unroll
+	for (int r = 0; r < NP; r++) pos[r] = r;
+	if (nkeep < NP) { // wave-uniform: the default keeps every row and skips the ranking
+#pragma unroll
+		for (int r = 0; r < NP; r++) {
+			int p = 0;
+#pragma unroll
+			for (int q = 0; q < NP; q++) p += (h[q] < h[r] || (h[q] == h[r] && q < r)) ? 1 : 0;
+			pos[r] = p;
+		}
+	}
+	if (a.lfh) { // caller-supplied Lie derivatives, indexed by row position (src/asif.cpp:287-292)
+#pragma unroll
+		for (int r = 0; r < NP; r++) {
+			const int p = pos[r] < nkeep ? pos[r] : 0;
+			Lfh[r] = a.lfh[(int64_t)p * a.ld + i];
+#pragma unroll
+			for (int j = 0; j < NU; j++) Lgh[r + j * NP] = a.lgh[(int64_t)(p + j * nkeep) * a.ld + i];
+		}
+	}
 	if (assemble_only) {
 		if (live && g == 0) {
 #pragma unroll
-			for (int r = 0; r < NC; r++) {
+			for (int r = 0; r < NP; r++) {
+				if (pos[r] < nkeep) {
+					const int p = pos[r];
 #pragma unroll
-				for (int j = 0; j < NU; j++) a.A[(r + j * NC) * a.ld + i] = Lgh[r + j * NP];
-				a.A[(r + NU * NC) * a.ld + i] = h[r];
-				a.b[r * a.ld + i] = -Lfh[r];
+					for (int j = 0; j < NU; j++) a.A[(int64_t)(p + j * nkeep) * a.ld + i] = Lgh[r + j * NP];
+					a.A[(int64_t)(p + NU * nkeep) * a.ld + i] = h[r];
+					a.b[(int64_t)p * a.ld + i] = -Lfh[r];
+				}
 			}
 			a.code[i] = 1;
+			if (a.diag) // which safety function sits in each row
+				for (int r = 0; r < NP; r++)
+					if (pos[r] < nkeep) a.diag[(int64_t)pos[r] * a.ld + i] = (double)r;
 		}
 		return;
 	}
@@ -71,7 +101,7 @@ __global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_f
 		bool feasible = true;
 #pragma unroll
 		for (int r = 0; r < NC; r++) {
-			const double a_ = Lgh[r], rhs = -Lfh[r] - h[r] * o.relaxLb;
+			const double a_ = Lgh[r], rhs = pos[r] < nkeep ? -Lfh[r] - h[r] * o.relaxLb : -1.0;
 			if (a_ > 0.0) lo = fmax(lo, rhs / a_);
 			else if (a_ < 0.0) hi = fmin(hi, rhs / a_);
 			else if (rhs > 0.0) feasible = false;
@@ -115,7 +145,7 @@ __global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_f
 		qp.eq[k] = false;
 #pragma unroll
 		for (int r = 0; r < NC; r++)
-			if (r == g + k * G) {
+			if (r == g + k * G && pos[r] < nkeep) {
 #pragma unroll
 				for (int j = 0; j < NU; j++) qp.A[k][j] = Lgh[r + j * NP];
 				qp.A[k][NU] = h[r];
@@ -250,16 +280,15 @@ int launch_rollout_explicit_di(const DevOptions &o, const asif_hip_solver &S0, c
 	return (int)hipGetLastError();
 }
 
-template <int G>
+template <class M, int G>
 static int launch_g(const DevOptions &o, const asif_hip_solver &S0, const FilterArgs &a, bool assemble_only,
                     hipStream_t stream)
 {
 	const int block = 64;
-	// one Ruiz pass by default: the 4 x 2 rows are well scaled and a second pass only costs finish rounds
-	// and the finish is tried after the first iteration already
+	// one Ruiz pass by default: the rows are well scaled and a second pass only costs finish rounds
 	const asif_hip_solver S = resolve_scaling(S0, 1, 1);
-	hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, G, false>), dim3(grid_for(a.B, G, block)), dim3(block),
-	                   0, stream, o, S, a, assemble_only);
+	hipLaunchKernelGGL((explicit_filter_kernel<M, G, false>), dim3(grid_for(a.B, G, block)), dim3(block), 0, stream, o,
+	                   S, a, assemble_only);
 	return (int)hipGetLastError();
 }
 
@@ -274,12 +303,21 @@ int launch_explicit_di(const DevOptions &o, const asif_hip_solver &S, const Filt
 		return (int)hipGetLastError();
 	}
 	switch (S.lanes_per_qp) {
-	case 2: return launch_g<2>(o, S, a, assemble_only, stream);
-	case 4: return launch_g<4>(o, S, a, assemble_only, stream);
+	case 2: return launch_g<DoubleIntegrator, 2>(o, S, a, assemble_only, stream);
+	case 4: return launch_g<DoubleIntegrator, 4>(o, S, a, assemble_only, stream);
 	case 0:
-	case 1: return launch_g<1>(o, S, a, assemble_only, stream);
+	case 1: return launch_g<DoubleIntegrator, 1>(o, S, a, assemble_only, stream);
 	default: return ASIF_HIP_EINVAL;
 	}
+}
+
+// class ASIF on the synthetic two-input model: nv = 3, five rows
+int launch_explicit_p2(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                       hipStream_t stream)
+{
+	if (a.B <= 0) return 0;
+	if (S.lanes_per_qp > 1) return ASIF_HIP_EINVAL;
+	return launch_g<PlanarTwoInput, 1>(o, S, a, assemble_only, stream);
 }
 
 } // namespace asif

@@ -19,10 +19,14 @@ struct FilterArgs {
 	int32_t *code;
 	// implicit / implicit-RB: block checkpoints of the backup trajectory, [ceil(npBT / kTrajBlock)][nx + nx*nx + 2][ld]
 	double *ckpt;
+	// class ASIF with caller-supplied Lie derivatives (src/asif.cpp:287-292): lfh[nc][ld], lgh[nc*nu][ld], or nullptr
+	const double *lfh, *lgh;
 };
 
-// explicit CBF filter (class ASIF), model = DoubleIntegrator
+// explicit CBF filter (class ASIF), model = DoubleIntegrator / PlanarTwoInput
 int launch_explicit_di(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                       hipStream_t stream);
+int launch_explicit_p2(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                        hipStream_t stream);
 
 // closed loop: T x (explicit filter + plant Euler step) per launch, model = DoubleIntegrator

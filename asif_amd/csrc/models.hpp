@@ -33,6 +33,9 @@ struct DevOptions {
 	double xUnc[ASIF_HIP_MAX_NX];
 	int nDebug;      // already validated against npBT (initialize(), src/asif_implicit_robust.cpp:298-303)
 	int useLearning;
+	int npKeep;      // class ASIF: rows kept per call (npSSmax clamped to npSS, src/asif.cpp:21)
+	int integrator;  // 0 forward Euler, 1 dopri5 with dense output (the reference's USE_ODEINT build)
+	double trajAbsTol, trajRelTol;
 	// LearningData (include/asif_learning_utils.h:8-32) uploaded by asif_hip_set_learning: device pointers
 	struct Learn {
 		int dHidden[2], dHidden2[2], dOut[2]; // [0] drift network, [1] actuation network
@@ -215,6 +218,31 @@ struct InvertedPendulum {
 		u[0] = -3.0 * x[0] + -3.0 * x[1];
 		Du[0] = -3.0;
 		Du[1] = -3.0;
+	}
+};
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic two-input model for class ASIF.  NOT one of the reference's examples (none of them has nu > 1); it
+// exists so that the nu > 1 code of src/asif.cpp (:279-303 Lgh = Dh g with nu columns, :314-352 cost and clamp per
+// input) has a device path: x' = F x + G u with a non-diagonal G, five half-planes r_i - a_i . x >= 0.
+struct PlanarTwoInput {
+	static constexpr int NX = 2, NU = 2, NPSS = 5;
+	__device__ static void safetySet(const DevOptions &, const double (&x)[NX], double (&h)[NPSS], double (&Dh)[NPSS * NX])
+	{
+		const double a[5][2] = {{1., 0.}, {-1., 0.}, {0., 1.}, {0., -1.}, {0.6, 0.8}}, r[5] = {1., 1., 1., 1., 1.2};
+#pragma unroll
+		for (int i = 0; i < 5; i++) {
+			h[i] = r[i] - a[i][0] * x[0] - a[i][1] * x[1];
+			Dh[i] = -a[i][0];
+			Dh[i + 5] = -a[i][1];
+		}
+	}
+	__device__ static void dynamics(const DevOptions &, const double (&x)[NX], double (&f)[NX], double (&g)[NX * NU])
+	{
+		f[0] = -0.5 * x[0] + 0.2 * x[1];
+		f[1] = 0.1 * x[0] + -0.3 * x[1];
+		g[0] = 1.0; g[1] = 0.0;
+		g[2] = 0.3; g[3] = 1.0;
 	}
 };
 

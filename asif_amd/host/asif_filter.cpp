@@ -123,6 +123,8 @@ int32_t ASIF::updateOptions(void)
 		o.relaxLb = options_.relaxLb;
 		o.inf = options_.inf;
 		o.satSharpness = options_.satSharpness;
+	o.npSSmax = (int32_t)npSSmax_; // the device keeps the same rows per call (src/asif.cpp:250-268)
+		o.npSSmax = (int32_t)npSSmax_;
 		for (uint32_t j = 0; j < nu_ && j < ASIF_HIP_MAX_NU; j++) {
 			o.lb[j] = lb_[j];
 			o.ub[j] = ub_[j];

@@ -67,7 +67,10 @@ enum asif_hip_model {
 	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_SAMPLED = 4,/* examples/DoubleIntegrator_RealizableSampled.cpp:16-62 (interval dynamics) */
 	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_ROBUST = 5, /* examples/DoubleIntegrator_Robust.cpp:17-58 (asif_hip_create_robust_data) */
 	ASIF_HIP_MODEL_INVERTED_PENDULUM_TB = 6,     /* examples/InvertedPendulum_ImplicitTB.cpp:14-99 (ASIF_HIP_IMPLICIT_TB) */
-	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT = 7 /* examples/DoubleIntegrator_implicit.cpp:13-90 (ASIF_HIP_IMPLICIT) */
+	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT = 7, /* examples/DoubleIntegrator_implicit.cpp:13-90 (ASIF_HIP_IMPLICIT) */
+	ASIF_HIP_MODEL_PLANAR_TWO_INPUT = 8 /* NOT an example of the reference: synthetic nx = 2, nu = 2 model (x' = Fx + Gu,
+	                                     * five half-planes) so that class ASIF's nu > 1 code (src/asif.cpp:279-303,
+	                                     * 314-352) has a device path and a parity test */
 };
 
 enum asif_hip_variant {
@@ -81,7 +84,7 @@ enum asif_hip_variant {
 	                           * optional learned residual; models INVERTED_PENDULUM, DOUBLE_INTEGRATOR_IMPLICIT */
 };
 
-#define ASIF_HIP_MAX_NU 1
+#define ASIF_HIP_MAX_NU 2
 #define ASIF_HIP_MAX_NX 4
 #define ASIF_HIP_MAX_HALFPLANES 8
 
@@ -111,6 +114,15 @@ typedef struct asif_hip_options {
 	/* in ASIFimplicit::Options too (include/asif_implicit.h:23,33): honoured by ASIF_HIP_IMPLICIT and _IMPLICIT_RB */
 	int32_t n_debug;               /* -1: the network sees Dh at the most critical sample; else at this sample */
 	int32_t use_learning;          /* needs asif_hip_set_learning before the first filter call */
+	/* class ASIF, constructor argument npSSmax (include/asif.h:28, src/asif.cpp:21): <= 0 or >= npSS keeps every safety
+	 * function; otherwise the npSSmax rows with the smallest h are kept per call, in ascending order of h
+	 * (src/asif.cpp:250-268; ties: lowest index first) and nc = npSSmax */
+	int32_t npSSmax;
+	/* backup-trajectory integrator of ASIFimplicit: 0 = forward Euler (the reference's default build), 1 = the
+	 * reference's USE_ODEINT build: dopri5 with dense output at the sample times (src/asif_implicit.cpp:427-460),
+	 * tolerances Options::backTrajAbsTol / backTrajRelTol (include/asif_implicit.h:29-30) */
+	int32_t integrator;
+	double backTrajAbsTol, backTrajRelTol;
 } asif_hip_options;
 
 /* LearningData (include/asif_learning_utils.h:8-32): two small ReLU networks whose outputs are added to the
@@ -263,6 +275,13 @@ int asif_hip_update_robust_data_options(asif_hip_ctx *ctx, const asif_hip_robust
  * TB: {TTS_, BTorthoBS_}; all: last slot = ADMM iterations used.  iters (may be NULL): int32[B]. */
 int asif_hip_filter_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx, const double *x, const double *udes,
                           double *uact, double *relax, int32_t *rc, double *diag, void *stream);
+
+/* Class ASIF with caller-supplied Lie derivatives: filter(x, uDes, uAct, Lfh, Lgh[, relax]) (src/asif.cpp:130-165;
+ * the override in updateConstraints, :287-292): row i of the QP is [Lgh(i, :) | h_i], b_i = -Lfh_i with h of the kept
+ * safety functions and lfh[nc][ldx], lgh[(nc*nu)][ldx] (component i + j*nc) as handed in.  Explicit handles only. */
+int asif_hip_filter_batch_lie(asif_hip_ctx *ctx, int64_t B, int64_t ldx, const double *x, const double *udes,
+                              const double *lfh, const double *lgh, double *uact, double *relax, int32_t *rc,
+                              double *diag, void *stream);
 
 /* Closed loop, T control steps per launch -- the caller's side of filter(), examples/DoubleIntegrator.cpp:81-116:
  * per step  rc = filter(x, uDes, uAct, relax)  (cold start, same arithmetic as asif_hip_filter_batch), then the

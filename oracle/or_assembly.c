@@ -39,7 +39,14 @@ void or_default_options(int model, int variant, or_options *o)
 	o->pMin = o->pMax = 1.0;
 	o->backContDt = 0.01; /* include/asif_implicit_robust.h:31 */
 	o->n_debug = -1;      /* :26 */
+	o->npSSmax = -1;            /* include/asif.h:28 */
+	o->backTrajAbsTol = 1.0e-6; /* include/asif_implicit.h:29-30 */
+	o->backTrajRelTol = 1.0e-6;
 	switch (model) {
+	case OR_MODEL_PLANAR_TWO_INPUT: /* synthetic: both inputs in [-1, 1], the class defaults otherwise */
+		o->lb[0] = o->lb[1] = -1.0;
+		o->ub[0] = o->ub[1] = 1.0;
+		break;
 	case OR_MODEL_DOUBLE_INTEGRATOR:
 		o->lb[0] = -1.0;
 		o->ub[0] = 1.0;
@@ -126,7 +133,7 @@ int or_get_dims(int model, int variant, const or_options *o, or_dims *d)
 	case OR_VARIANT_EXPLICIT: /* src/asif.cpp:17-22 */
 		if (!m->dynamics || model == OR_MODEL_INVERTED_PENDULUM_ROBUST) return -1;
 		d->nv = m->nu + 1;
-		d->nc = m->npSS;
+		d->nc = (o->npSSmax > 0 && o->npSSmax < m->npSS) ? o->npSSmax : m->npSS; /* src/asif.cpp:21 */
 		d->nrelax = 1;
 		break;
 	case OR_VARIANT_IMPLICIT_RB: /* src/asif_implicit_robust.cpp:206-214: same shape as ASIFimplicit */
@@ -162,21 +169,76 @@ int or_get_dims(int model, int variant, const or_options *o, or_dims *d)
 }
 
 /* ---------------------------------------------------------------- explicit */
-/* src/asif.cpp:233-312 with npSSmax == npSS (no row subset) */
-static int assemble_explicit(const or_model *m, const or_options *o, const double *x, double *A, double *b)
+/* src/asif.cpp:233-312.  npSSmax < npSS: the rows of the npSSmax smallest h, in ascending order of h (:250-268;
+ * std::sort leaves ties unspecified there, lowest index first here).  LfhIn / LghIn (may be NULL): the caller-
+ * supplied Lie derivatives of filter(x, uDes, uAct, Lfh, Lgh) (:287-292), indexed by ROW. */
+static __thread int g_kept[OR_MAX_NPSS], g_nkept;
+int or_last_kept_rows(int *idx, int cap)
 {
-	const int nx = m->nx, nu = m->nu, np = m->npSS, nc = np;
-	double h[OR_MAX_NPSS], Dh[OR_MAX_NPSS * OR_MAX_NX], f[OR_MAX_NX], g[OR_MAX_NX * OR_MAX_NU];
-	double Lfh[OR_MAX_NPSS], Lgh[OR_MAX_NPSS * OR_MAX_NU];
-	m->safety(o, x, h, Dh);
+	const int n = g_nkept < cap ? g_nkept : cap;
+	for (int i = 0; i < n; i++) idx[i] = g_kept[i];
+	return g_nkept;
+}
+static int assemble_explicit_lie(const or_model *m, const or_options *o, const double *x, const double *LfhIn,
+                                 const double *LghIn, double *A, double *b)
+{
+	const int nx = m->nx, nu = m->nu, npFull = m->npSS;
+	const int np = (o->npSSmax > 0 && o->npSSmax < npFull) ? o->npSSmax : npFull, nc = np;
+	double hFull[OR_MAX_NPSS], DhFull[OR_MAX_NPSS * OR_MAX_NX], f[OR_MAX_NX], g[OR_MAX_NX * OR_MAX_NU];
+	double h[OR_MAX_NPSS], Dh[OR_MAX_NPSS * OR_MAX_NX], Lfh[OR_MAX_NPSS], Lgh[OR_MAX_NPSS * OR_MAX_NU];
+	m->safety(o, x, hFull, DhFull);
 	m->dynamics(o, x, f, g);
+	int order[OR_MAX_NPSS];
+	for (int i = 0; i < npFull; i++) order[i] = i;
+	if (np < npFull)
+		for (int i = 1; i < npFull; i++) { /* stable insertion sort by h */
+			const int v = order[i];
+			int j = i;
+			while (j > 0 && hFull[order[j - 1]] > hFull[v]) {
+				order[j] = order[j - 1];
+				j--;
+			}
+			order[j] = v;
+		}
+	g_nkept = np;
+	for (int i = 0; i < np; i++) {
+		g_kept[i] = order[i];
+		h[i] = hFull[order[i]];
+		for (int j = 0; j < nx; j++) Dh[i + j * np] = DhFull[order[i] + j * npFull];
+	}
 	or_matvec(Dh, np, nx, f, Lfh);
 	or_matmul(Dh, np, nx, g, nu, Lgh);
+	if (LfhIn && LghIn) {
+		for (int i = 0; i < np; i++) Lfh[i] = LfhIn[i];
+		for (int i = 0; i < np * nu; i++) Lgh[i] = LghIn[i];
+	}
 	for (int i = 0; i < np; i++) {
 		for (int j = 0; j < nu; j++) A[i + j * nc] = Lgh[i + j * np];
 		A[i + nu * nc] = h[i];
 		b[i] = -Lfh[i];
 	}
+	return 1;
+}
+static int assemble_explicit(const or_model *m, const or_options *o, const double *x, double *A, double *b)
+{
+	return assemble_explicit_lie(m, o, x, 0, 0, A, b);
+}
+
+int or_filter_explicit_lie(int model, const or_options *o, const double *x, const double *uDes, const double *Lfh,
+                           const double *Lgh, double *uAct, double *relax)
+{
+	const or_model *m = or_model_get(model);
+	or_dims d;
+	if (!m || or_get_dims(model, OR_VARIANT_EXPLICIT, o, &d)) return -100;
+	double A[OR_MAX_NPSS * (OR_MAX_NU + 1)], b[OR_MAX_NPSS], Hd[OR_MAX_NU + 1], c[OR_MAX_NU + 1], lb[OR_MAX_NU + 1],
+	    ub[OR_MAX_NU + 1], sol[OR_MAX_NU + 1];
+	uint8_t be[OR_MAX_NPSS];
+	or_qp_static(model, OR_VARIANT_EXPLICIT, o, uDes, Hd, c, lb, ub, be);
+	assemble_explicit_lie(m, o, x, Lfh, Lgh, A, b);
+	or_qp qp = {d.nv, d.nc, Hd, c, A, b, lb, ub, be};
+	if (or_qp_exact_small(&qp, sol) != 1) return -1; /* src/asif.cpp:208-209 */
+	for (int i = 0; i < d.nu; i++) uAct[i] = sol[i] > o->ub[i] ? o->ub[i] : (sol[i] < o->lb[i] ? o->lb[i] : sol[i]);
+	relax[0] = sol[d.nu];
 	return 1;
 }
 

@@ -410,17 +410,40 @@ static void dii_grad(const void *ud, const double *x, double *Df, double *Dg)
 	for (int i = 0; i < 4; i++) Dg[i] = 0.0;
 }
 
-static const or_model MODELS[6] = {
+/* ----------------------------------------------------------------------------
+ * Synthetic two-input model for class ASIF (NOT from the reference: none of its examples has nu > 1, but
+ * src/asif.cpp is written for any nu): x' = F x + G u with a non-diagonal input matrix, five half-planes. */
+static void p2_safety(const void *ud, const double *x, double *h, double *Dh)
+{
+	(void)ud;
+	const double a[5][2] = {{1., 0.}, {-1., 0.}, {0., 1.}, {0., -1.}, {0.6, 0.8}}, r[5] = {1., 1., 1., 1., 1.2};
+	for (int i = 0; i < 5; i++) {
+		h[i] = r[i] - a[i][0] * x[0] - a[i][1] * x[1];
+		Dh[i] = -a[i][0];
+		Dh[i + 5] = -a[i][1];
+	}
+}
+static void p2_dynamics(const void *ud, const double *x, double *f, double *g)
+{
+	(void)ud;
+	f[0] = -0.5 * x[0] + 0.2 * x[1];
+	f[1] = 0.1 * x[0] + -0.3 * x[1];
+	g[0] = 1.0; g[1] = 0.0; /* column 0 */
+	g[2] = 0.3; g[3] = 1.0; /* column 1 */
+}
+
+static const or_model MODELS[7] = {
     {2, 1, 4, 0, di_safety, 0, di_dynamics, 0, 0, 0, 0, 0},
     {2, 1, 4, 1, ip_safety, ip_backup, ip_dynamics, ip_grad, ip_ctrl, 0, ip_safety_af, 10}, /* examples/InvertedPendulum_Implicit.cpp:17 */
     {4, 1, 4, 1, sg_safety, sg_backup, sg_dynamics, sg_grad, sg_ctrl, 0, 0, 4},
     {2, 1, 0, 0, ipr_safety, 0, 0, 0, 0, ipr_dynamics_af, 0, 0},
     {2, 1, 4, 1, ipt_safety, ipt_backup, ip_dynamics, ip_grad, ipt_ctrl, 0, 0, 4}, /* dynamics :67-74,87-94 = the pendulum's */
     {2, 1, 4, 1, dii_safety, dii_backup, di_dynamics, dii_grad, dii_ctrl, 0, dii_safety_af, 4}, /* dynamics :57-63 = A x, B; npBTSS :17 */
+    {2, 2, 5, 0, p2_safety, 0, p2_dynamics, 0, 0, 0, 0, 0},
 };
 
 const or_model *or_model_get(int id)
 {
-	if (id < 0 || id > 5) return 0;
+	if (id < 0 || id > 6) return 0;
 	return &MODELS[id];
 }

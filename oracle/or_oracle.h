@@ -36,7 +36,9 @@ enum or_model_id {
 	OR_MODEL_SEGWAY = 2,                   /* examples/segway_implicit_tb.cpp:13-212       */
 	OR_MODEL_INVERTED_PENDULUM_ROBUST = 3, /* examples/InvertedPendulum_Robust.cpp:20-79   */
 	OR_MODEL_INVERTED_PENDULUM_TB = 4,     /* examples/InvertedPendulum_ImplicitTB.cpp:14-99 */
-	OR_MODEL_DOUBLE_INTEGRATOR_IMPLICIT = 5 /* examples/DoubleIntegrator_implicit.cpp:13-90 */
+	OR_MODEL_DOUBLE_INTEGRATOR_IMPLICIT = 5, /* examples/DoubleIntegrator_implicit.cpp:13-90 */
+	OR_MODEL_PLANAR_TWO_INPUT = 6 /* NOT an example of the reference: a synthetic nx = 2, nu = 2 model for class ASIF,
+	                               * so that the nu > 1 loops of src/asif.cpp:279-303,314-352 are exercised */
 };
 
 enum or_variant_id {
@@ -48,7 +50,7 @@ enum or_variant_id {
 };
 
 #define OR_MAX_NX 4
-#define OR_MAX_NU 1
+#define OR_MAX_NU 2
 #define OR_MAX_NPSS 8
 
 /* LearningData, include/asif_learning_utils.h:8-32 (the two output-side pointers Lfh_diff / Lgh_diff are
@@ -88,6 +90,13 @@ typedef struct {
 	int32_t n_debug;            /* -1: Dh_index_ taken at the most critical sample */
 	int32_t use_learning;
 	const or_learning *learning;/* ASIFimplicitRB::learning_data_ (public member the caller fills) */
+	/* class ASIF: constructor argument npSSmax (include/asif.h:28): <= 0 or >= npSS keeps every row, otherwise the
+	 * npSSmax rows with the smallest h are kept per call (src/asif.cpp:250-268) */
+	int32_t npSSmax;
+	/* backup-trajectory integrator: 0 forward Euler (the reference's default build), 1 the USE_ODEINT build
+	 * (dopri5 dense output, src/asif_implicit.cpp:427-460) with Options::backTrajAbsTol / backTrajRelTol */
+	int32_t integrator;
+	double backTrajAbsTol, backTrajRelTol;
 } or_options;
 
 /* Defaults per variant+model exactly as the named example's main() sets them. */
@@ -180,6 +189,13 @@ int or_assemble(int model, int variant, const or_options *o, const double *x, do
 /* Full QP at the boundary: Hd,c,lb,ub,be as initialize()/updateCost() build them. */
 void or_qp_static(int model, int variant, const or_options *o, const double *uDes,
                   double *Hd, double *c, double *lb, double *ub, uint8_t *be);
+
+/* class ASIF with caller-supplied Lie derivatives, filter(x, uDes, uAct, Lfh, Lgh[, relax]) (src/asif.cpp:130-165,
+ * 287-292): rows use h of the (selected) safety functions and Lfh[i], Lgh[i + j*nc] as handed in. */
+int or_filter_explicit_lie(int model, const or_options *o, const double *x, const double *uDes, const double *Lfh,
+                           const double *Lgh, double *uAct, double *relax);
+/* indexes of the safety functions kept by the last explicit or_assemble on this thread, in row order */
+int or_last_kept_rows(int *idx, int cap);
 
 /* critical sample indexes picked by the last or_assemble on this thread (implicit/TB) */
 int or_last_crit_idx(int *idx, int cap);

@@ -24,7 +24,9 @@ CONFIGS = {2: (MODEL_DI, VAR_EXPLICIT), 3: (MODEL_IP, VAR_IMPLICIT), 4: (MODEL_S
            5: (MODEL_IP_ROBUST, VAR_ROBUST),
            8: (MODEL_IP_TB, VAR_TB),     # examples/InvertedPendulum_ImplicitTB.cpp (not a BASELINE.json config)
            9: (5, VAR_IMPLICIT),         # examples/DoubleIntegrator_implicit.cpp   (not a BASELINE.json config)
-           10: (MODEL_IP, VAR_IMPLICIT_RB)}  # ASIFimplicitRB on the pendulum model
+           10: (MODEL_IP, VAR_IMPLICIT_RB),  # ASIFimplicitRB on the pendulum model
+           11: (6, VAR_EXPLICIT)}        # class ASIF on the synthetic two-input model (no reference example has nu > 1)
+MODEL_P2 = 6
 
 
 class Learning(C.Structure):
@@ -53,10 +55,12 @@ class Options(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "relaxCost", "relaxLb", "relaxReachLb", "relaxTTS", "relaxMinOrtho", "backTrajHorizon",
         "backTrajExtend", "backTrajDt", "backTrajMinOrtho", "satSharpness", "inf")] + [
-        ("lb", C.c_double * 1), ("ub", C.c_double * 1), ("pMin", C.c_double), ("pMax", C.c_double),
+        ("lb", C.c_double * 2), ("ub", C.c_double * 2), ("pMin", C.c_double), ("pMax", C.c_double),
         ("nHalfPlanes", C.c_int32), ("halfPlanes", C.c_double * 16),
         ("backContDt", C.c_double), ("x_unc", C.c_double * 4), ("n_debug", C.c_int32),
-        ("use_learning", C.c_int32), ("learning", C.POINTER(Learning))]
+        ("use_learning", C.c_int32), ("learning", C.POINTER(Learning)),
+        ("npSSmax", C.c_int32), ("integrator", C.c_int32), ("backTrajAbsTol", C.c_double),
+        ("backTrajRelTol", C.c_double)]
 
     def set_learning(self, L):
         self._learning_keep = L
@@ -203,6 +207,26 @@ def qp_solve_batch(nv, nc, Hd, c, A, b, lb, ub, be=None, solver=SOLVER_ADMM, set
     return sol, status, iters
 
 
+def filter_explicit_lie(model, o, x, udes, lfh, lgh):
+    """One ASIF::filter(x, uDes, uAct, Lfh, Lgh, relax) per row of x (AoS), exact optimum; returns uact, relax, rc."""
+    d = dims(model, VAR_EXPLICIT, o)
+    B = x.shape[0]
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (x, np.reshape(udes, (B, d.nu)), lfh, lgh)]
+    ua = np.full((B, d.nu), np.nan)
+    rl = np.full((B, 1), np.nan)
+    rc = np.zeros(B, dtype=np.int32)
+    for i in range(B):
+        rc[i] = lib().or_filter_explicit_lie(model, C.byref(o), _p(arrs[0][i]), _p(arrs[1][i]), _p(arrs[2][i]),
+                                             _p(arrs[3][i]), _p(ua[i]), _p(rl[i]))
+    return ua, rl, rc
+
+
+def last_kept_rows(cap=8):
+    idx = np.zeros(cap, dtype=np.int32)
+    n = lib().or_last_kept_rows(_p(idx, C.c_int32), cap)
+    return idx[:n].copy()
+
+
 def last_crit_idx(cap=16):
     idx = np.zeros(cap, dtype=np.int32)
     n = lib().or_last_crit_idx(_p(idx, C.c_int32), cap)
@@ -266,7 +290,7 @@ class RzDesc(C.Structure):
         ("facetNormals", C.POINTER(C.c_double)), ("facetActive", C.POINTER(C.c_int32)),
         ("uncertaintyBounds", C.c_double * 4)] + [
         (n, C.c_double) for n in ("relaxDes", "relaxOffset", "relaxCost", "inf")] + [
-        ("lb", C.c_double * 1), ("ub", C.c_double * 1)] + [
+        ("lb", C.c_double * 2), ("ub", C.c_double * 2)] + [
         (n, C.c_double) for n in ("mMin", "mMax", "Klo", "Khi", "Flo", "Fhi")]
 
 
@@ -389,7 +413,7 @@ def make_batch_realizable(kernel, B, first=0, seed=6):
 # ------------------------------------------- robust filter on shipped half-planes (oracle/or_robust_data.c)
 class RbDesc(C.Structure):
     _fields_ = [("N", C.c_int32), ("npSSmax", C.c_int32), ("halfPlanes", C.POINTER(C.c_double))] + [
-        (n, C.c_double) for n in ("relaxCost", "relaxLb", "inf")] + [("lb", C.c_double * 1), ("ub", C.c_double * 1)] + [
+        (n, C.c_double) for n in ("relaxCost", "relaxLb", "inf")] + [("lb", C.c_double * 2), ("ub", C.c_double * 2)] + [
         (n, C.c_double) for n in ("mMin", "mMax", "Klo", "Khi", "Flo", "Fhi")]
 
 

@@ -48,14 +48,15 @@ def test_default_options_match_oracle(capi, oracle):
 def test_struct_layouts_match_header(capi):
     # sizes the C compiler gives the same structs (gcc on the public header)
     import subprocess, tempfile
-    src = '#include "asif_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu\\n",sizeof(asif_hip_options),sizeof(asif_hip_solver),sizeof(asif_hip_dims));return 0;}\n'
+    src = '#include "asif_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu\\n",sizeof(asif_hip_options),sizeof(asif_hip_solver),sizeof(asif_hip_dims),sizeof(asif_hip_realizable_options),sizeof(asif_hip_robust_data_options));return 0;}\n'
     with tempfile.TemporaryDirectory() as td:
         p = os.path.join(td, "s.c")
         open(p, "w").write(src)
         exe = os.path.join(td, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), p, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
-    assert sizes == [C.sizeof(capi.Options), C.sizeof(capi.Solver), C.sizeof(capi.Dims)]
+    assert sizes == [C.sizeof(capi.Options), C.sizeof(capi.Solver), C.sizeof(capi.Dims),
+                     C.sizeof(capi.RealizableOptions), C.sizeof(capi.RobustDataOptions)]
 
 
 def test_no_gpu_means_loud_failure(capi):

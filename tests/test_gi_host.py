@@ -81,7 +81,8 @@ def _family(rng, nv, nc, B, kind):
 @pytest.mark.parametrize("nv,nc", [(2, 4), (2, 18), (3, 17), (3, 41)])
 @pytest.mark.parametrize("kind", ["plain", "parallel", "pinned", "eqrow", "zero", "degenerate", "crossed"])
 def test_stress_families(oracle, gi, nv, nc, kind):
-    rng = np.random.default_rng(hash((nv, nc, kind)) % 2**32)
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(f"{nv}x{nc}:{kind}".encode()))  # str hashes change from run to run
     B = 4000
     Hd, c, A, b, lb, ub, be = _family(rng, nv, nc, B, kind)
     ex, stex, _ = oracle.qp_solve_batch(nv, nc, Hd, c, A, b, lb, ub, be, oracle.SOLVER_EXACT)
@@ -89,7 +90,16 @@ def test_stress_families(oracle, gi, nv, nc, kind):
     und = st == 0
     # "undecided" hands the problem to the ADMM iterations; it must stay the exception and never be a wrong verdict
     assert und.mean() <= 0.03, und.mean()
-    assert np.array_equal((st == 1)[~und], (stex == 1)[~und])
+    diff = np.where(((st == 1) != (stex == 1)) & ~und)[0]
+    # Rows built to pass through ONE point leave problems whose feasible set is that point within rounding: the
+    # enumeration (1e-12 relative, long double) and this solver (1e-12 on the selection, 1e-9 at a vertex its working
+    # set pins) may then disagree about "feasible".  Such a verdict is accepted only with a point that meets every row.
+    for k in diff:
+        assert kind == "degenerate" and st[k] == 1, (kind, k, st[k], stex[k])
+        Am = A[k].reshape(nv, nc).T
+        assert (b[k] - Am @ sol[k]).max() <= 1e-9 * (1 + np.abs(b[k]).max())
+        assert np.all(sol[k] >= lb[k] - 1e-9) and np.all(sol[k] <= ub[k] + 1e-9)
+    assert len(diff) <= 2
     ok = (st == 1) & (stex == 1)
     if ok.any():
         assert (np.abs(sol[ok] - ex[ok]) / (1 + np.abs(ex[ok]))).max() <= 1e-9
