@@ -45,7 +45,7 @@ def make_batch(cfg, B, first=0):
         x = np.stack([-1.5 + 3.0 * uniform(10, i, 0), -1.5 + 3.0 * uniform(10, i, 1)])
         u = (-1.5 + 3.0 * uniform(10, i, 2))[None, :]
     elif cfg == 11:  # synthetic two-input model under class ASIF (not a reference example): nx = 2, nu = 2
-        x = np.stack([-1.15 + 2.3 * uniform(11, i, 0), -1.15 + 2.3 * uniform(11, i, 1)])
+        x = np.stack([-1.6 + 3.2 * uniform(11, i, 0), -1.6 + 3.2 * uniform(11, i, 1)])
         u = np.stack([-1.5 + 3.0 * uniform(11, i, 2), -1.5 + 3.0 * uniform(11, i, 3)])
     else:
         raise ValueError(f"unknown config {cfg}")

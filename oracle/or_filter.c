@@ -255,8 +255,8 @@ void or_make_batch(int cfg, int64_t B, int64_t first, double *x, double *uDes)
 			uDes[k] = -1.5 + 3.0 * or_rng_uniform(10, i, 2);
 			break;
 		case 11: /* synthetic two-input model under class ASIF, seed 11: part of the batch starts outside the set */
-			x[2 * k + 0] = -1.15 + 2.3 * or_rng_uniform(11, i, 0);
-			x[2 * k + 1] = -1.15 + 2.3 * or_rng_uniform(11, i, 1);
+			x[2 * k + 0] = -1.6 + 3.2 * or_rng_uniform(11, i, 0);
+			x[2 * k + 1] = -1.6 + 3.2 * or_rng_uniform(11, i, 1);
 			uDes[2 * k + 0] = -1.5 + 3.0 * or_rng_uniform(11, i, 2);
 			uDes[2 * k + 1] = -1.5 + 3.0 * or_rng_uniform(11, i, 3);
 			break;
