@@ -102,6 +102,26 @@ struct BackupLoop {
 		closedLoopT<false>(o, x, fCL, DfCL, none, 0.0);
 	}
 
+	// ODErhs (src/asif_implicit.cpp:817-827): zdot = [fCL(x); DfCL(x) Q], time-invariant (no held input)
+	__device__ __forceinline__ static void rhs(const DevOptions &o, const double (&z)[NZ], double (&zd)[NZ])
+	{
+		double x[NX], fCL[NX], DfCL[NX * NX];
+#pragma unroll
+		for (int i = 0; i < NX; i++) x[i] = z[i];
+		closedLoop(o, x, fCL, DfCL);
+#pragma unroll
+		for (int i = 0; i < NX; i++) zd[i] = fCL[i];
+#pragma unroll
+		for (int i = 0; i < NX; i++)
+#pragma unroll
+			for (int j = 0; j < NX; j++) {
+				double s = 0.0;
+#pragma unroll
+				for (int k = 0; k < NX; k++) s += DfCL[i + k * NX] * z[NX + k + j * NX];
+				zd[NX + i + j * NX] = s;
+			}
+	}
+
 	__device__ __forceinline__ static void eulerStep(const DevOptions &o, double (&z)[NZ])
 	{
 		Hold none = {0.0, 0.0};
@@ -130,6 +150,123 @@ struct BackupLoop {
 			}
 #pragma unroll
 		for (int k = 0; k < NZ; k++) z[k] = zd[k] * o.trajDt + z[k];
+	}
+};
+
+// The reference's USE_ODEINT build of the backup trajectory (src/asif_implicit.cpp:427-460):
+//   make_dense_output(backTrajAbsTol, backTrajRelTol, runge_kutta_dopri5<state_t>()) observed every backTrajDt.
+// One instance per lane, every lane with its own step size.  Boost.odeint is not in the reference tree nor in the
+// image: the Dormand-Prince tableau and its continuous extension are the published ones, the step controller is
+// odeint's restated from memory (see oracle/or_assembly.c, dopri5_step: same formulas, same order) -- unpinned.
+template <class M>
+struct Dopri5 {
+	static constexpr int NZ = BackupLoop<M>::NZ;
+	double t, tOld, dt;
+	double z[NZ], zOld[NZ];
+	double k1[NZ], k3[NZ], k4[NZ], k5[NZ], k6[NZ], k7[NZ]; // of the last accepted step; k7 = f(z) (first same as last)
+
+	__device__ __forceinline__ void init(const DevOptions &o, const double (&z0)[NZ], double dt0)
+	{
+		t = 0.0;
+		tOld = 0.0;
+		dt = dt0;
+#pragma unroll
+		for (int i = 0; i < NZ; i++) {
+			z[i] = z0[i];
+			zOld[i] = z0[i];
+			k1[i] = k3[i] = k4[i] = k5[i] = k6[i] = 0.0;
+		}
+		BackupLoop<M>::rhs(o, z, k7);
+	}
+
+	// one attempt of a step for the lanes with `need`; accepted -> state advances, rejected -> dt shrinks
+	__device__ __forceinline__ void tryStep(const DevOptions &o, bool need)
+	{
+		constexpr double a21 = 1.0 / 5, a31 = 3.0 / 40, a32 = 9.0 / 40, a41 = 44.0 / 45, a42 = -56.0 / 15, a43 = 32.0 / 9,
+		                 a51 = 19372.0 / 6561, a52 = -25360.0 / 2187, a53 = 64448.0 / 6561, a54 = -212.0 / 729,
+		                 a61 = 9017.0 / 3168, a62 = -355.0 / 33, a63 = 46732.0 / 5247, a64 = 49.0 / 176,
+		                 a65 = -5103.0 / 18656, c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192,
+		                 c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+		constexpr double dc1 = 35.0 / 384 - 5179.0 / 57600, dc3 = 500.0 / 1113 - 7571.0 / 16695,
+		                 dc4 = 125.0 / 192 - 393.0 / 640, dc5 = -2187.0 / 6784 - (-92097.0 / 339200),
+		                 dc6 = 11.0 / 84 - 187.0 / 2100, dc7 = -1.0 / 40;
+		const double h = dt;
+		double zt[NZ], n2[NZ], n3[NZ], n4[NZ], n5[NZ], n6[NZ], n7[NZ], zn[NZ];
+		{
+#pragma clang fp contract(off) // the oracle's gcc build keeps every product and sum separately rounded
+#pragma unroll
+			for (int i = 0; i < NZ; i++) zt[i] = z[i] + h * a21 * k7[i];
+			BackupLoop<M>::rhs(o, zt, n2);
+#pragma unroll
+			for (int i = 0; i < NZ; i++) zt[i] = z[i] + h * (a31 * k7[i] + a32 * n2[i]);
+			BackupLoop<M>::rhs(o, zt, n3);
+#pragma unroll
+			for (int i = 0; i < NZ; i++) zt[i] = z[i] + h * (a41 * k7[i] + a42 * n2[i] + a43 * n3[i]);
+			BackupLoop<M>::rhs(o, zt, n4);
+#pragma unroll
+			for (int i = 0; i < NZ; i++) zt[i] = z[i] + h * (a51 * k7[i] + a52 * n2[i] + a53 * n3[i] + a54 * n4[i]);
+			BackupLoop<M>::rhs(o, zt, n5);
+#pragma unroll
+			for (int i = 0; i < NZ; i++)
+				zt[i] = z[i] + h * (a61 * k7[i] + a62 * n2[i] + a63 * n3[i] + a64 * n4[i] + a65 * n5[i]);
+			BackupLoop<M>::rhs(o, zt, n6);
+#pragma unroll
+			for (int i = 0; i < NZ; i++) zn[i] = z[i] + h * (c1 * k7[i] + c3 * n3[i] + c4 * n4[i] + c5 * n5[i] + c6 * n6[i]);
+			BackupLoop<M>::rhs(o, zn, n7);
+		}
+		double err = 0.0;
+		{
+#pragma clang fp contract(off)
+#pragma unroll
+			for (int i = 0; i < NZ; i++) {
+				const double xe = h * (dc1 * k7[i] + dc3 * n3[i] + dc4 * n4[i] + dc5 * n5[i] + dc6 * n6[i] + dc7 * n7[i]);
+				const double e = fabs(xe) / (o.trajAbsTol + o.trajRelTol * (fabs(z[i]) + fabs(h) * fabs(k7[i])));
+				err = fmax(err, e);
+			}
+		}
+		const bool reject = need && err > 1.0;
+		const bool accept = need && !(err > 1.0);
+		const double shrink = fmax(0.9 * pow(err, -1.0 / 3.0), 0.2);
+		const double grow = 0.9 * pow(fmax(err, 1.0 / 3125.0), -1.0 / 5.0);
+		dt = reject ? h * shrink : ((accept && err < 0.5) ? h * grow : dt);
+		tOld = accept ? t : tOld;
+		t = accept ? t + h : t;
+#pragma unroll
+		for (int i = 0; i < NZ; i++) {
+			zOld[i] = accept ? z[i] : zOld[i];
+			k1[i] = accept ? k7[i] : k1[i];
+			z[i] = accept ? zn[i] : z[i];
+			k3[i] = accept ? n3[i] : k3[i];
+			k4[i] = accept ? n4[i] : k4[i];
+			k5[i] = accept ? n5[i] : k5[i];
+			k6[i] = accept ? n6[i] : k6[i];
+			k7[i] = accept ? n7[i] : k7[i];
+		}
+	}
+
+	// continuous extension on the last step [tOld, t] (odeint runge_kutta_dopri5::calc_state)
+	__device__ __forceinline__ void dense(double ts, double (&out)[NZ]) const
+	{
+#pragma clang fp contract(off)
+		constexpr double b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784, b6 = 11.0 / 84;
+		const double h = t - tOld;
+		const bool moved = h > 0.0;
+		const double th = (ts - tOld) / (moved ? h : 1.0);
+		const double X1 = 5.0 * (2558722523.0 - 31403016.0 * th) / 11282082432.0;
+		const double X3 = 100.0 * (882725551.0 - 15701508.0 * th) / 32700410799.0;
+		const double X4 = 25.0 * (443332067.0 - 31403016.0 * th) / 1880347072.0;
+		const double X5 = 32805.0 * (23143187.0 - 3489224.0 * th) / 199316789632.0;
+		const double X6 = 55.0 * (29972135.0 - 7076736.0 * th) / 822651844.0;
+		const double X7 = 10.0 * (7414447.0 - 829305.0 * th) / 29380423.0;
+		const double thm1 = th - 1.0, thsq = th * th;
+		const double A = thsq * (3.0 - 2.0 * th), B = thsq * thm1, C = thsq * thm1 * thm1, D = th * thm1 * thm1;
+		const double bt1 = A * b1 - C * X1 + D, bt3 = A * b3 + C * X3, bt4 = A * b4 - C * X4, bt5 = A * b5 + C * X5,
+		             bt6 = A * b6 - C * X6, bt7 = B + C * X7;
+#pragma unroll
+		for (int i = 0; i < NZ; i++) {
+			const double v = zOld[i] + h * (bt1 * k1[i] + bt3 * k3[i] + bt4 * k4[i] + bt5 * k5[i] + bt6 * k6[i] + bt7 * k7[i]);
+			out[i] = moved ? v : z[i];
+		}
 	}
 };
 

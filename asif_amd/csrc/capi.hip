@@ -217,6 +217,11 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 	dev.satMiddle = (o.ub[0] + o.lb[0]) / 2;
 	dev.twoOverRange = 2.0 / dev.satRange;
 
+	// the reference's USE_ODEINT build exists for ASIFimplicit, ASIFimplicitTB and ASIFimplicitRB; the device has it for
+	// ASIFimplicit (src/asif_implicit.cpp:427-460)
+	if (o.integrator != 0 && o.integrator != 1) return ASIF_HIP_EINVAL;
+	if (o.integrator == 1 && variant != ASIF_HIP_IMPLICIT) return ASIF_HIP_EUNSUPPORTED;
+	if (o.integrator == 1 && !(o.backTrajAbsTol > 0 && o.backTrajRelTol > 0)) return ASIF_HIP_EINVAL;
 	dev.integrator = o.integrator;
 	dev.trajAbsTol = o.backTrajAbsTol;
 	dev.trajRelTol = o.backTrajRelTol;

@@ -56,9 +56,14 @@ __device__ inline double learn_net(const DevOptions::Learn &L, int net, const do
 	return s + b3[outIdx];
 }
 
-template <class M, bool RB>
+// DOPRI: the backup trajectory of the reference's USE_ODEINT build (asif_hip_options::integrator = 1): adaptive
+// dopri5 with dense output at the sample times instead of forward Euler.  The adaptive step straddles samples, so
+// there is no per-block restart point: one pass, the exact per-sample selection with the states parked in LDS
+// (the handful of Runge-Kutta steps per trajectory is cheap next to 5000 Euler steps; the samples are interpolations).
+template <class M, bool RB, bool DOPRI = false>
 __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterArgs a)
 {
+	static_assert(!(RB && DOPRI), "the held input of ASIFimplicitRB makes the rhs time-dependent: Euler only");
 	constexpr int NX = M::NX, NP = M::NPSS, K = M::NPBTSS, NB = M::NPBS, NZ = NX + NX * NX;
 	constexpr int NC = K * NP + NB;
 	static_assert(NB == 1, "one backup-set function");
@@ -83,6 +88,42 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 		z[k] = x0[k];
 		z[NX + k * (NX + 1)] = 1.0; // Q(0) = I, :417-425
 	}
+	typedef typename BackupLoop<M>::Hold Hold;
+	Hold hold = {0.0, 0.0};
+	double zDbg[NZ]; // the sample feeding the networks when n_debug selects one (:590-605)
+#pragma unroll
+	for (int k = 0; k < NZ; k++) zDbg[k] = z[k];
+	TopK<K> top;
+	top.init();
+	double zEnd[NZ];
+	if constexpr (DOPRI) {
+		Dopri5<M> rk;
+		rk.init(o, z, o.trajDt);
+		int guard = 200000; // odeint gives up after 500 failed attempts of one step; a stuck controller must not hang a wave
+#pragma unroll 1
+		for (int s = 0; s < o.npBT; s++) {
+			const double ts = o.trajDt * (double)s; // backTraj_[i].first, :451
+			// n_step_iterator: step while t < ts (less_with_sign: by more than epsilon), then interpolate
+			while (guard > 0 && __any(ts - rk.t > 2.220446049250313e-16)) {
+				rk.tryStep(o, ts - rk.t > 2.220446049250313e-16);
+				guard--;
+			}
+			double zs[NZ], xs[NX];
+			rk.dense(ts, zs);
+#pragma unroll
+			for (int k = 0; k < NX; k++) xs[k] = zs[k];
+			const double hm = M::safetyMin(o, xs);
+			if (__any(hm < top.key[K - 1])) {
+				const int slot = top.insert(hm, s);
+				if (slot >= 0) {
+#pragma unroll
+					for (int k = 0; k < NZ; k++) pay[(slot * NZ + k) * 64 + lane] = zs[k];
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < NZ; k++) zEnd[k] = zs[k];
+		}
+	} else {
 	// ---- pass 1: the whole trajectory, nothing kept per sample.  Per block of MB consecutive samples the smallest
 	// margin of the block feeds a running selection of the K blocks with the smallest minima (ties -> earlier
 	// block).  Every one of the K most critical SAMPLES (value, then index) lies in one of those K blocks: a block
@@ -94,13 +135,8 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 	// The per-sample selection network this replaces ran on nearly every step (some lane of the wave inserts)
 	// and cost 35 % of the kernel.
 	constexpr int MB = M::kTrajBlock, CK = NZ + 2;
-	typedef typename BackupLoop<M>::Hold Hold;
 	TopK<K> topB;
 	topB.init();
-	Hold hold = {0.0, 0.0};
-	double zDbg[NZ]; // the sample feeding the networks when n_debug selects one (:590-605)
-#pragma unroll
-	for (int k = 0; k < NZ; k++) zDbg[k] = z[k];
 	double bmin = __builtin_huge_val();
 	double *ck = a.ckpt + i;
 	const int64_t ldc = a.ld;
@@ -140,15 +176,12 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 		bmin = fmin(bmin, M::safetyMin(o, xs));
 	}
 	commit((o.npBT - 1) / MB);
-	double zEnd[NZ];
 #pragma unroll
 	for (int k = 0; k < NZ; k++) zEnd[k] = z[k];
 
 	// ---- pass 2: re-integrate the selected blocks from their checkpoints, in increasing block order so that
 	// samples arrive in increasing index (the selection's tie rule: earlier sample first), and run the exact
 	// per-sample selection with the states parked in LDS -- at most K*MB of the npBT steps.
-	TopK<K> top;
-	top.init();
 	int cur = -1;
 #pragma unroll 1
 	for (int j = 0; j < K; j++) {
@@ -186,6 +219,7 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 			}
 		}
 	}
+	} // Euler
 #pragma unroll
 	for (int k = 0; k < NZ; k++) z[k] = zEnd[k];
 	if (!live) return;
@@ -347,7 +381,10 @@ int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const Filt
 {
 	using M = InvertedPendulum;
 	if (a.B <= 0) return 0;
+	if (o.integrator == 1 && rb) return ASIF_HIP_EUNSUPPORTED; // held input: time-dependent rhs, Euler only
 	if (rb) hipLaunchKernelGGL((implicit_rows_kernel<M, true>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
+	else if (o.integrator == 1)
+		hipLaunchKernelGGL((implicit_rows_kernel<M, false, true>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
 	else hipLaunchKernelGGL((implicit_rows_kernel<M, false>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
 	int e = (int)hipGetLastError();
 	if (e || assemble_only) return e;
@@ -368,7 +405,10 @@ int launch_implicit_di(const DevOptions &o, const asif_hip_solver &S, const Filt
 	using M = DoubleIntegratorImplicit;
 	static_assert(M::NPBTSS * M::NPSS + M::NPBS == 17, "QP shape 3 x 17");
 	if (a.B <= 0) return 0;
+	if (o.integrator == 1 && rb) return ASIF_HIP_EUNSUPPORTED;
 	if (rb) hipLaunchKernelGGL((implicit_rows_kernel<M, true>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
+	else if (o.integrator == 1)
+		hipLaunchKernelGGL((implicit_rows_kernel<M, false, true>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
 	else hipLaunchKernelGGL((implicit_rows_kernel<M, false>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
 	int e = (int)hipGetLastError();
 	if (e || assemble_only) return e;

@@ -333,6 +333,121 @@ static void ode_rhs(const or_model *m, const or_options *o, const double *z, dou
 	or_matmul(DfCL, m->nx, m->nx, z + m->nx, m->nx, zdot + m->nx);
 }
 
+/* ---- the reference's USE_ODEINT build (src/asif_implicit.cpp:427-460): boost::numeric::odeint
+ *   make_dense_output(backTrajAbsTol, backTrajRelTol, runge_kutta_dopri5<state_t>())
+ * observed at t_k = k*backTrajDt through an n_step_iterator.  Boost is NOT in /root/reference and NOT in this
+ * image: restated from the published method (Dormand & Prince 1980 tableau; Shampine's / Hairer's continuous
+ * extension as odeint's runge_kutta_dopri5::calc_state evaluates it) and from memory of odeint's controller
+ * (controlled_runge_kutta<..., default_error_checker, default_step_adjuster>, FSAL variant):
+ *   err = max_i |xerr_i| / (abs + rel (|x_i| + dt |dxdt_i|));
+ *   err > 1: reject, dt *= max(0.9 err^(-1/3), 1/5)             (error order 4 -> exponent -1/(4-1));
+ *   else accept, and if err < 0.5: dt *= 0.9 max(5^-5, err)^(-1/5)   (stepper order 5; growth capped at 5x);
+ *   the iterator steps while t_cur < t_k - eps and then interpolates; initial dt = backTrajDt.
+ * PARITY UNPINNED at this boundary, like OSQP: no golden vector of the reference exists (it ships no tests and its
+ * default build has USE_ODEINT off, CMakeLists.txt:20). */
+typedef struct {
+	int nz;
+	double t, t_old, dt;
+	double z[OR_MAX_NX + OR_MAX_NX * OR_MAX_NX], z_old[OR_MAX_NX + OR_MAX_NX * OR_MAX_NX];
+	double k[7][OR_MAX_NX + OR_MAX_NX * OR_MAX_NX]; /* stage derivatives of the LAST accepted step; k[6] = f(z) (FSAL) */
+	double dz[OR_MAX_NX + OR_MAX_NX * OR_MAX_NX];   /* derivative at z */
+} dopri5_t;
+
+static void dopri5_init(dopri5_t *d, const or_model *m, const or_options *o, const double *z0, int nz, double dt)
+{
+	memset(d, 0, sizeof(*d));
+	d->nz = nz;
+	d->t = d->t_old = 0.0;
+	d->dt = dt;
+	memcpy(d->z, z0, sizeof(double) * nz);
+	memcpy(d->z_old, z0, sizeof(double) * nz);
+	ode_rhs(m, o, d->z, d->dz, 0, 0.0);
+}
+
+/* one accepted step (retries inside) */
+static void dopri5_step(dopri5_t *d, const or_model *m, const or_options *o)
+{
+	static const double a21 = 1.0 / 5, a31 = 3.0 / 40, a32 = 9.0 / 40, a41 = 44.0 / 45, a42 = -56.0 / 15, a43 = 32.0 / 9,
+	                    a51 = 19372.0 / 6561, a52 = -25360.0 / 2187, a53 = 64448.0 / 6561, a54 = -212.0 / 729,
+	                    a61 = 9017.0 / 3168, a62 = -355.0 / 33, a63 = 46732.0 / 5247, a64 = 49.0 / 176,
+	                    a65 = -5103.0 / 18656, c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192,
+	                    c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+	static const double dc1 = 35.0 / 384 - 5179.0 / 57600, dc3 = 500.0 / 1113 - 7571.0 / 16695,
+	                    dc4 = 125.0 / 192 - 393.0 / 640, dc5 = -2187.0 / 6784 - (-92097.0 / 339200),
+	                    dc6 = 11.0 / 84 - 187.0 / 2100, dc7 = -1.0 / 40;
+	const int n = d->nz;
+	double zt[OR_MAX_NX + OR_MAX_NX * OR_MAX_NX], zn[OR_MAX_NX + OR_MAX_NX * OR_MAX_NX], k[7][OR_MAX_NX + OR_MAX_NX * OR_MAX_NX];
+	for (int tries = 0; tries < 500; tries++) {
+		const double h = d->dt;
+		memcpy(k[0], d->dz, sizeof(double) * n);
+		for (int i = 0; i < n; i++) zt[i] = d->z[i] + h * a21 * k[0][i];
+		ode_rhs(m, o, zt, k[1], 0, 0.0);
+		for (int i = 0; i < n; i++) zt[i] = d->z[i] + h * (a31 * k[0][i] + a32 * k[1][i]);
+		ode_rhs(m, o, zt, k[2], 0, 0.0);
+		for (int i = 0; i < n; i++) zt[i] = d->z[i] + h * (a41 * k[0][i] + a42 * k[1][i] + a43 * k[2][i]);
+		ode_rhs(m, o, zt, k[3], 0, 0.0);
+		for (int i = 0; i < n; i++) zt[i] = d->z[i] + h * (a51 * k[0][i] + a52 * k[1][i] + a53 * k[2][i] + a54 * k[3][i]);
+		ode_rhs(m, o, zt, k[4], 0, 0.0);
+		for (int i = 0; i < n; i++)
+			zt[i] = d->z[i] + h * (a61 * k[0][i] + a62 * k[1][i] + a63 * k[2][i] + a64 * k[3][i] + a65 * k[4][i]);
+		ode_rhs(m, o, zt, k[5], 0, 0.0);
+		for (int i = 0; i < n; i++)
+			zn[i] = d->z[i] + h * (c1 * k[0][i] + c3 * k[2][i] + c4 * k[3][i] + c5 * k[4][i] + c6 * k[5][i]);
+		ode_rhs(m, o, zn, k[6], 0, 0.0);
+		double err = 0.0;
+		for (int i = 0; i < n; i++) {
+			const double xe = h * (dc1 * k[0][i] + dc3 * k[2][i] + dc4 * k[3][i] + dc5 * k[4][i] + dc6 * k[5][i] + dc7 * k[6][i]);
+			const double e = fabs(xe) / (o->backTrajAbsTol + o->backTrajRelTol * (fabs(d->z[i]) + fabs(h) * fabs(d->dz[i])));
+			if (e > err) err = e;
+		}
+		if (err > 1.0) {
+			double fac = 0.9 * pow(err, -1.0 / 3.0);
+			if (fac < 0.2) fac = 0.2;
+			d->dt = h * fac;
+			continue;
+		}
+		memcpy(d->z_old, d->z, sizeof(double) * n);
+		memcpy(d->z, zn, sizeof(double) * n);
+		memcpy(d->k, k, sizeof(k));
+		memcpy(d->dz, k[6], sizeof(double) * n);
+		d->t_old = d->t;
+		d->t = d->t + h;
+		if (err < 0.5) {
+			const double floor5 = pow(5.0, -5.0);
+			const double e = err > floor5 ? err : floor5;
+			d->dt = h * 0.9 * pow(e, -1.0 / 5.0);
+		}
+		return;
+	}
+}
+
+/* state at time ts >= the last sample: step while t < ts - eps, then the continuous extension on [t_old, t] */
+static void dopri5_sample(dopri5_t *d, const or_model *m, const or_options *o, double ts, double *out)
+{
+	while (ts - d->t > 2.220446049250313e-16) dopri5_step(d, m, o);
+	const int n = d->nz;
+	const double b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784, b6 = 11.0 / 84;
+	const double h = d->t - d->t_old;
+	if (!(h > 0.0)) { /* before any step: ts == 0 */
+		memcpy(out, d->z, sizeof(double) * n);
+		return;
+	}
+	const double th = (ts - d->t_old) / h;
+	const double X1 = 5.0 * (2558722523.0 - 31403016.0 * th) / 11282082432.0;
+	const double X3 = 100.0 * (882725551.0 - 15701508.0 * th) / 32700410799.0;
+	const double X4 = 25.0 * (443332067.0 - 31403016.0 * th) / 1880347072.0;
+	const double X5 = 32805.0 * (23143187.0 - 3489224.0 * th) / 199316789632.0;
+	const double X6 = 55.0 * (29972135.0 - 7076736.0 * th) / 822651844.0;
+	const double X7 = 10.0 * (7414447.0 - 829305.0 * th) / 29380423.0;
+	const double thm1 = th - 1.0, thsq = th * th;
+	const double A = thsq * (3.0 - 2.0 * th), B = thsq * thm1, C = thsq * thm1 * thm1, D = th * thm1 * thm1;
+	const double bt1 = A * b1 - C * X1 + D, bt3 = A * b3 + C * X3, bt4 = A * b4 - C * X4, bt5 = A * b5 + C * X5,
+	             bt6 = A * b6 - C * X6, bt7 = B + C * X7;
+	for (int i = 0; i < n; i++)
+		out[i] = d->z_old[i] + h * (bt1 * d->k[0][i] + bt3 * d->k[2][i] + bt4 * d->k[3][i] + bt5 * d->k[4][i] +
+		                                           bt6 * d->k[5][i] + bt7 * d->k[6][i]);
+}
+
 typedef struct {
 	int npBT, nz;
 	double dt;
@@ -371,9 +486,16 @@ static void integrate(const or_model *m, const or_options *o, int variant, int n
 	memset(&zoh, 0, sizeof(zoh));
 	zoh.dt = T->dt;
 	const int rb = variant == OR_VARIANT_IMPLICIT_RB;
+	const int dopri = o->integrator == 1 && variant == OR_VARIANT_IMPLICIT;
+	dopri5_t ds;
+	if (dopri) dopri5_init(&ds, m, o, z0, nz, T->dt);
 	for (int i = 0; i < n; i++) {
 		double *zi = T->z + (size_t)i * nz;
-		if (i > 0) {
+		if (i > 0 && dopri) {
+			/* src/asif_implicit.cpp:447-460: n_step_iterator over a dense-output dopri5, sample i at t = i*backTrajDt */
+			T->t[i] = T->dt * (double)i;
+			dopri5_sample(&ds, m, o, T->t[i], zi);
+		} else if (i > 0) {
 			const double *zp = zi - nz;
 			T->t[i] = T->t[i - 1] + T->dt;
 			/* src/asif_implicit_robust.cpp:567: the rhs at sample i-1 is stamped t = i*backTrajDt */
