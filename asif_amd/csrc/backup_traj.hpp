@@ -23,7 +23,12 @@ struct BackupLoop {
 	__device__ __forceinline__ static void saturateSoft(const DevOptions &o, double u, double &uSat, double &DuSat)
 	{
 		const double r = o.satSharpness;
-		const double mi = o.lb[0], ma = o.ub[0];
+		double mi = o.lb[0], ma = o.ub[0];
+#if defined(__HIP_DEVICE_COMPILE__)
+		// the selects below need these two in VGPRs; as plain SGPR values the compiler re-materialises them with four
+		// v_mov per Euler step -- an opaque register copy is hoisted out of the trajectory loop once
+		asm("" : "+v"(mi), "+v"(ma));
+#endif
 		const double range = o.satRange;
 		const double middle = o.satMiddle;
 		const double uc = (u - middle) * o.twoOverRange;
@@ -36,16 +41,21 @@ struct BackupLoop {
 		uSat = hi ? ma : (lo ? mi : u);
 		DuSat = (hi || lo) ? 0.0 : 1.0;
 		const bool bevelUp = !hi && uc > o.bevelStart, bevelDn = !lo && uc < -o.bevelStart;
-		if (__any(bevelUp || bevelDn)) {
-			if (bevelUp) {
-				const double s = sqrt(r * r - (uc - xc) * (uc - xc));
-				DuSat = (xc - uc) / s;
-				uSat = 0.5 * (s + yc) * range + middle;
-			} else if (bevelDn) {
-				const double s = sqrt(r * r - (uc + xc) * (uc + xc));
-				DuSat = (xc + uc) / s;
-				uSat = 0.5 * (-s - yc) * range + middle;
-			}
+		// Both bevels as ONE branch-free evaluation on |uc| -- bit for bit the reference's two expressions:
+		//   up:   s = sqrt(r^2 - (uc - xc)^2),  DuSat = (xc - uc)/s,  uSat = 0.5 ( s + yc) range + middle
+		//   down: s = sqrt(r^2 - (uc + xc)^2),  DuSat = (xc + uc)/s,  uSat = 0.5 (-s - yc) range + middle
+		// ((uc + xc)^2 = (|uc| - xc)^2 and 0.5 (-s - yc) range = -(0.5 (s + yc) range) exactly.)  Some lane of a wave
+		// sits in a bevel on ~40 % of the Euler steps; the wave-level branch around a divergent sqrt + divide block
+		// cost more than computing them for every lane (measured: 1.40 -> 1.33 ms on C3).
+		{
+			const double au = fabs(uc);
+			const bool bev = bevelUp || bevelDn;
+			const double d = bev ? r * r - (au - xc) * (au - xc) : 1.0;
+			const double sq = sqrt(d);
+			const double du = (xc - au) / sq;
+			const double us = 0.5 * (sq + yc) * range;
+			DuSat = bev ? du : DuSat;
+			uSat = bev ? (bevelUp ? us + middle : middle - us) : uSat;
 		}
 	}
 
@@ -57,7 +67,7 @@ struct BackupLoop {
 		double u, tLast;
 	};
 
-	template <bool HOLD>
+	template <bool HOLD, bool POISON = false>
 	__device__ __forceinline__ static void closedLoopT(const DevOptions &o, const double (&x)[NX], double (&fCL)[NX],
 	                                                   double (&DfCL)[NX * NX], Hold &hold, double t)
 	{
@@ -73,7 +83,7 @@ struct BackupLoop {
 			us = hold.u;
 		}
 		saturateSoft(o, us, uSat, DuSat);
-		M::dynamicsAndGradients(o, x, f, g, Df, Dg);
+		M::template dynamicsAndGradients<POISON>(o, x, f, g, Df, Dg);
 		if constexpr (M::kInputOnLastState) {
 			// g = e_last, Dg = 0: the general expression below with its constant factors folded by hand
 			// (the compiler may not fold x*0 or 0+x for doubles)
@@ -115,6 +125,10 @@ struct BackupLoop {
 		for (int i = 0; i < NX; i++)
 #pragma unroll
 			for (int j = 0; j < NX; j++) {
+				if (M::kDfFirstRowShift && NX == 2 && i == 0) { // 0 * Q(0,j) + 1 * Q(1,j): the same value without the FMAs
+					zd[NX + i + j * NX] = z[NX + 1 + j * NX];
+					continue;
+				}
 				double s = 0.0;
 #pragma unroll
 				for (int k = 0; k < NX; k++) s += DfCL[i + k * NX] * z[NX + k + j * NX];
@@ -130,19 +144,24 @@ struct BackupLoop {
 
 	// one forward-Euler step of [x; vec Q] (src/asif_implicit.cpp:470-477: rhs*dt + previous); t is the time
 	// the reference stamps on this rhs (src/asif_implicit_robust.cpp:567: i*backTrajDt for the step INTO sample i)
-	template <bool HOLD>
+	// POISON: the model's sin / cos never branch; out-of-range arguments turn the state into NaN (see sincos_fast)
+	template <bool HOLD, bool POISON = false>
 	__device__ __forceinline__ static void eulerStepT(const DevOptions &o, double (&z)[NZ], Hold &hold, double t)
 	{
 		double x[NX], fCL[NX], DfCL[NX * NX], zd[NZ];
 #pragma unroll
 		for (int i = 0; i < NX; i++) x[i] = z[i];
-		closedLoopT<HOLD>(o, x, fCL, DfCL, hold, t);
+		closedLoopT<HOLD, POISON>(o, x, fCL, DfCL, hold, t);
 #pragma unroll
 		for (int i = 0; i < NX; i++) zd[i] = fCL[i];
 #pragma unroll
 		for (int i = 0; i < NX; i++)
 #pragma unroll
 			for (int j = 0; j < NX; j++) {
+				if (M::kDfFirstRowShift && NX == 2 && i == 0) { // 0 * Q(0,j) + 1 * Q(1,j): the same value without the FMAs
+					zd[NX + i + j * NX] = z[NX + 1 + j * NX];
+					continue;
+				}
 				double s = 0.0;
 #pragma unroll
 				for (int k = 0; k < NX; k++) s += DfCL[i + k * NX] * z[NX + k + j * NX];

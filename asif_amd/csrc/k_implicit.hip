@@ -20,6 +20,7 @@
 //   The interval Lie derivatives the reference also forms (:698-709) feed nothing there and are not computed.
 // The 5000-step trajectory is ~99 % of the work and is inherently sequential per instance; the solve
 // is re-dealt G lanes per QP so the second launch fills the whole chip.
+#include <type_traits>
 #include "backup_traj.hpp"
 #include "qp_kernel.hpp"
 
@@ -156,26 +157,50 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 			}
 		}
 	};
+	// One block at a time: its samples, then the step into the next block's first sample.  The block runs on the
+	// branch-free fast path (sincos_fast<true>); if that poisoned a lane's state (an argument outside the fast
+	// path's range, or NaN) the block is repeated from its start state with the checking version -- same results as
+	// checking at every step, without a wave-level branch in the common step.
+	const int nblk = (o.npBT + MB - 1) / MB;
 #pragma unroll 1
-	for (int s = 0; s < o.npBT; s++) {
-		if (s > 0) BackupLoop<M>::template eulerStepT<RB>(o, z, hold, (double)(unsigned)s * o.trajDt);
-		if (RB && s == o.nDebug) {
-#pragma unroll
-			for (int k = 0; k < NZ; k++) zDbg[k] = z[k];
-		}
-		if (s % MB == 0 && s > 0) { // wave-uniform
-			commit(s / MB - 1);
+	for (int blk = 0; blk < nblk; blk++) {
+		const int s0 = blk * MB;
+		const int n = (o.npBT - s0) < MB ? (o.npBT - s0) : MB; // samples of this block
+		const bool more = s0 + n < o.npBT;
+		auto run = [&](auto poison) {
+			constexpr bool P = decltype(poison)::value;
 			bmin = __builtin_huge_val();
+#pragma unroll 1
+			for (int k = 0; k < n; k++) {
+				const int sidx = s0 + k;
+				if (k > 0) BackupLoop<M>::template eulerStepT<RB, P>(o, z, hold, (double)(unsigned)sidx * o.trajDt);
+				if (RB && sidx == o.nDebug) {
 #pragma unroll
-			for (int k = 0; k < NZ; k++) zs[k] = z[k];
-			hs = hold;
+					for (int c = 0; c < NZ; c++) zDbg[c] = z[c];
+				}
+				double xs[NX];
+#pragma unroll
+				for (int c = 0; c < NX; c++) xs[c] = z[c];
+				bmin = fmin(bmin, M::safetyMin(o, xs));
+			}
+			if (more) BackupLoop<M>::template eulerStepT<RB, P>(o, z, hold, (double)(unsigned)(s0 + n) * o.trajDt);
+		};
+		run(std::true_type());
+		bool bad = false;
+#pragma unroll
+		for (int c = 0; c < NZ; c++) bad = bad || (z[c] != z[c]);
+		if (__any(bad)) { // never on sane trajectories
+#pragma unroll
+			for (int c = 0; c < NZ; c++) z[c] = zs[c];
+			hold = hs;
+			run(std::false_type());
 		}
-		double xs[NX];
+		commit(blk);
 #pragma unroll
-		for (int k = 0; k < NX; k++) xs[k] = z[k];
-		bmin = fmin(bmin, M::safetyMin(o, xs));
+		for (int c = 0; c < NZ; c++) zs[c] = z[c];
+		hs = hold;
 	}
-	commit((o.npBT - 1) / MB);
+	// z now holds the state of the last sample: the loop's last block has no step beyond it
 #pragma unroll
 	for (int k = 0; k < NZ; k++) zEnd[k] = z[k];
 

@@ -12,6 +12,7 @@
 //   Lanes of a wave stop at different samples; the loop runs to the wave's slowest lane.
 // Stage 2  qp_policy_kernel<2,18,G> with the TB epilogue: rc 2 / 1 / -1 / raw solver status / -3 and the
 //   saturated backup controller on every failure (:290-361).
+#include <type_traits>
 #include "backup_traj.hpp"
 #include "qp_kernel.hpp"
 
@@ -54,17 +55,9 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o, FilterArgs a)
 	constexpr int MB = M::kTrajBlock;
 	constexpr bool BYSLOT = NZ <= 8;
 	TopK<K> topB;
-	topB.init();
 	double *ck = a.ckpt + i;
 	double zs[BYSLOT ? NZ : 1];
-	if constexpr (BYSLOT) {
-#pragma unroll
-		for (int k = 0; k < NZ; k++) zs[k] = z[k];
-	} else {
-#pragma unroll
-		for (int k = 0; k < NZ; k++) ck[k * ld] = z[k]; // block 0 starts at sample 0
-	}
-	double bmin = M::safetyMin(o, x0);
+	double bmin;
 	auto commit = [&](int blk) { // close block blk
 		if (__any(bmin < topB.key[K - 1])) {
 			const int slot = topB.insert(bmin, blk);
@@ -77,41 +70,77 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o, FilterArgs a)
 			}
 		}
 	};
-	bool done = inside || !live, hit = false;
-	int idxHit = 0, sLast = 0;
-	double t = 0.0, tHit = 0.0;
+	bool done, hit;
+	int idxHit, sLast;
+	double t, tHit;
+	// The whole pass runs on the branch-free trig fast path (sincos_fast<true>: an argument outside its range turns
+	// the lane's state into NaN instead of taking a wave-level branch at every step); a poisoned lane is found
+	// after the pass -- NaN never enters the backup set -- and the pass is then repeated with the checking version.
+	auto pass1 = [&](auto poison) {
+		constexpr bool P = decltype(poison)::value;
+#pragma unroll
+		for (int k = 0; k < NZ; k++) z[k] = 0.0;
+#pragma unroll
+		for (int k = 0; k < NX; k++) {
+			z[k] = x0[k];
+			z[NX + k * (NX + 1)] = 1.0;
+		}
+		topB.init();
+		if constexpr (BYSLOT) {
+#pragma unroll
+			for (int k = 0; k < NZ; k++) zs[k] = z[k];
+		} else {
+#pragma unroll
+			for (int k = 0; k < NZ; k++) ck[k * ld] = z[k]; // block 0 starts at sample 0
+		}
+		bmin = M::safetyMin(o, x0);
+		done = inside || !live;
+		hit = false;
+		idxHit = 0;
+		sLast = 0;
+		t = 0.0;
+		tHit = 0.0;
+		typename BackupLoop<M>::Hold none = {0.0, 0.0};
 #pragma unroll 1
-	for (int s = 1; s < o.npBT; s++) {
-		if (__all(done)) break;
-		if (!done) {
-			BackupLoop<M>::eulerStep(o, z);
-			t = t + o.trajDt; // backTraj_[i].first accumulates, :475
-			sLast = s;
-			if (s % MB == 0) { // wave-uniform: close the previous block, open the next
-				commit(s / MB - 1);
-				bmin = __builtin_huge_val();
-				if constexpr (BYSLOT) {
+		for (int s = 1; s < o.npBT; s++) {
+			if (__all(done)) break;
+			if (!done) {
+				BackupLoop<M>::template eulerStepT<false, P>(o, z, none, 0.0);
+				t = t + o.trajDt; // backTraj_[i].first accumulates, :475
+				sLast = s;
+				if (s % MB == 0) { // wave-uniform: close the previous block, open the next
+					commit(s / MB - 1);
+					bmin = __builtin_huge_val();
+					if constexpr (BYSLOT) {
 #pragma unroll
-					for (int k = 0; k < NZ; k++) zs[k] = z[k];
-				} else {
-					double *c = ck + (int64_t)(s / MB) * NZ * ld;
+						for (int k = 0; k < NZ; k++) zs[k] = z[k];
+					} else {
+						double *c = ck + (int64_t)(s / MB) * NZ * ld;
 #pragma unroll
-					for (int k = 0; k < NZ; k++) c[k * ld] = z[k];
+						for (int k = 0; k < NZ; k++) c[k * ld] = z[k];
+					}
+				}
+				double xs[NX];
+#pragma unroll
+				for (int k = 0; k < NX; k++) xs[k] = z[k];
+				bmin = fmin(bmin, M::safetyMin(o, xs));
+				if (M::backupSetInside(o, xs)) {
+					hit = true;
+					done = true;
+					idxHit = s;
+					tHit = t;
 				}
 			}
-			double xs[NX];
-#pragma unroll
-			for (int k = 0; k < NX; k++) xs[k] = z[k];
-			bmin = fmin(bmin, M::safetyMin(o, xs));
-			if (M::backupSetInside(o, xs)) {
-				hit = true;
-				done = true;
-				idxHit = s;
-				tHit = t;
-			}
 		}
+		commit(sLast / MB); // every lane's last (possibly partial) block
+	};
+	pass1(std::true_type());
+	{
+		bool bad = false;
+#pragma unroll
+		for (int k = 0; k < NZ; k++) bad = bad || (z[k] != z[k]);
+		if (__any(bad)) pass1(std::false_type()); // never on sane trajectories
 	}
-	commit(sLast / MB); // every lane's last (possibly partial) block
 	double zHit[NZ]; // the rows below are written for the state at idxHit
 #pragma unroll
 	for (int k = 0; k < NZ; k++) zHit[k] = z[k];
