@@ -170,8 +170,7 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 		auto run = [&](auto poison) {
 			constexpr bool P = decltype(poison)::value;
 			bmin = __builtin_huge_val();
-#pragma unroll 1
-			for (int k = 0; k < n; k++) {
+			auto sample = [&](int k) {
 				const int sidx = s0 + k;
 				if (k > 0) BackupLoop<M>::template eulerStepT<RB, P>(o, z, hold, (double)(unsigned)sidx * o.trajDt);
 				if (RB && sidx == o.nDebug) {
@@ -182,6 +181,13 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 #pragma unroll
 				for (int c = 0; c < NX; c++) xs[c] = z[c];
 				bmin = fmin(bmin, M::safetyMin(o, xs));
+			};
+			if (n == MB) { // full block: compile-time trip count, unrolled by four (loop control is SALU + a branch per step)
+#pragma unroll 4
+				for (int k = 0; k < MB; k++) sample(k);
+			} else {
+#pragma unroll 1
+				for (int k = 0; k < n; k++) sample(k);
 			}
 			if (more) BackupLoop<M>::template eulerStepT<RB, P>(o, z, hold, (double)(unsigned)(s0 + n) * o.trajDt);
 		};

@@ -181,7 +181,9 @@ struct InvertedPendulum {
 	}
 	__device__ static double safetyMin(const DevOptions &, const double (&x)[NX])
 	{
-		return fmin(fmin(-x[0] + kPi, x[0] + kPi), fmin(x[1] + kPi, -x[1] + kPi));
+		// min(-x0 + pi, x0 + pi, x1 + pi, -x1 + pi) = pi - max(|x0|, |x1|), bit for bit: the smaller of the two sums of
+		// a pair is fl(pi - |x_k|), and rounding is monotone (two instructions instead of seven in the 5000-step loop)
+		return kPi - fmax(fabs(x[0]), fabs(x[1]));
 	}
 	// the same set on interval_t operands over x +- x_unc (ASIFimplicitRB's safetySet_int), lower ends
 	__device__ static void safetySetLo(const DevOptions &o, const double (&x)[NX], double (&h)[NPSS])
@@ -282,7 +284,8 @@ struct DoubleIntegratorImplicit {
 	}
 	__device__ static double safetyMin(const DevOptions &, const double (&x)[NX])
 	{
-		return fmin(fmin(-x[0] + 1.0, x[0] - (-1.0)), fmin(x[1] - (-1.0), -x[1] + 1.0));
+		// min(-x0 + 1, x0 - (-1), x1 - (-1), -x1 + 1) = 1 - max(|x0|, |x1|), bit for bit (see InvertedPendulum)
+		return 1.0 - fmax(fabs(x[0]), fabs(x[1]));
 	}
 	// the same set on interval_t operands over x +- x_unc (ASIFimplicitRB's safetySet_int), lower ends
 	__device__ static void safetySetLo(const DevOptions &o, const double (&x)[NX], double (&h)[NPSS])
