@@ -13,7 +13,9 @@ namespace asif {
 
 // PRE = asif_hip_solver::presolve: its own instantiation, so that the closed-form path does not carry the
 // solver's register footprint.
-template <class M, int G, bool PRE>
+// SEL: the optional paths of src/asif.cpp (npSSmax < npSS row selection, caller-supplied Lie derivatives) are
+// compiled in; the default instantiation (every row, the model's own Lie derivatives) does not carry them.
+template <class M, int G, bool PRE, bool SEL = false>
 __global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_filter_kernel(DevOptions o, asif_hip_solver S, FilterArgs a,
                                                              bool assemble_only)
 {
@@ -51,11 +53,11 @@ __global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_f
 	}
 	// npSSmax < npSS: only the rows of the smallest h are kept, in ascending order of h (src/asif.cpp:250-268);
 	// pos[r] = position of safety function r in that order (ties: lower index first), kept iff pos[r] < nkeep
-	const int nkeep = o.npKeep;
+	const int nkeep = SEL ? o.npKeep : NP;
 	int pos[NP];
 #pragma unroll
 	for (int r = 0; r < NP; r++) pos[r] = r;
-	if (nkeep < NP) { // wave-uniform: the default keeps every row and skips the ranking
+	if (SEL && nkeep < NP) { // wave-uniform
 #pragma unroll
 		for (int r = 0; r < NP; r++) {
 			int p = 0;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_f
 			pos[r] = p;
 		}
 	}
-	if (a.lfh) { // caller-supplied Lie derivatives, indexed by row position (src/asif.cpp:287-292)
+	if (SEL && a.lfh) { // caller-supplied Lie derivatives, indexed by row position (src/asif.cpp:287-292)
 #pragma unroll
 		for (int r = 0; r < NP; r++) {
 			const int p = pos[r] < nkeep ? pos[r] : 0;
@@ -287,8 +289,13 @@ static int launch_g(const DevOptions &o, const asif_hip_solver &S0, const Filter
 	const int block = 64;
 	// one Ruiz pass by default: the rows are well scaled and a second pass only costs finish rounds
 	const asif_hip_solver S = resolve_scaling(S0, 1, 1);
-	hipLaunchKernelGGL((explicit_filter_kernel<M, G, false>), dim3(grid_for(a.B, G, block)), dim3(block), 0, stream, o,
-	                   S, a, assemble_only);
+	const bool sel = o.npKeep < M::NPSS || a.lfh != nullptr;
+	if (sel)
+		hipLaunchKernelGGL((explicit_filter_kernel<M, G, false, true>), dim3(grid_for(a.B, G, block)), dim3(block), 0,
+		                   stream, o, S, a, assemble_only);
+	else
+		hipLaunchKernelGGL((explicit_filter_kernel<M, G, false, false>), dim3(grid_for(a.B, G, block)), dim3(block), 0,
+		                   stream, o, S, a, assemble_only);
 	return (int)hipGetLastError();
 }
 
@@ -298,8 +305,12 @@ int launch_explicit_di(const DevOptions &o, const asif_hip_solver &S, const Filt
 	if (a.B <= 0) return 0;
 	if (S.presolve && !assemble_only) { // closed form, one instance per lane, larger blocks (tiny register footprint)
 		const int block = 256;
-		hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, 1, true>), dim3(grid_for(a.B, 1, block)), dim3(block),
-		                   0, stream, o, S, a, false);
+		if (o.npKeep < DoubleIntegrator::NPSS || a.lfh != nullptr)
+			hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, 1, true, true>), dim3(grid_for(a.B, 1, block)),
+			                   dim3(block), 0, stream, o, S, a, false);
+		else
+			hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, 1, true, false>), dim3(grid_for(a.B, 1, block)),
+			                   dim3(block), 0, stream, o, S, a, false);
 		return (int)hipGetLastError();
 	}
 	switch (S.lanes_per_qp) {

@@ -41,7 +41,7 @@ VALU_ISSUE_CYCLES = 4    # one wave's FP64 / FP32 vector instruction occupies it
 PROFILE_ROUND = "r02"
 
 # algorithmic HBM bytes per instance of the state->input path: read 8(nx+nu), write 8(nu+nrelax)+4
-ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44, 6: 52, 7: 44, 8: 44, 9: 52, 10: 52}
+ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44, 6: 52, 7: 44, 8: 44, 9: 52, 10: 52, 11: 60}
 IMPLICIT_RB_CFG = 10  # ASIFimplicitRB on the pendulum model; not a BASELINE.json config
 REALIZABLE_CFG = 6  # ASIFrealizable on the sampled double integrator; not a BASELINE.json config
 ROBUST_DATA_CFG = 7  # ASIFrobust on the shipped data: examples/DoubleIntegrator_Robust.cpp + KernelData_70-135kg.h
@@ -56,6 +56,7 @@ WORKLOAD = {
     9: "C9 DoubleIntegrator_implicit (ASIFimplicit::filter, 201-step backup trajectory, npBTSS 4, nv=3 nc=17)",
     10: "C10 ASIFimplicitRB::filter on the InvertedPendulum_Implicit model (backup input held 10 steps, interval "
         "margins under x_unc, two 4-16-16-1 ReLU residual networks with seeded weights)",
+    11: "C11 class ASIF on a synthetic two-input model (nx=2, nu=2, five half-planes; no reference example has nu > 1)",
 }
 
 
@@ -137,7 +138,7 @@ def cpu_baseline(cfg, gpu_uact, gpu_rc, x, udes):
         o = rb_options(O, model, variant)
         o.set_learning(O.Learning.from_dict(workloads.make_learning()))
     cores = host_cores()
-    probe = {2: 20000, 3: 16, 4: 256, 5: 2000, 8: 16, 9: 512, 10: 16}[cfg]
+    probe = {2: 20000, 3: 16, 4: 256, 5: 2000, 8: 16, 9: 512, 10: 16, 11: 20000}[cfg]
     xs, us = O.make_batch(cfg, probe)
     t = time.perf_counter()
     O.filter_batch(model, variant, o, xs, us, O.SOLVER_ADMM, None, 1)
@@ -147,10 +148,10 @@ def cpu_baseline(cfg, gpu_uact, gpu_rc, x, udes):
     t = time.perf_counter()
     O.filter_batch(model, variant, o, xs, us, O.SOLVER_ADMM, None, cores)
     dt = time.perf_counter() - t
-    m = min(x.shape[1], {2: 65536, 3: 512, 4: 16384, 5: 8192, 8: 512, 9: 16384, 10: 512}[cfg])
+    m = min(x.shape[1], {2: 65536, 3: 512, 4: 16384, 5: 8192, 8: 512, 9: 16384, 10: 512, 11: 65536}[cfg])
     ua, _, rc = O.filter_batch(model, variant, o, np.ascontiguousarray(x[:, :m].T),
                                np.ascontiguousarray(udes[:, :m].T), O.SOLVER_EXACT, None, cores,
-                               uact_init=np.zeros((m, 1)))
+                               uact_init=np.zeros((m, gpu_uact.shape[0])))
     ok = (rc == 1) | (rc == 2)
     err = float(np.abs(gpu_uact[:, :m].T[ok] - ua[ok]).max()) if ok.any() else 0.0
     mism = int((rc != gpu_rc[:m]).sum())
@@ -415,6 +416,11 @@ def main():
                          "once before the first iteration")
     ap.add_argument("--presolve", type=int, default=0,
                     help="asif_hip_solver.presolve (config 2: closed-form clip instead of the in-kernel ADMM; default 0)")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="0 (default): K direct launches; 1: the K timed launches are captured into one HIP graph and replayed "
+                         "once (a filter call only enqueues kernels, INTEGRATION.md 2).  Measured on MI355X / ROCm 7.2: a "
+                         "graph of kernel nodes runs each 6.7 us C2 step in 7.7 us (node-to-node dependency), direct "
+                         "launches keep the queue full at 6.7 us -- so direct launches are the default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
     args = ap.parse_args()
@@ -469,10 +475,11 @@ def main():
     rc = torch.zeros(B, dtype=torch.int32, device=dev)
 
     # Hot loop: one C-ABI call per step with every argument marshalled once (a Python-side wrapper per
-    # call costs more than this 20 us kernel).
+    # call costs more than this 7 us kernel).  The launches go to a side stream so that they can be captured.
     import ctypes as C
     fn = flt.lib.asif_hip_filter_batch
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream(device=dev)
+    stream.wait_stream(torch.cuda.current_stream())
     call_args = (flt.handle, B, tx.stride(0), C.c_void_p(tx.data_ptr()), C.c_void_p(tu.data_ptr()),
                  C.c_void_p(uact.data_ptr()), C.c_void_p(relax.data_ptr()), C.c_void_p(rc.data_ptr()), None,
                  C.c_void_p(stream.cuda_stream))
@@ -484,16 +491,29 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    # --graph 1: the K timed steps as ONE HIP graph of K filter launches.  Same K launches, same arguments, same
+    # stream order.  Off by default: measured slower than direct launches for the short kernels (see --help).
+    graph = None
+    if args.graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                for _ in range(args.steps):
+                    step()
+        except Exception as e:  # capture not possible (e.g. a first call still has to size staging buffers)
+            print(f"bench.py: graph capture failed ({e}); direct launches", file=sys.stderr)
+            graph = None
+        torch.cuda.synchronize()
     grp.barrier()
-    # per-step device durations from HIP events on the launch stream (torch's current stream, which is
-    # the stream handed to the library)
+    # device duration of the K steps from HIP events on the launch stream
     # (raw hipEvent* through ctypes: a torch.cuda.Event.record costs more host time than this kernel runs)
     hip = C.CDLL("libamdhip64.so")
     hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
     hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
     # One event pair brackets the K back-to-back launches: an event between every two kernels puts a
-    # barrier packet into the queue and stretches a 19 us step to 27 us.  average launch duration =
-    # device time between the two events / K (includes the ~1 us launch-to-launch gap).
+    # barrier packet into the queue and stretches the step.  average launch duration =
+    # device time between the two events / K (includes the launch-to-launch gap).
     ev = []
     for _ in range(2):
         e = C.c_void_p()
@@ -502,8 +522,12 @@ def main():
     sptr = C.c_void_p(stream.cuda_stream)
     t0 = time.perf_counter()
     hip.hipEventRecord(ev[0], sptr)
-    for k in range(args.steps):
-        step()
+    if graph is not None:
+        with torch.cuda.stream(stream):
+            graph.replay()
+    else:
+        for k in range(args.steps):
+            step()
     hip.hipEventRecord(ev[1], sptr)
     torch.cuda.synchronize()  # this rank's K steps are done: stop its clock, then meet the others
     t1 = time.perf_counter()
@@ -556,6 +580,8 @@ def main():
         "config": {"workload": WORKLOAD[cfg], "batch_per_gpu": B, "sharding": "instances, no collective",
                    "lanes_per_qp": args.lanes or "default",
                    "presolve": args.presolve,
+                   "launch": (f"one HIP graph of {args.steps} filter launches, replayed once" if graph is not None
+                              else f"{args.steps} direct launches"),
                    # how the QPs were decided: polish 2 runs the in-register dual active-set stage first, then OSQP-style
                    # ADMM iterations (with an active-set finish at every check) for what it leaves undecided
                    "solver": {"polish": solver.polish,
