@@ -18,44 +18,102 @@ struct BackupLoop {
 	static constexpr int NX = M::NX, NZ = NX + NX * NX;
 	static_assert(M::NU == 1, "backup loop is written for single-input models (every shipped example)");
 
+	// sqrt and divide as the compiler expands them (v_rsq / v_rcp, Newton steps in FMA, v_div_fixup), minus the
+	// rescaling of operands near the ends of the exponent range (v_div_scale, the ldexp pair around the sqrt).  Bit for
+	// bit the IEEE results whenever the rescaling would not have triggered: x = 0 or x >= 2^-767 for the sqrt; for a / b
+	// both magnitudes (a may be 0) within 2^+-255.  The caller guarantees that from the options (satFastOk).
+	__device__ __forceinline__ static double sqrt_plain_range(double x)
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		const double y = __builtin_amdgcn_rsq(x);
+		double g = x * y, h = 0.5 * y;
+		const double r = fma(-h, g, 0.5);
+		g = fma(g, r, g);
+		h = fma(h, r, h);
+		double d = fma(-g, g, x);
+		g = fma(d, h, g);
+		d = fma(-g, g, x);
+		g = fma(d, h, g);
+		return (x == 0.0 || x == __builtin_huge_val()) ? x : g;
+#else
+		return sqrt(x);
+#endif
+	}
+	__device__ __forceinline__ static double div_plain_range(double a, double b)
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		double r = __builtin_amdgcn_rcp(b);
+		double e = fma(-b, r, 1.0);
+		r = fma(r, e, r);
+		e = fma(-b, r, 1.0);
+		r = fma(r, e, r);
+		double q = a * r;
+		const double t = fma(-b, q, a);
+		q = fma(t, r, q);
+		return __builtin_amdgcn_div_fixup(q, b, a);
+#else
+		return a / b;
+#endif
+	}
 	// bevelled smooth saturation of the backup input; DuSat is d uSat / d u in the reference's own
-	// (normalised-arc) convention -- reproduced literally
+	// (normalised-arc) convention -- reproduced literally.
+	// Four regions: linear, clamped high / low (selects), and the two bevels (sqrt + divide) as ONE evaluation on |uc|,
+	// bit for bit the reference's two expressions:
+	//   up:   s = sqrt(r^2 - (uc - xc)^2),  DuSat = (xc - uc)/s,  uSat = 0.5 ( s + yc) range + middle
+	//   down: s = sqrt(r^2 - (uc + xc)^2),  DuSat = (xc + uc)/s,  uSat = 0.5 (-s - yc) range + middle
+	// ((uc + xc)^2 = (|uc| - xc)^2 and 0.5 (-s - yc) range = -(0.5 (s + yc) range) exactly.)  Some lane of a wave sits in
+	// a bevel on ~40 % of the Euler steps: one divergent block (exec mask + a branch the wave takes when no lane is in
+	// a bevel).  Two divergent arcs cost 1.40 ms on C3, this form 1.33, and running the block on every step for every
+	// lane 1.47 against 1.20 at the time of that measurement.
+	// FAST (only where the host has set DevOptions::satFastOk: 0 < bevelStart < bevelStop, sharpness and bevelStop
+	// within 2^+-100) decides the regions on |uc| and the sign of uc -- three compares instead of six; with ordered
+	// positive thresholds the same regions, NaN in none of them either way -- and takes sqrt and divide without the
+	// rescaling steps: nonzero d >= ulp(r^2)/2, sq in [r 2^-27, r], |xc - au| in {0} U [ulp(xc)/2, bevelL], far from the
+	// thresholds where the IEEE sequences rescale.  Same bits, ~10 VALU issues fewer per step.
+	template <bool FAST = false>
 	__device__ __forceinline__ static void saturateSoft(const DevOptions &o, double u, double &uSat, double &DuSat)
 	{
 		const double r = o.satSharpness;
-		double mi = o.lb[0], ma = o.ub[0];
-#if defined(__HIP_DEVICE_COMPILE__)
-		// the selects below need these two in VGPRs; as plain SGPR values the compiler re-materialises them with four
-		// v_mov per Euler step -- an opaque register copy is hoisted out of the trajectory loop once
-		asm("" : "+v"(mi), "+v"(ma));
-#endif
+		const double mi = o.lb[0], ma = o.ub[0]; // in VGPRs already: see the rows kernels' prologue
 		const double range = o.satRange;
 		const double middle = o.satMiddle;
 		const double uc = (u - middle) * o.twoOverRange;
 		const double xc = o.bevelStop;
 		const double yc = 1 - r;
-		// four regions: linear, clamped high / low (selects), and the two bevels (sqrt + divide).  The bevels are
-		// a narrow band of u; they sit behind ONE wave-level branch so that the common step pays a compare and a
-		// not-taken scalar branch instead of four nested exec-mask sequences.
-		const bool hi = uc >= o.bevelStop, lo = uc <= -o.bevelStop;
-		uSat = hi ? ma : (lo ? mi : u);
-		DuSat = (hi || lo) ? 0.0 : 1.0;
-		const bool bevelUp = !hi && uc > o.bevelStart, bevelDn = !lo && uc < -o.bevelStart;
-		// Both bevels as ONE branch-free evaluation on |uc| -- bit for bit the reference's two expressions:
-		//   up:   s = sqrt(r^2 - (uc - xc)^2),  DuSat = (xc - uc)/s,  uSat = 0.5 ( s + yc) range + middle
-		//   down: s = sqrt(r^2 - (uc + xc)^2),  DuSat = (xc + uc)/s,  uSat = 0.5 (-s - yc) range + middle
-		// ((uc + xc)^2 = (|uc| - xc)^2 and 0.5 (-s - yc) range = -(0.5 (s + yc) range) exactly.)  Some lane of a wave
-		// sits in a bevel on ~40 % of the Euler steps; the wave-level branch around a divergent sqrt + divide block
-		// cost more than computing them for every lane (measured: 1.40 -> 1.33 ms on C3).
-		{
+		if constexpr (FAST) {
 			const double au = fabs(uc);
-			const bool bev = bevelUp || bevelDn;
-			const double d = bev ? r * r - (au - xc) * (au - xc) : 1.0;
-			const double sq = sqrt(d);
-			const double du = (xc - au) / sq;
-			const double us = 0.5 * (sq + yc) * range;
-			DuSat = bev ? du : DuSat;
-			uSat = bev ? (bevelUp ? us + middle : middle - us) : uSat;
+			const bool clamped = au >= o.bevelStop, neg = uc < 0.0;
+			uSat = clamped ? (neg ? mi : ma) : u;
+			DuSat = clamped ? 0.0 : 1.0;
+			if (au > o.bevelStart && !clamped) { // divergent: skipped by the wave when no lane is in a bevel
+				const double d = r * r - (au - xc) * (au - xc);
+				const double sq = sqrt_plain_range(d);
+				const double us = 0.5 * (sq + yc) * range;
+				DuSat = div_plain_range(xc - au, sq);
+				uSat = neg ? middle - us : us + middle;
+			}
+		} else { // the reference's chain, region by region and in its order (src/asif_implicit.cpp:704-735)
+			if (uc >= o.bevelStop) {
+				uSat = ma;
+				DuSat = 0.0;
+			} else if (uc <= -o.bevelStop) {
+				uSat = mi;
+				DuSat = 0.0;
+			} else if (uc <= o.bevelStart && uc >= -o.bevelStart) {
+				uSat = u;
+				DuSat = 1.0;
+			} else if (uc > o.bevelStart) {
+				const double sq = sqrt(r * r - (uc - xc) * (uc - xc));
+				DuSat = (xc - uc) / sq;
+				uSat = 0.5 * (sq + yc) * range + middle;
+			} else if (uc < -o.bevelStart) {
+				const double sq = sqrt(r * r - (uc + xc) * (uc + xc));
+				DuSat = (xc + uc) / sq;
+				uSat = 0.5 * (-sq - yc) * range + middle;
+			} else { // NaN
+				uSat = u;
+				DuSat = 1.0;
+			}
 		}
 	}
 
@@ -67,7 +125,7 @@ struct BackupLoop {
 		double u, tLast;
 	};
 
-	template <bool HOLD, bool POISON = false>
+	template <bool HOLD, int POISON = kTrigChecked>
 	__device__ __forceinline__ static void closedLoopT(const DevOptions &o, const double (&x)[NX], double (&fCL)[NX],
 	                                                   double (&DfCL)[NX * NX], Hold &hold, double t)
 	{
@@ -82,7 +140,7 @@ struct BackupLoop {
 			}
 			us = hold.u;
 		}
-		saturateSoft(o, us, uSat, DuSat);
+		saturateSoft<POISON != kTrigChecked>(o, us, uSat, DuSat);
 		M::template dynamicsAndGradients<POISON>(o, x, f, g, Df, Dg);
 		if constexpr (M::kInputOnLastState) {
 			// g = e_last, Dg = 0: the general expression below with its constant factors folded by hand
@@ -145,7 +203,7 @@ struct BackupLoop {
 	// one forward-Euler step of [x; vec Q] (src/asif_implicit.cpp:470-477: rhs*dt + previous); t is the time
 	// the reference stamps on this rhs (src/asif_implicit_robust.cpp:567: i*backTrajDt for the step INTO sample i)
 	// POISON: the model's sin / cos never branch; out-of-range arguments turn the state into NaN (see sincos_fast)
-	template <bool HOLD, bool POISON = false>
+	template <bool HOLD, int POISON = kTrigChecked>
 	__device__ __forceinline__ static void eulerStepT(const DevOptions &o, double (&z)[NZ], Hold &hold, double t)
 	{
 		double x[NX], fCL[NX], DfCL[NX * NX], zd[NZ];

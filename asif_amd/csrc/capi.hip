@@ -213,6 +213,14 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 	dev.bevelL = o.satSharpness * std::tan(M_PI / 8);
 	dev.bevelStart = 1 - std::cos(M_PI / 4) * dev.bevelL;
 	dev.bevelStop = 1 + dev.bevelL;
+	{
+		const double lo = std::ldexp(1.0, -100), hi = std::ldexp(1.0, 100);
+		const bool ok = o.satSharpness >= lo && o.satSharpness <= hi && dev.bevelStop >= lo && dev.bevelStop <= hi &&
+		                dev.bevelStart > 0 && dev.bevelStart < dev.bevelStop && std::isfinite(o.lb[0]) &&
+		                std::isfinite(o.ub[0]) && o.lb[0] < o.ub[0];
+		dev.satFastOk = ok ? 1 : 0;
+	}
+
 	dev.satRange = o.ub[0] - o.lb[0];
 	dev.satMiddle = (o.ub[0] + o.lb[0]) / 2;
 	dev.twoOverRange = 2.0 / dev.satRange;

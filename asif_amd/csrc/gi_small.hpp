@@ -45,7 +45,53 @@ struct GiSmall {
 	static constexpr double kEqScore = 1e300;
 
 	// g: this lane's index in its group.  x: the optimum (when kGiOptimal is returned).  steps: iterations used.
+	//
+	// A variable pinned by its bounds (lb == ub) in EVERY QP of the wave is eliminated first -- the explicit class pins
+	// its relaxation variable (src/asif.cpp:88-91), which turns its 2-variable problem into a 1-variable one: with a
+	// diagonal cost the pinned coordinate decouples, its column moves to the right-hand side (b - a_j x_j), and the same
+	// method runs one dimension lower (a third of the instructions for nv = 2 -> 1).  Wave-uniform by construction
+	// (wave_all), so no lane diverges; a wave with mixed pins takes the general path below, where a pinned variable
+	// is pre-loaded into the working set instead.
 	ASIF_HD static int solve(const QpLaneData<NV, RPL> &in, int g, int max_steps, double (&x)[NV], int &steps)
+	{
+		if constexpr (NV >= 2) {
+			bool pinned[NV];
+#pragma unroll
+			for (int j = 0; j < NV; j++) pinned[j] = wave_all((in.lb[j] == in.ub[j]) & (fabs(in.lb[j]) < 1e300));
+			int verdict = -1;
+			unrolled_until<NV>([&](auto jc) {
+				constexpr int J = NV - 1 - decltype(jc)::value; // last variable first: the relaxation variables sit at the end
+				if (!pinned[J]) return false;
+				QpLaneData<NV - 1, RPL> red;
+				const double pin = in.lb[J];
+#pragma unroll
+				for (int k = 0; k < RPL; k++) {
+#pragma unroll
+					for (int j = 0; j < NV - 1; j++) red.A[k][j] = in.A[k][j < J ? j : j + 1];
+					red.b[k] = in.b[k] - in.A[k][J] * pin;
+					red.eq[k] = in.eq[k];
+				}
+#pragma unroll
+				for (int j = 0; j < NV - 1; j++) {
+					const int jj = j < J ? j : j + 1;
+					red.Hd[j] = in.Hd[jj];
+					red.c[j] = in.c[jj];
+					red.lb[j] = in.lb[jj];
+					red.ub[j] = in.ub[jj];
+				}
+				double xr[NV - 1];
+				verdict = GiSmall<NV - 1, RPL, G>::solve(red, g, max_steps, xr, steps);
+#pragma unroll
+				for (int j = 0; j < NV - 1; j++) x[j < J ? j : j + 1] = xr[j];
+				x[J] = pin;
+				return true;
+			});
+			if (verdict >= 0) return verdict;
+		}
+		return solve_general(in, g, max_steps, x, steps);
+	}
+
+	ASIF_HD static int solve_general(const QpLaneData<NV, RPL> &in, int g, int max_steps, double (&x)[NV], int &steps)
 	{
 		double Pinv[NV];
 		bool convex = true;

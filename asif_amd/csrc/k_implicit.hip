@@ -61,9 +61,19 @@ __device__ inline double learn_net(const DevOptions::Learn &L, int net, const do
 // dopri5 with dense output at the sample times instead of forward Euler.  The adaptive step straddles samples, so
 // there is no per-block restart point: one pass, the exact per-sample selection with the states parked in LDS
 // (the handful of Runge-Kutta steps per trajectory is cheap next to 5000 Euler steps; the samples are interpolations).
+// models whose tracked safety margin bounds their trig arguments (models.hpp: kTrigBoundedByMargin)
+template <class M, class = void>
+struct trig_by_margin : std::false_type {};
+template <class M>
+struct trig_by_margin<M, std::enable_if_t<M::kTrigBoundedByMargin>> : std::true_type {};
+
 template <class M, bool RB, bool DOPRI = false>
-__global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterArgs a)
+__global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, FilterArgs a)
 {
+	// the soft saturation selects between these two and the input: as kernel arguments (SGPRs) they are copied into
+	// VGPRs at every Euler step; an opaque copy made once, here, stays in two VGPR pairs for the whole kernel
+	DevOptions o = o_arg;
+	asm("" : "+v"(o.lb[0]), "+v"(o.ub[0]));
 	static_assert(!(RB && DOPRI), "the held input of ASIFimplicitRB makes the rhs time-dependent: Euler only");
 	constexpr int NX = M::NX, NP = M::NPSS, K = M::NPBTSS, NB = M::NPBS, NZ = NX + NX * NX;
 	constexpr int NC = K * NP + NB;
@@ -158,17 +168,22 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 		}
 	};
 	// One block at a time: its samples, then the step into the next block's first sample.  The block runs on the
-	// branch-free fast path (sincos_fast<true>); if that poisoned a lane's state (an argument outside the fast
-	// path's range, or NaN) the block is repeated from its start state with the checking version -- same results as
-	// checking at every step, without a wave-level branch in the common step.
+	// branch-free fast path of the model's sin / cos.  Its argument range is policed per block, not per step: either the
+	// fast path poisons the state of a lane whose argument left the range (kTrigPoison), or -- where the safety margin
+	// this loop tracks anyway bounds the argument (kTrigBoundedByMargin) -- the block's smallest margin is looked at
+	// (kTrigUnchecked: every step of run() starts from a sample whose margin went into bmin).  Either way the block is
+	// repeated from its start state with the checking version: same results as checking at every step, without a
+	// wave-level branch (and, by margin, without any per-step work) in the common step.
+	// The fast path also takes the soft saturation's short forms (BackupLoop::saturateSoft<FAST>), valid for ordinary
+	// saturation constants (DevOptions::satFastOk, checked on the host); other options run the generic step.
 	const int nblk = (o.npBT + MB - 1) / MB;
 #pragma unroll 1
 	for (int blk = 0; blk < nblk; blk++) {
 		const int s0 = blk * MB;
 		const int n = (o.npBT - s0) < MB ? (o.npBT - s0) : MB; // samples of this block
 		const bool more = s0 + n < o.npBT;
-		auto run = [&](auto poison) {
-			constexpr bool P = decltype(poison)::value;
+		auto run = [&](auto fast) {
+			constexpr int P = !decltype(fast)::value ? kTrigChecked : (trig_by_margin<M>::value ? kTrigUnchecked : kTrigPoison);
 			bmin = __builtin_huge_val();
 			auto sample = [&](int k) {
 				const int sidx = s0 + k;
@@ -191,16 +206,21 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o, FilterA
 			}
 			if (more) BackupLoop<M>::template eulerStepT<RB, P>(o, z, hold, (double)(unsigned)(s0 + n) * o.trajDt);
 		};
-		run(std::true_type());
-		bool bad = false;
+		bool redo = !o.satFastOk; // options outside the fast step's preconditions (uniform): generic step throughout
+		if (!redo) {
+			run(std::true_type());
+			bool bad = false;
 #pragma unroll
-		for (int c = 0; c < NZ; c++) bad = bad || (z[c] != z[c]);
-		if (__any(bad)) { // never on sane trajectories
+			for (int c = 0; c < NZ; c++) bad = bad || (z[c] != z[c]);
+			if constexpr (trig_by_margin<M>::value) bad = bad || !M::trigArgsBounded(bmin);
+			redo = __any(bad); // never on sane trajectories
+			if (redo) {
 #pragma unroll
-			for (int c = 0; c < NZ; c++) z[c] = zs[c];
-			hold = hs;
-			run(std::false_type());
+				for (int c = 0; c < NZ; c++) z[c] = zs[c];
+				hold = hs;
+			}
 		}
+		if (redo) run(std::false_type());
 		commit(blk);
 #pragma unroll
 		for (int c = 0; c < NZ; c++) zs[c] = z[c];

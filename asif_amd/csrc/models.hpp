@@ -24,6 +24,10 @@ struct DevOptions {
 	// soft-saturation bevel constants, evaluated ONCE on the host with libm exactly as the reference
 	// evaluates them per call (src/asif_implicit.cpp:689-703): r*tan(pi/8), 1-cos(pi/4)*bevelL, 1+bevelL
 	double bevelL, bevelStart, bevelStop;
+	// 1 when the saturation's constants are ordinary: 0 < bevelStart < bevelStop, satSharpness and bevelStop within
+	// 2^+-100, finite bounds lb < ub.  The trajectory kernels then run their steps on BackupLoop's fast forms (fewer
+	// compares, sqrt / divide without rescaling steps; same bits); otherwise on the generic ones.
+	int satFastOk;
 	// input range of the soft saturation, host-evaluated: ub-lb, (ub+lb)/2 and 2/(ub-lb).  The kernel
 	// forms uc = (u - middle) * twoOverRange where the reference divides, 2*(u-middle)/range
 	// (src/asif_implicit.cpp:696): one rounding of difference, no FP64 divide in the 5000-step loop.
@@ -83,11 +87,22 @@ __device__ __forceinline__ double fma_sc(double a, double b, double c)
 #endif
 }
 
-// POISON: no per-call branch at all -- a lane whose argument is outside the fast path's range (or NaN) gets NaN for
-// both results instead.  The NaN travels with the trajectory state, the caller looks for it once per block of samples
-// and repeats that block with the checking version (rollback in k_implicit.hip), so the results are those of the
-// checking version bit for bit while the common step saves a wave-level branch (~9 % of the pendulum's Euler step).
-template <bool POISON = false>
+// How the fast path's argument range (|x| <= 1e5) is policed (the same constant selects the backup loop's step form:
+// anything but kTrigChecked also takes BackupLoop::saturateSoft<FAST>, which needs DevOptions::satFastOk):
+//   kTrigChecked    one wave-level test per call and a branch that sane trajectories never take;
+//   kTrigPoison     no per-call branch at all -- a lane whose argument is outside the range (or NaN) gets NaN for both
+//                   results instead.  The NaN travels with the trajectory state, the caller looks for it once per block
+//                   of samples and repeats that block with the checking version (rollback in k_implicit.hip), so the
+//                   results are those of the checking version bit for bit while the common step saves a wave-level
+//                   branch (~9 % of the pendulum's Euler step);
+//   kTrigUnchecked  nothing here: the caller bounds the arguments of a whole block by other means (the pendulum's
+//                   safety margin pi - max(|x0|,|x1|) is tracked per sample anyway and bounds |x0|) and repeats the
+//                   block with the checking version when the bound fails -- five VALU issues per step less than the
+//                   poison.  NaN and +-inf arguments need no policing: the reduction below turns them into NaN for
+//                   both results, as libm does.
+constexpr int kTrigChecked = 0, kTrigPoison = 1, kTrigUnchecked = 2;
+constexpr double kTrigFastRange = 1e5;
+template <int POISON = kTrigChecked>
 __device__ __forceinline__ void sincos_fast(double x, double &s, double &c)
 {
 	const double n = rint(x * 6.36619772367581382433e-01);
@@ -110,8 +125,9 @@ __device__ __forceinline__ void sincos_fast(double x, double &s, double &c)
 	c = (q & 1) ? sr : cr;
 	if (q & 2) s = -s;
 	if ((q + 1) & 2) c = -c;
-	if constexpr (POISON) {
-		const bool big = !(fabs(x) <= 1e5);
+	if constexpr (POISON == kTrigUnchecked) return;
+	if constexpr (POISON == kTrigPoison) {
+		const bool big = !(fabs(x) <= kTrigFastRange);
 		s = big ? __builtin_nan("") : s;
 		c = big ? __builtin_nan("") : c;
 		return;
@@ -120,12 +136,12 @@ __device__ __forceinline__ void sincos_fast(double x, double &s, double &c)
 	// The reduction above is good to |x| <= 1e5.  Beyond that (or NaN) ocml's sincos overwrites the lane's result;
 	// one wave-level test and a branch that is never taken on sane trajectories, instead of an if/else whose two
 	// exec-mask sequences cost ~140 cycles per Euler step in a one-wave-per-SIMD dependent loop.
-	const bool big = !(fabs(x) <= 1e5);
+	const bool big = !(fabs(x) <= kTrigFastRange);
 	if (__builtin_expect(__any(big), 0)) {
 		if (big) sincos(x, &s, &c);
 	}
 #else
-	if (!(fabs(x) <= 1e5)) sincos(x, &s, &c);
+	if (!(fabs(x) <= kTrigFastRange)) sincos(x, &s, &c);
 #endif
 }
 
@@ -185,6 +201,11 @@ struct InvertedPendulum {
 		// a pair is fl(pi - |x_k|), and rounding is monotone (two instructions instead of seven in the 5000-step loop)
 		return kPi - fmax(fabs(x[0]), fabs(x[1]));
 	}
+	// |x0| <= pi - safetyMin: while the smallest margin of a block of samples stays above this floor, no sample of
+	// the block hands sincos_fast an argument near the end of its range (kTrigFastRange; the floor keeps 10 % clear of
+	// it so that rounding in the margin cannot matter) -- see kTrigUnchecked
+	static constexpr bool kTrigBoundedByMargin = true;
+	__device__ static bool trigArgsBounded(double hmin) { return hmin >= -0.9 * kTrigFastRange; }
 	// the same set on interval_t operands over x +- x_unc (ASIFimplicitRB's safetySet_int), lower ends
 	__device__ static void safetySetLo(const DevOptions &o, const double (&x)[NX], double (&h)[NPSS])
 	{
@@ -213,7 +234,7 @@ struct InvertedPendulum {
 		g[0] = 0.0;
 		g[1] = 1.0;
 	}
-	template <bool POISON = false>
+	template <int POISON = kTrigChecked>
 	__device__ static void dynamicsAndGradients(const DevOptions &, const double (&x)[NX], double (&f)[NX],
 	                                            double (&g)[NX * NU], double (&Df)[NX * NX], double (&Dg)[NX * NU * NX])
 	{
@@ -316,7 +337,7 @@ struct DoubleIntegratorImplicit {
 		g[0] = 0.0;
 		g[1] = 1.0;
 	}
-	template <bool POISON = false>
+	template <int POISON = kTrigChecked>
 	__device__ static void dynamicsAndGradients(const DevOptions &o, const double (&x)[NX], double (&f)[NX],
 	                                            double (&g)[NX * NU], double (&Df)[NX * NX], double (&Dg)[NX * NU * NX])
 	{
@@ -382,7 +403,7 @@ struct InvertedPendulumTB {
 	{
 		InvertedPendulum::dynamics(o, x, f, g);
 	}
-	template <bool POISON = false>
+	template <int POISON = kTrigChecked>
 	__device__ static void dynamicsAndGradients(const DevOptions &o, const double (&x)[NX], double (&f)[NX],
 	                                            double (&g)[NX * NU], double (&Df)[NX * NX], double (&Dg)[NX * NU * NX])
 	{
@@ -480,7 +501,7 @@ struct Segway {
 		Du[0] = K0; Du[1] = K1; Du[2] = K2; Du[3] = K3;
 	}
 	struct Trig { double s1, c1, s2, c2; };
-	template <bool POISON = false>
+	template <int POISON = kTrigChecked>
 	__device__ static Trig trig(double pitch)
 	{
 		Trig t;
@@ -517,7 +538,7 @@ struct Segway {
 		dynamicsT(x, trig(x[2]), f, g);
 	}
 	// :113-212
-	template <bool POISON = false>
+	template <int POISON = kTrigChecked>
 	__device__ static void dynamicsAndGradients(const DevOptions &, const double (&x)[NX], double (&f)[NX],
 	                                            double (&g)[NX * NU], double (&Df)[NX * NX], double (&Dg)[NX * NU * NX])
 	{

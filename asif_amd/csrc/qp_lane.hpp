@@ -6,6 +6,7 @@
 // arithmetic on the CPU against the oracle.  ASIF_HD is host+device under hipcc and plain inline under g++;
 // that is a host/device split of one code base, not a second implementation.
 #pragma once
+#include <type_traits>
 #include <math.h>
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -96,6 +97,16 @@ ASIF_HD int gmin_int(int p)
 	if (G >= 8) { const int o = dpp_xchg<4>(p); p = o < p ? o : p; }
 	if (G >= 16) { const int o = dpp_xchg<8>(p); p = o < p ? o : p; }
 	return p;
+}
+// compile-time loop with early exit: f(integral_constant<int, I>) for I = 0 .. N-1 until one returns true
+template <int N, int I = 0, class F>
+ASIF_HD bool unrolled_until(F &&f)
+{
+	if constexpr (I < N) {
+		if (f(std::integral_constant<int, I>())) return true;
+		return unrolled_until<N, I + 1>(f);
+	}
+	return false;
 }
 // every lane of the wavefront agrees (host: the one "lane")
 ASIF_HD bool wave_all(bool p)

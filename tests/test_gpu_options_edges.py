@@ -67,6 +67,11 @@ def _with_options(hip, oracle, cfg, **kw):
     (3, 96, dict(relaxLb=3.0, relaxReachLb=1.0, backTrajHorizon=0.75, backTrajDt=0.005, satSharpness=0.4, lb=-2.0, ub=1.0)),
     (4, 1024, dict(relaxTTS=5.0, relaxMinOrtho=10.0, backTrajHorizon=1.5, backTrajMinOrtho=0.01, relaxCost=25.0)),
     (5, 1024, dict(pMin=0.5, pMax=1.5, relaxLb=1.0, relaxCost=3.0)),
+    # saturation constants outside the fast Euler step's preconditions (DevOptions::satFastOk): the trajectory kernels
+    # run their generic step -- a sharpness below 2^-100 (no bevel to speak of), and a large one (bevelStart < 0)
+    (3, 96, dict(satSharpness=1e-31, backTrajHorizon=0.75, backTrajDt=0.005)),
+    (3, 96, dict(satSharpness=4.0, backTrajHorizon=0.75, backTrajDt=0.005)),
+    (4, 512, dict(satSharpness=1e-31, backTrajHorizon=1.0)),
 ])
 def test_non_default_options(hip, oracle, cfg, B, kw):
     o, oo = _with_options(hip, oracle, cfg, **kw)
