@@ -49,6 +49,7 @@ __host__ __device__ inline size_t lds_doubles(int nv, int nc, int vpt, int rpt, 
 	n += 64 * vpt * 2;                 // va, dinv
 	n += 64 * rpt;                     // vr
 	n += 5 * (64 * (size_t)(rpt + vpt)); // line-search view of all rows: s, dl, l, u, mu
+	n += 2 + 2 * 64 * (size_t)(rpt + vpt); // line-search evaluation points: 0, 1 and the breakpoints
 	n += 32 * rpt;                     // active-row list (int32)
 	return n;
 }
@@ -81,7 +82,7 @@ __device__ __forceinline__ double lane_get(double v, int src) // src wave-unifor
 template <int VPT, int RPT, bool FULLH>
 struct LdsQp {
 	// LDS
-	double *At, *S, *Pp, *va, *dinv, *vr, *ls_s, *ls_d, *ls_l, *ls_u, *ls_m;
+	double *At, *S, *Pp, *va, *dinv, *vr, *ls_s, *ls_d, *ls_l, *ls_u, *ls_m, *ls_t;
 	int *alist;
 	int lane, nv, nc, RS, NVP, nact;
 	// variables owned by this lane
@@ -107,8 +108,10 @@ struct LdsQp {
 		for (int r = 0; r < RPT; r++) {
 			double s = 0.0;
 			const int i = vj(r);
-			if (isr[r])
+			if (isr[r]) {
+#pragma unroll 8
 				for (int j = 0; j < nv; j++) s += (ABS ? fabs(At[j * RS + i]) : At[j * RS + i]) * va[j];
+			}
 			out[r] = s;
 		}
 		sync();
@@ -124,8 +127,10 @@ struct LdsQp {
 		for (int k = 0; k < VPT; k++) {
 			double s = 0.0;
 			const int j = vj(k);
-			if (isv[k])
+			if (isv[k]) {
+#pragma unroll 8
 				for (int i = 0; i < nc; i++) s += (ABS ? fabs(At[j * RS + i]) : At[j * RS + i]) * vr[i];
+			}
 			out[k] = s;
 		}
 		sync();
@@ -142,8 +147,10 @@ struct LdsQp {
 			for (int k = 0; k < VPT; k++) {
 				double s = 0.0;
 				const int j = vj(k);
-				if (isv[k])
+				if (isv[k]) {
+#pragma unroll 8
 					for (int c = 0; c < nv; c++) s += (ABS ? fabs(Pp[pidx(c, j)]) : Pp[pidx(c, j)]) * va[c];
+				}
 				out[k] = s;
 			}
 			sync();
@@ -261,23 +268,39 @@ struct LdsQp {
 		}
 		nact = base;
 		sync();
-		// upper triangle, row-major: S[c][j], j >= c  (lane owns column index j)
+		// upper triangle, row-major: S[c][j], j >= c  (lane owns column index j), eight entries of the column at a
+		// time in registers: per active row one dependent read pair (its index, this lane's coefficient) feeds eight
+		// independent broadcast reads, instead of an exposed LDS latency per term
 #pragma unroll
 		for (int k = 0; k < VPT; k++) {
 			const int j = vj(k);
 			if (isv[k]) {
-				for (int c = 0; c <= j; c++) {
-					double s = 0.0;
-					if constexpr (FULLH) s = Pp[pidx(c, j)];
+				for (int c0 = 0; c0 <= j; c0 += 8) {
+					double acc[8];
+#pragma unroll
+					for (int u = 0; u < 8; u++) acc[u] = 0.0;
 					for (int t = 0; t < nact; t++) {
 						const int i = alist[t];
-						s += vr[i] * At[c * RS + i] * At[j * RS + i];
+						const double w = vr[i] * At[j * RS + i];
+#pragma unroll
+						for (int u = 0; u < 8; u++) {
+							const int c = c0 + u < nv ? c0 + u : nv - 1;
+							acc[u] += w * At[c * RS + i];
+						}
 					}
-					if (c == j) {
-						if constexpr (!FULLH) s += Pd[k];
-						s += 1.0 / kLdsGamma + (actb[k] ? mub[k] * ab[k] * ab[k] : 0.0);
+#pragma unroll
+					for (int u = 0; u < 8; u++) {
+						const int c = c0 + u;
+						if (c <= j) {
+							double sv = acc[u];
+							if constexpr (FULLH) sv += Pp[pidx(c, j)];
+							if (c == j) {
+								if constexpr (!FULLH) sv += Pd[k];
+								sv += 1.0 / kLdsGamma + (actb[k] ? mub[k] * ab[k] * ab[k] : 0.0);
+							}
+							S[c * NVP + j] = sv;
+						}
 					}
-					S[c * NVP + j] = s;
 				}
 			}
 		}
@@ -293,12 +316,24 @@ struct LdsQp {
 				const int j = vj(v);
 				ljk[v] = (isv[v] && j > k) ? S[k * NVP + j] * inv : 0.0;
 			}
-			for (int c = k + 1; c < nv; c++) {
-				const double sc = S[k * NVP + c];
+			// rows c > k of the trailing block, both triangles (the lower one is scratch until its column is final):
+			// one exec mask for the whole loop instead of a compare per entry, reads eight rows deep
 #pragma unroll
-				for (int v = 0; v < VPT; v++) {
-					const int j = vj(v);
-					if (isv[v] && j >= c) S[c * NVP + j] -= ljk[v] * sc;
+			for (int v = 0; v < VPT; v++) {
+				const int j = vj(v);
+				if (isv[v] && j > k) {
+					for (int c0 = k + 1; c0 < nv; c0 += 8) { // all sixteen reads before the first write
+						double sc[8], sv[8];
+#pragma unroll
+						for (int u = 0; u < 8; u++) {
+							const int c = c0 + u < nv ? c0 + u : nv - 1;
+							sc[u] = S[k * NVP + c];
+							sv[u] = S[c * NVP + j];
+						}
+#pragma unroll
+						for (int u = 0; u < 8; u++)
+							if (c0 + u < nv) S[(c0 + u) * NVP + j] = sv[u] - ljk[v] * sc[u];
+					}
 				}
 			}
 			sync();
@@ -319,24 +354,46 @@ struct LdsQp {
 	// r <- K^-1 r  (registers; pivots broadcast by v_readlane, factor rows from LDS)
 	__device__ __forceinline__ void solve(double (&r)[VPT])
 	{
-		for (int k = 0; k < nv - 1; k++) {
-			double rk = lane_get(r[0], k & 63);
-			if (VPT > 1 && k >= 64) rk = lane_get(r[VPT - 1], k & 63);
+		// four pivots at a time: their factor rows are read before the first dependent step (the rows do not depend on
+		// the substitution, only the broadcast right-hand sides do)
+		for (int k0 = 0; k0 < nv - 1; k0 += 4) {
+			double f[4][VPT];
 #pragma unroll
-			for (int v = 0; v < VPT; v++) {
-				const int j = vj(v);
-				if (isv[v] && j > k) r[v] -= S[k * NVP + j] * rk;
+			for (int u = 0; u < 4; u++) {
+				const int k = k0 + u < nv - 1 ? k0 + u : nv - 2;
+#pragma unroll
+				for (int v = 0; v < VPT; v++) f[u][v] = (isv[v] && vj(v) > k) ? S[k * NVP + vj(v)] : 0.0;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int k = k0 + u;
+				if (k < nv - 1) {
+					double rk = lane_get(r[0], k & 63);
+					if (VPT > 1 && k >= 64) rk = lane_get(r[VPT - 1], k & 63);
+#pragma unroll
+					for (int v = 0; v < VPT; v++) r[v] -= f[u][v] * rk;
+				}
 			}
 		}
 #pragma unroll
 		for (int v = 0; v < VPT; v++) r[v] = isv[v] ? r[v] * dinv[vj(v)] : 0.0;
-		for (int k = nv - 1; k >= 1; k--) {
-			double rk = lane_get(r[0], k & 63);
-			if (VPT > 1 && k >= 64) rk = lane_get(r[VPT - 1], k & 63);
+		for (int k0 = nv - 1; k0 >= 1; k0 -= 4) {
+			double f[4][VPT];
 #pragma unroll
-			for (int v = 0; v < VPT; v++) {
-				const int j = vj(v);
-				if (j < k) r[v] -= S[k * NVP + j] * rk;
+			for (int u = 0; u < 4; u++) {
+				const int k = k0 - u >= 1 ? k0 - u : 1;
+#pragma unroll
+				for (int v = 0; v < VPT; v++) f[u][v] = vj(v) < k ? S[k * NVP + vj(v)] : 0.0;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int k = k0 - u;
+				if (k >= 1) {
+					double rk = lane_get(r[0], k & 63);
+					if (VPT > 1 && k >= 64) rk = lane_get(r[VPT - 1], k & 63);
+#pragma unroll
+					for (int v = 0; v < VPT; v++) r[v] -= f[u][v] * rk;
+				}
 			}
 		}
 	}
@@ -372,6 +429,7 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 		s.ls_l = p; p += m;
 		s.ls_u = p; p += m;
 		s.ls_m = p; p += m;
+		s.ls_t = p; p += 2 + 2 * m;
 		s.alist = (int *)p;
 	}
 	// ---- form translation (src/qpwrapper_osqp.cpp:263-376): P = 2H, q = c, rows [A; I], l = [b; lb], u = [inf | b; ub]
@@ -438,11 +496,19 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 #pragma unroll
 	for (int k = 0; k < VPT; k++) pactb[k] = false;
 	double pri_prev = -1.0, best_res = 1e300;
+	// section timers of a scratch build (tools/dev_lds_sections.py); compiled out of the library
+#ifdef ASIF_LDS_PROFILE
+	long long tsec[6] = {0, 0, 0, 0, 0, 0}, tmark = __builtin_readcyclecounter();
+#define LDS_T(k) { const long long tn_ = __builtin_readcyclecounter(); tsec[k] += tn_ - tmark; tmark = tn_; }
+#else
+#define LDS_T(k)
+#endif
 
 	for (int outer = 0; outer < kLdsMaxOuter && status == 0; outer++) {
 		double sr[RPT], sb[VPT]; // s = a.x + y/mu of the rows / bounds at the current x
-		double gfloor = 0.0;
+		double gfloor = 0.0, gscale = 1.0;
 		for (int inner = 0; inner < kLdsMaxInner; inner++) {
+			LDS_T(5)
 			// ---- gradient of the inner objective
 			double ax[RPT], rr[RPT], px[VPT], atr[VPT], g[VPT];
 			s.row_dot(s.x, ax);
@@ -456,9 +522,13 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 			}
 			s.col_dot(rr, atr);
 			s.p_mul(s.x, px);
+			// scale of the gradient's own terms (a sum of large cancelling terms must not look like a small gradient):
+			// an order of magnitude, taken at the first step of each inner solve and kept for the rest of it
 			double atra[VPT], pxa[VPT];
-			s.template col_dot<true>(rr, atra);
-			s.template p_mul<true>(s.x, pxa);
+			if (inner == 0) {
+				s.template col_dot<true>(rr, atra);
+				s.template p_mul<true>(s.x, pxa);
+			}
 			double gn = 0.0, gs = 0.0;
 			bool changed = !have_factor;
 			double rbv[VPT];
@@ -472,14 +542,14 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 				const double ay = atr[k] + s.ab[k] * rb;
 				g[k] = s.isv[k] ? px[k] + s.q[k] + (s.x[k] - s.xh[k]) * (1.0 / kLdsGamma) + ay : 0.0;
 				gn = fmax(gn, fabs(g[k]));
-				// scale of the gradient's own terms (a sum of large cancelling terms must not look like a small gradient)
-				gs = fmax(gs, fmax(pxa[k], fmax(fabs(s.q[k]), atra[k] + fabs(s.ab[k] * rb))));
+				if (inner == 0) gs = fmax(gs, fmax(pxa[k], fmax(fabs(s.q[k]), atra[k] + fabs(s.ab[k] * rb))));
 				changed = changed || (actb[k] != pactb[k]);
 			}
 #pragma unroll
 			for (int r = 0; r < RPT; r++) changed = changed || (actr[r] != pactr[r]);
 			gn = wmax(gn);
-			gs = 1.0 + wmax(gs);
+			if (inner == 0) gscale = 1.0 + wmax(gs);
+			gs = gscale;
 			if (inner == 0) {
 				// rounding floor of the gradient: r_i = mu_i (s_i - proj s_i) carries mu_i eps (terms of s_i)
 				double axa[RPT], er[RPT], fl[VPT];
@@ -500,6 +570,7 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 				gfloor = wmax(f) + 2.2e-16 * gs;
 			}
 			(void)rbv;
+			LDS_T(0)
 			if (gn <= 0.1 * tol * gs || gn <= 8.0 * gfloor) break;
 			if (newton >= max_newton) break;
 			// ---- Newton direction on the current active set
@@ -511,10 +582,12 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 #pragma unroll
 				for (int k = 0; k < VPT; k++) pactb[k] = actb[k];
 			}
+			LDS_T(1)
 			double d[VPT];
 #pragma unroll
 			for (int k = 0; k < VPT; k++) d[k] = -g[k];
 			s.solve(d);
+			LDS_T(2)
 			newton++;
 			// ---- exact line search: phi'(t) = qa + t a1 + sum_i mu_i dl_i (s_i + t dl_i - proj(s_i + t dl_i))
 			double dl[RPT], pd[VPT];
@@ -561,44 +634,55 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 			s.sync();
 			auto dphi = [&](double t) {
 				double f = qa + t * a1;
+#pragma unroll 4
 				for (int i = 0; i < nc; i++) { // general rows
 					const double st = s.ls_s[i] + t * s.ls_d[i];
 					f += s.ls_m[i] * s.ls_d[i] * (st - fmin(fmax(st, s.ls_l[i]), s.ls_u[i]));
 				}
+#pragma unroll 4
 				for (int i = 64 * RPT; i < 64 * RPT + nv; i++) { // bounds
 					const double st = s.ls_s[i] + t * s.ls_d[i];
 					f += s.ls_m[i] * s.ls_d[i] * (st - fmin(fmax(st, s.ls_l[i]), s.ls_u[i]));
 				}
 				return f;
 			};
-			// bracket of the zero of phi' among {0} u breakpoints u {1}
+			// bracket of the zero of phi' among {0} u breakpoints u {1}.  The evaluation points go into one list (0, 1,
+			// then the breakpoints in (0, 1], compacted by ballots) and every lane evaluates phi' at its own point:
+			// one pass over the rows for up to 64 points instead of one pass per point.
 			double tlo = 0.0, flo = 0.0, thi = 2.0, fhi = 0.0;
 			{
-				const double f0 = dphi(0.0), f1 = dphi(1.0);
-				flo = f0;
-				if (f1 >= 0.0) { thi = 1.0; fhi = f1; }
-				bool anyb = false;
+				int npt = 2;
+				if (lane == 0) s.ls_t[0] = 0.0;
+				if (lane == 1) s.ls_t[1] = 1.0;
 #pragma unroll
-				for (int e = 0; e < 2 * (RPT + VPT); e++) anyb = anyb || bp[e] <= 1.0;
-				if (__any(anyb)) {
-#pragma unroll
-					for (int e = 0; e < 2 * (RPT + VPT); e++) {
-						if (__any(bp[e] <= 1.0)) {
-							const double tb = bp[e] <= 1.0 ? bp[e] : 1.0;
-							const double fb = dphi(tb);
-							// best lower bracket: largest t with f < 0; best upper: smallest t with f >= 0
-							const double cl = (bp[e] <= 1.0 && fb < 0.0) ? tb : -1.0;
-							const double ch = (bp[e] <= 1.0 && fb >= 0.0) ? tb : 3.0;
-							const double gl = wmax(cl), gh = wmin(ch);
-							if (gl > tlo) {
-								tlo = gl;
-								flo = wmax(cl == gl ? fb : -1e300); // f at that breakpoint (negative: max picks it among ties)
-							}
-							if (gh < thi) {
-								thi = gh;
-								fhi = wmin(ch == gh ? fb : 1e300);
-							}
-						}
+				for (int e = 0; e < 2 * (RPT + VPT); e++) {
+					const bool v = bp[e] <= 1.0;
+					const unsigned long long m = __ballot(v);
+					if (v) s.ls_t[npt + __popcll(m & ((1ull << lane) - 1ull))] = bp[e];
+					npt += __popcll(m);
+				}
+				s.sync();
+				for (int base = 0; base < npt; base += 64) {
+					const bool mine = base + lane < npt;
+					const double tb = mine ? s.ls_t[base + lane] : 1.0;
+					const double fb = dphi(tb);
+					if (base == 0) {
+						const double f0 = lane_get(fb, 0), f1 = lane_get(fb, 1);
+						flo = f0;
+						if (f1 >= 0.0) { thi = 1.0; fhi = f1; }
+					}
+					const bool isbp = mine && (base + lane >= 2);
+					// best lower bracket: largest t with f < 0; best upper: smallest t with f >= 0
+					const double cl = (isbp && fb < 0.0) ? tb : -1.0;
+					const double ch = (isbp && fb >= 0.0) ? tb : 3.0;
+					const double gl = wmax(cl), gh = wmin(ch);
+					if (gl > tlo) {
+						tlo = gl;
+						flo = wmax(cl == gl ? fb : -1e300); // f at that breakpoint (negative: max picks it among ties)
+					}
+					if (gh < thi) {
+						thi = gh;
+						fhi = wmin(ch == gh ? fb : 1e300);
 					}
 				}
 				s.sync();
@@ -608,7 +692,9 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 			if (!(t > 0.0)) t = thi <= 1.0 ? thi : 1.0; // degenerate bracket: take the upper end
 #pragma unroll
 			for (int k = 0; k < VPT; k++) s.x[k] += t * d[k];
+			LDS_T(3)
 		}
+		LDS_T(5)
 		// ---- multiplier update, residuals, certificates
 		double ax[RPT], ynew[RPT], aty[VPT], px[VPT];
 		s.row_dot(s.x, ax);
@@ -696,6 +782,7 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 			}
 		}
 		pri_prev = pri;
+		LDS_T(4)
 	}
 	if (status == 0 || status == kStatusMaxIter) {
 		// budget spent: OSQP's "solved inaccurate" counts as solved for the wrapper (src/qpwrapper_osqp.cpp:225)
@@ -708,6 +795,11 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 		a.status[qi] = status;
 		if (a.iters) a.iters[qi] = newton;
 	}
+#ifdef ASIF_LDS_PROFILE
+	if (lane == 0)
+		for (int k = 0; k < 6; k++) a.sol[(int64_t)k * ld + qi] = (double)tsec[k]; // scratch build: times instead of x
+#endif
+#undef LDS_T
 }
 
 } // namespace asif
