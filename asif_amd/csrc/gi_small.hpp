@@ -91,8 +91,49 @@ struct GiSmall {
 		return solve_general(in, g, max_steps, x, steps);
 	}
 
+	// One variable (where the elimination above leaves the explicit class's QP): the working set holds one constraint,
+	// every step of the method is a move to the nearest end of the feasible interval, and the whole iteration collapses
+	// into its fixed point -- clip the unconstrained minimiser to the intersection [lo, hi] of the half-lines the rows
+	// and bounds define.  Verdicts as the general path gives them: a row without the variable (a == 0 exactly; the
+	// general path's dependence test on an empty working set is exact too) or a pair of rows that exclude each other
+	// is a conflict only beyond kActiveTol relative to the row's own terms, checked on the residuals at the clipped
+	// point (a conflict below that is a degenerate vertex and counts as met).
+	ASIF_HD static int solve_1d(const QpLaneData<NV, RPL> &in, int g, double (&x)[NV], int &steps)
+	{
+		const double P = 2.0 * in.Hd[0];
+		steps = 0;
+		if (!wave_all(P > 0.0)) return kGiUndecided;
+		const double xu = -in.c[0] / (P > 0.0 ? P : 1.0);
+		double lo = in.lb[0], hi = in.ub[0];
+#pragma unroll
+		for (int k = 0; k < RPL; k++) {
+			const double a = in.A[k][0];
+			const double q = in.b[k] / (a != 0.0 ? a : 1.0);
+			lo = ((a > 0.0) | (in.eq[k] & (a < 0.0))) ? fmax(lo, q) : lo;
+			hi = ((a < 0.0) | (in.eq[k] & (a > 0.0))) ? fmin(hi, q) : hi;
+		}
+		lo = gmax<G>(lo);
+		hi = gmin<G>(hi);
+		const double xs = fmin(fmax(xu, lo), hi);
+		int bad = 0;
+#pragma unroll
+		for (int k = 0; k < RPL; k++) {
+			const double t = in.A[k][0] * xs;
+			const double res = in.b[k] - t;
+			const double v = in.eq[k] ? fabs(res) : res;
+			bad |= (v > kActiveTol * (1.0 + fabs(in.b[k]) + fabs(t))) ? 1 : 0;
+		}
+		bad |= (in.lb[0] - xs > kActiveTol * (1.0 + fabs(xs) + fabs(in.lb[0]))) ? 1 : 0;
+		bad |= (xs - in.ub[0] > kActiveTol * (1.0 + fabs(xs) + fabs(in.ub[0]))) ? 1 : 0;
+		bad = gor<G>(bad);
+		x[0] = xs;
+		steps = 1;
+		return bad ? kGiInfeasible : kGiOptimal;
+	}
+
 	ASIF_HD static int solve_general(const QpLaneData<NV, RPL> &in, int g, int max_steps, double (&x)[NV], int &steps)
 	{
+		if constexpr (NV == 1) return solve_1d(in, g, x, steps);
 		double Pinv[NV];
 		bool convex = true;
 #pragma unroll

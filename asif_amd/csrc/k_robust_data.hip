@@ -52,16 +52,7 @@ struct RbRows {
 };
 
 template <int G>
-__device__ __forceinline__ double gmin(double v)
-{
-	if (G >= 2) v = fmin(v, dpp_xchg<1>(v));
-	if (G >= 4) v = fmin(v, dpp_xchg<2>(v));
-	if (G >= 8) v = fmin(v, dpp_xchg<4>(v));
-	if (G >= 16) v = fmin(v, dpp_xchg<8>(v));
-	return v;
-}
-template <int G>
-__device__ __forceinline__ int gmin(int v)
+__device__ __forceinline__ int gmini(int v)
 {
 	if (G >= 2) v = min(v, dpp_xchg<1>(v));
 	if (G >= 4) v = min(v, dpp_xchg<2>(v));
@@ -106,7 +97,7 @@ __device__ __forceinline__ void robust_data_rows(const RbDev &z, double x0, doub
 		R.idx[k] = 0;
 		if (k < z.npSSmax) { // wave-uniform
 			const double hm = gmin<G>(lh[0]);
-			const int im = gmin<G>(lh[0] == hm ? li[0] : 0x7fffffff);
+			const int im = gmini<G>(lh[0] == hm ? li[0] : 0x7fffffff);
 			R.h[k] = hm;
 			R.idx[k] = im;
 			const bool mine = (lh[0] == hm) && (li[0] == im);

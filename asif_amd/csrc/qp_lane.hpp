@@ -72,6 +72,15 @@ ASIF_HD double gmax(double v)
 	return v;
 }
 template <int G>
+ASIF_HD double gmin(double v)
+{
+	if (G >= 2) v = fmin(v, dpp_xchg<1>(v));
+	if (G >= 4) v = fmin(v, dpp_xchg<2>(v));
+	if (G >= 8) v = fmin(v, dpp_xchg<4>(v));
+	if (G >= 16) v = fmin(v, dpp_xchg<8>(v));
+	return v;
+}
+template <int G>
 ASIF_HD int gand(int p)
 {
 	if (G >= 2) p &= dpp_xchg<1>(p);
