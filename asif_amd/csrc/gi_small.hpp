@@ -52,6 +52,36 @@ struct GiSmall {
 	// method runs one dimension lower (a third of the instructions for nv = 2 -> 1).  Wave-uniform by construction
 	// (wave_all), so no lane diverges; a wave with mixed pins takes the general path below, where a pinned variable
 	// is pre-loaded into the working set instead.
+	// the elimination itself, for a variable J the caller knows to be pinned in every QP of the wave
+	template <int J>
+	ASIF_HD static int solve_with_pinned(const QpLaneData<NV, RPL> &in, int g, int max_steps, double (&x)[NV], int &steps)
+	{
+		static_assert(NV >= 2 && J >= 0 && J < NV, "a variable to eliminate and one to keep");
+		QpLaneData<NV - 1, RPL> red;
+		const double pin = in.lb[J];
+#pragma unroll
+		for (int k = 0; k < RPL; k++) {
+#pragma unroll
+			for (int j = 0; j < NV - 1; j++) red.A[k][j] = in.A[k][j < J ? j : j + 1];
+			red.b[k] = in.b[k] - in.A[k][J] * pin;
+			red.eq[k] = in.eq[k];
+		}
+#pragma unroll
+		for (int j = 0; j < NV - 1; j++) {
+			const int jj = j < J ? j : j + 1;
+			red.Hd[j] = in.Hd[jj];
+			red.c[j] = in.c[jj];
+			red.lb[j] = in.lb[jj];
+			red.ub[j] = in.ub[jj];
+		}
+		double xr[NV - 1];
+		const int verdict = GiSmall<NV - 1, RPL, G>::solve(red, g, max_steps, xr, steps);
+#pragma unroll
+		for (int j = 0; j < NV - 1; j++) x[j < J ? j : j + 1] = xr[j];
+		x[J] = pin;
+		return verdict;
+	}
+
 	ASIF_HD static int solve(const QpLaneData<NV, RPL> &in, int g, int max_steps, double (&x)[NV], int &steps)
 	{
 		if constexpr (NV >= 2) {
@@ -62,28 +92,7 @@ struct GiSmall {
 			unrolled_until<NV>([&](auto jc) {
 				constexpr int J = NV - 1 - decltype(jc)::value; // last variable first: the relaxation variables sit at the end
 				if (!pinned[J]) return false;
-				QpLaneData<NV - 1, RPL> red;
-				const double pin = in.lb[J];
-#pragma unroll
-				for (int k = 0; k < RPL; k++) {
-#pragma unroll
-					for (int j = 0; j < NV - 1; j++) red.A[k][j] = in.A[k][j < J ? j : j + 1];
-					red.b[k] = in.b[k] - in.A[k][J] * pin;
-					red.eq[k] = in.eq[k];
-				}
-#pragma unroll
-				for (int j = 0; j < NV - 1; j++) {
-					const int jj = j < J ? j : j + 1;
-					red.Hd[j] = in.Hd[jj];
-					red.c[j] = in.c[jj];
-					red.lb[j] = in.lb[jj];
-					red.ub[j] = in.ub[jj];
-				}
-				double xr[NV - 1];
-				verdict = GiSmall<NV - 1, RPL, G>::solve(red, g, max_steps, xr, steps);
-#pragma unroll
-				for (int j = 0; j < NV - 1; j++) x[j < J ? j : j + 1] = xr[j];
-				x[J] = pin;
+				verdict = solve_with_pinned<J>(in, g, max_steps, x, steps);
 				return true;
 			});
 			if (verdict >= 0) return verdict;

@@ -11,8 +11,8 @@
 
 namespace asif {
 
-// PRE = asif_hip_solver::presolve: its own instantiation, so that the closed-form path does not carry the
-// solver's register footprint.
+// PRE: the instantiation for problems the dual active-set stage is known to decide on its own (one input, default
+// solver mode or asif_hip_solver::presolve): no ADMM / finish code, hence none of their register footprint.
 // SEL: the optional paths of src/asif.cpp (npSSmax < npSS row selection, caller-supplied Lie derivatives) are
 // compiled in; the default instantiation (every row, the model's own Lie derivatives) does not carry them.
 template <class M, int G, bool PRE, bool SEL = false>
@@ -95,37 +95,6 @@ __global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_f
 		return;
 	}
 
-	if constexpr (PRE) {
-		static_assert(NU == 1, "closed form needs a single input");
-		// The explicit class pins its relaxation variable (lb = ub = relaxLb, src/asif.cpp:88-91), so with one
-		// input the QP is  min (u - uDes)^2  s.t.  Lgh_r u >= -Lfh_r - h_r relaxLb,  lb <= u <= ub:  a clip.
-		double lo = o.lb[0], hi = o.ub[0];
-		bool feasible = true;
-#pragma unroll
-		for (int r = 0; r < NC; r++) {
-			const double a_ = Lgh[r], rhs = pos[r] < nkeep ? -Lfh[r] - h[r] * o.relaxLb : -1.0;
-			if (a_ > 0.0) lo = fmax(lo, rhs / a_);
-			else if (a_ < 0.0) hi = fmin(hi, rhs / a_);
-			else if (rhs > 0.0) feasible = false;
-		}
-		feasible = feasible && (lo <= hi);
-		if (live && g == 0) {
-			if (feasible) {
-				a.uact[i] = fmin(fmax(fmin(fmax(uDes[0], lo), hi), o.lb[0]), o.ub[0]);
-				a.relax[i] = o.relaxLb;
-				a.rc[i] = ASIF_HIP_RC_OK;
-			} else {
-				a.rc[i] = ASIF_HIP_RC_QP_FAILED;
-			}
-			if (a.diag) {
-				a.diag[0 * a.ld + i] = 0.0;
-				a.diag[1 * a.ld + i] = 0.0;
-				a.diag[(a.ndiag - 1) * a.ld + i] = 0.0;
-			}
-		}
-		return;
-	}
-
 	QpLaneData<NV, RPL> qp;
 #pragma unroll
 	for (int j = 0; j < NU; j++) {
@@ -154,6 +123,32 @@ __global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_f
 				qp.b[k] = -Lfh[r];
 			}
 	}
+	if constexpr (PRE) {
+		static_assert(NU == 1 && G == 1, "one input: the pinned relaxation variable leaves a one-variable problem");
+		// The explicit class pins its relaxation variable (lb = ub = relaxLb, src/asif.cpp:88-91): the dual active-set
+		// stage eliminates it and what is left has one variable, which that stage always decides (gi_small.hpp:
+		// solve_1d -- optimal or infeasible, never "undecided").  This instantiation therefore carries neither the ADMM
+		// iterations nor the finish: 40 VGPRs instead of 256 + AGPRs, eight waves per SIMD instead of one.
+		double sol[NV];
+		int steps;
+		const int verdict = GiSmall<NV, RPL, G>::template solve_with_pinned<NU>(qp, g, 8 * NV + 4, sol, steps);
+		if (live) {
+			if (verdict == kGiOptimal) {
+				a.uact[i] = fmin(fmax(sol[0], o.lb[0]), o.ub[0]);
+				a.relax[i] = sol[NU];
+				a.rc[i] = ASIF_HIP_RC_OK;
+			} else {
+				a.rc[i] = ASIF_HIP_RC_QP_FAILED; // uAct and relax stay untouched, src/asif.cpp:208-209
+			}
+			if (a.diag) {
+				a.diag[0 * a.ld + i] = 0.0;
+				a.diag[1 * a.ld + i] = 0.0;
+				a.diag[(a.ndiag - 1) * a.ld + i] = 0.0;
+			}
+		}
+		return;
+	}
+
 	AdmmSmall<NV, RPL, G> admm;
 	double sol[NV];
 	int status, iters;
@@ -303,7 +298,9 @@ int launch_explicit_di(const DevOptions &o, const asif_hip_solver &S, const Filt
                        hipStream_t stream)
 {
 	if (a.B <= 0) return 0;
-	if (S.presolve && !assemble_only) { // closed form, one instance per lane, larger blocks (tiny register footprint)
+	// default solver mode (dual active-set stage first) or presolve: that stage alone decides every instance of this
+	// class with one input -- the light instantiation, one instance per lane, larger blocks
+	if ((S.presolve || (S.polish == 2 && S.lanes_per_qp <= 1)) && !assemble_only) {
 		const int block = 256;
 		if (o.npKeep < DoubleIntegrator::NPSS || a.lfh != nullptr)
 			hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, 1, true, true>), dim3(grid_for(a.B, 1, block)),

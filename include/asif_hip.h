@@ -45,10 +45,12 @@
 extern "C" {
 #endif
 
-#define ASIF_HIP_VERSION 130 /* 110: realizable / robust-data handles, solver.presolve, scaling_iters 0 = default;
+#define ASIF_HIP_VERSION 131 /* 110: realizable / robust-data handles, solver.presolve, scaling_iters 0 = default;
                               * 120: ASIF_HIP_IMPLICIT_RB (options grew at the end), asif_hip_set_learning, asif_hip_affine_replay;
                               * 130: solver.adaptive_rho_interval (struct grew at the end), polish == 2 is the dual active-set
-                              *      stage of gi_small.hpp */
+                              *      stage of gi_small.hpp;
+                              * 131: that stage eliminates variables pinned by their bounds and solves one-variable problems in
+                              *      closed form; class ASIF with one input runs on a kernel without the iterative stages */
 
 enum asif_hip_error {
 	ASIF_HIP_OK = 0,
@@ -157,7 +159,9 @@ typedef struct asif_hip_solver {
 	/* 1: eliminate variables whose bounds pin them (lb == ub) before the solve and, when one free variable is left,
 	 * take the closed-form optimum (a clip) instead of iterating.  Applies to the explicit class ASIF, whose
 	 * relaxation variable is pinned by construction (src/asif.cpp:88-91).  Same optimum, same return codes.
-	 * Default 0: every QP goes through the in-kernel ADMM the way the reference sends every QP through OSQP. */
+	 * Default 0.  (Since version 131 the default solver mode, polish == 2, reaches the same one-variable solve through
+	 * the dual active-set stage's elimination of pinned variables and takes the same light kernel; presolve = 1 asks
+	 * for it under polish 0 / 1 as well.) */
 	int32_t presolve;
 	/* asif_hip_rollout_batch only.  1 (default): from the second control step on, the first finish attempt starts from
 	 * the working set the previous step ended with (iterates still start from zero) -- the batched analogue of the
