@@ -61,11 +61,6 @@ __device__ inline double learn_net(const DevOptions::Learn &L, int net, const do
 // dopri5 with dense output at the sample times instead of forward Euler.  The adaptive step straddles samples, so
 // there is no per-block restart point: one pass, the exact per-sample selection with the states parked in LDS
 // (the handful of Runge-Kutta steps per trajectory is cheap next to 5000 Euler steps; the samples are interpolations).
-// models whose tracked safety margin bounds their trig arguments (models.hpp: kTrigBoundedByMargin)
-template <class M, class = void>
-struct trig_by_margin : std::false_type {};
-template <class M>
-struct trig_by_margin<M, std::enable_if_t<M::kTrigBoundedByMargin>> : std::true_type {};
 
 template <class M, bool RB, bool DOPRI = false>
 __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, FilterArgs a)

@@ -18,6 +18,7 @@
 
 namespace asif {
 
+
 template <class M>
 __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArgs a)
 {
@@ -77,11 +78,13 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 	bool done, hit;
 	int idxHit, sLast;
 	double t, tHit;
-	// The whole pass runs on the branch-free trig fast path (sincos_fast<true>: an argument outside its range turns
-	// the lane's state into NaN instead of taking a wave-level branch at every step); a poisoned lane is found
-	// after the pass -- NaN never enters the backup set -- and the pass is then repeated with the checking version.
-	auto pass1 = [&](auto poison) {
-		constexpr bool P = decltype(poison)::value;
+	// The whole pass runs on the branch-free trig fast path; its argument range is policed once, after the pass: by
+	// the smallest safety margin seen (kTrigUnchecked: these models' margins bound the trig arguments, models.hpp) or
+	// by NaN poisoning (kTrigPoison: an argument outside the range turns the lane's state into NaN -- NaN never enters
+	// the backup set).  A lane out of range has the pass repeated with the checking version.
+	double hall; // smallest safety margin of the whole pass (kTrigUnchecked: it bounds the trig arguments)
+	auto pass1 = [&](auto fast) {
+		constexpr int P = !decltype(fast)::value ? kTrigChecked : (trig_by_margin<M>::value ? kTrigUnchecked : kTrigPoison);
 #pragma unroll
 		for (int k = 0; k < NZ; k++) z[k] = 0.0;
 #pragma unroll
@@ -98,6 +101,7 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 			for (int k = 0; k < NZ; k++) ck[k * ld] = z[k]; // block 0 starts at sample 0
 		}
 		bmin = M::safetyMin(o, x0);
+		hall = bmin;
 		done = inside || !live;
 		hit = false;
 		idxHit = 0;
@@ -127,7 +131,9 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 				double xs[NX];
 #pragma unroll
 				for (int k = 0; k < NX; k++) xs[k] = z[k];
-				bmin = fmin(bmin, M::safetyMin(o, xs));
+				const double hm = M::safetyMin(o, xs);
+				bmin = fmin(bmin, hm);
+				if constexpr (trig_by_margin<M>::value) hall = fmin(hall, hm);
 				if (M::backupSetInside(o, xs)) {
 					hit = true;
 					done = true;
@@ -146,6 +152,7 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 		bool bad = false;
 #pragma unroll
 		for (int k = 0; k < NZ; k++) bad = bad || (z[k] != z[k]);
+		if constexpr (trig_by_margin<M>::value) bad = bad || !M::trigArgsBounded(hall);
 		redo = __any(bad); // never on sane trajectories
 	}
 	if (redo) pass1(std::false_type());

@@ -4,6 +4,7 @@
 // Df column-major nx x nx, Dg index i + k*nx + j*nx*nu, Du column-major nu x nx.
 // The numeric constants are the workload definition and are restated from the cited example files.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include "asif_hip.h"
 
@@ -102,6 +103,11 @@ __device__ __forceinline__ double fma_sc(double a, double b, double c)
 //                   both results, as libm does.
 constexpr int kTrigChecked = 0, kTrigPoison = 1, kTrigUnchecked = 2;
 constexpr double kTrigFastRange = 1e5;
+// models whose tracked safety margin bounds their trig arguments declare kTrigBoundedByMargin + trigArgsBounded(hmin)
+template <class M, class = void>
+struct trig_by_margin : std::false_type {};
+template <class M>
+struct trig_by_margin<M, std::enable_if_t<M::kTrigBoundedByMargin>> : std::true_type {};
 template <int POISON = kTrigChecked>
 __device__ __forceinline__ void sincos_fast(double x, double &s, double &c)
 {
@@ -381,6 +387,9 @@ struct InvertedPendulumTB {
 	{
 		return fmin(fmin(-x[0] + kPi, x[0] - (-kPi / 2.)), fmin(x[1] - (-kPi / 2.), -x[1] + kPi / 2.));
 	}
+	// -pi/2 - hmin <= x0 <= pi - hmin: see InvertedPendulum::trigArgsBounded
+	static constexpr bool kTrigBoundedByMargin = true;
+	__device__ static bool trigArgsBounded(double hmin) { return hmin >= -0.9 * kTrigFastRange; }
 	// :36-65
 	__device__ static void backupSet(const DevOptions &, const double (&x)[NX], double &h, double (&Dh)[NX],
 	                                 double (&DDh)[NX * NX])
@@ -442,6 +451,9 @@ struct Segway {
 		for (int i = 1; i < NX; i++) m = fmin(m, (xb(i) * xb(i)) - (x[i] * x[i]));
 		return m;
 	}
+	// pitch^2 <= xb(2)^2 - hmin: above this floor |2 pitch| stays below 9e4, inside the trig fast path's range
+	static constexpr bool kTrigBoundedByMargin = true;
+	__device__ static bool trigArgsBounded(double hmin) { return hmin >= -2.0e9; }
 	// :40-54  Pv^2 - sum (x_i/xBound_i)^2 with gradient and (diagonal) Hessian
 	__device__ static void backupSet(const DevOptions &, const double (&x)[NX], double &h, double (&Dh)[NX],
 	                                 double (&DDh)[NX * NX])
