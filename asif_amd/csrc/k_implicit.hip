@@ -172,6 +172,7 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 	// The fast path also takes the soft saturation's short forms (BackupLoop::saturateSoft<FAST>), valid for ordinary
 	// saturation constants (DevOptions::satFastOk, checked on the host); other options run the generic step.
 	const int nblk = (o.npBT + MB - 1) / MB;
+	bool anyRedo = false; // some block of this wave ran on the generic step (pass 2 then does too)
 #pragma unroll 1
 	for (int blk = 0; blk < nblk; blk++) {
 		const int s0 = blk * MB;
@@ -215,7 +216,10 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 				hold = hs;
 			}
 		}
-		if (redo) run(std::false_type());
+		if (redo) {
+			run(std::false_type());
+			anyRedo = true;
+		}
 		commit(blk);
 #pragma unroll
 		for (int c = 0; c < NZ; c++) zs[c] = z[c];
@@ -229,6 +233,7 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 	// samples arrive in increasing index (the selection's tie rule: earlier sample first), and run the exact
 	// per-sample selection with the states parked in LDS -- at most K*MB of the npBT steps.
 	int cur = -1;
+	const bool fast2 = o.satFastOk && !anyRedo; // wave-uniform
 #pragma unroll 1
 	for (int j = 0; j < K; j++) {
 		int nb = 0x7fffffff, sl = 0;
@@ -251,7 +256,13 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 #pragma unroll 1
 		for (int t = 0; t < MB; t++) {
 			const int s = blk * MB + t;
-			if (t > 0) BackupLoop<M>::template eulerStepT<RB>(o, z, hold, (double)(unsigned)s * o.trajDt);
+			if (t > 0) {
+				// the samples of a selected block went through pass 1's range check with these very states: the fast step
+				// is valid for them again (steps past the horizon or of a lane without a block feed nothing)
+				constexpr int P = trig_by_margin<M>::value ? kTrigUnchecked : kTrigPoison;
+				if (fast2) BackupLoop<M>::template eulerStepT<RB, P>(o, z, hold, (double)(unsigned)s * o.trajDt);
+				else BackupLoop<M>::template eulerStepT<RB>(o, z, hold, (double)(unsigned)s * o.trajDt);
+			}
 			double xs[NX];
 #pragma unroll
 			for (int k = 0; k < NX; k++) xs[k] = z[k];

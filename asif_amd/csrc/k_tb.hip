@@ -165,6 +165,7 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 	TopK<K> top;
 	top.init();
 	int cur = -1;
+	const bool fast2 = o.satFastOk && !redo; // wave-uniform
 #pragma unroll 1
 	for (int j = 0; j < K; j++) {
 		int nb = 0x7fffffff, sl = 0;
@@ -185,7 +186,13 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 #pragma unroll 1
 		for (int tt = 0; tt < MB; tt++) {
 			const int s = blk * MB + tt;
-			if (tt > 0) BackupLoop<M>::eulerStep(o, z);
+			if (tt > 0) {
+				// pass 1 has range-checked these very states (unless it had to be redone): the fast step is valid again
+				constexpr int P = trig_by_margin<M>::value ? kTrigUnchecked : kTrigPoison;
+				typename BackupLoop<M>::Hold none2 = {0.0, 0.0};
+				if (fast2) BackupLoop<M>::template eulerStepT<false, P>(o, z, none2, 0.0);
+				else BackupLoop<M>::eulerStep(o, z);
+			}
 			double xs[NX];
 #pragma unroll
 			for (int k = 0; k < NX; k++) xs[k] = z[k];
