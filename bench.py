@@ -213,7 +213,13 @@ def valu_roofline(sq, step_ms, tag):
         return None
     avail = N_SIMD * SHADER_CLOCK_HZ * step_ms * 1e-3
     used = sq["insts_valu_per_step"] * VALU_ISSUE_CYCLES
+    slots = None
+    if sq.get("insts_salu_per_step") is not None:
+        # a wave issues one instruction per turn whatever its type: with a single wave on a SIMD (this path's batch
+        # sizes) scalar instructions take issue turns away from vector ones instead of overlapping with them
+        slots = (sq["insts_valu_per_step"] + sq["insts_salu_per_step"]) * VALU_ISSUE_CYCLES / avail
     return {"bound": "valu-issue", "insts_valu_per_step": sq["insts_valu_per_step"],
+            "insts_salu_per_step": sq.get("insts_salu_per_step"), "frac_valu_plus_salu": slots,
             "waves_per_step": sq.get("waves_per_step"), "insts_valu_per_wave": sq.get("insts_valu_per_wave"),
             "issue_cycles_per_inst": VALU_ISSUE_CYCLES, "simd_cycles_available": avail, "frac": used / avail,
             "counters_source": f"profiles/{PROFILE_ROUND}/{tag}_sq_summary.json (rocprofv3 --pmc, separate pass of the "

@@ -53,7 +53,7 @@ def sq_summary(tag, out, calls_per_kernel):
     if not kernels:
         return
     steps = max(calls_per_kernel.values()) if calls_per_kernel else 1
-    valu = waves = 0.0
+    valu = waves = salu = 0.0
     for k, c in kernels.items():
         per_step = 1.0
         for name, calls in calls_per_kernel.items():
@@ -62,10 +62,11 @@ def sq_summary(tag, out, calls_per_kernel):
         c["launches_per_step"] = per_step
         valu += c.get("SQ_INSTS_VALU", 0.0) * per_step
         waves += c.get("SQ_WAVES", 0.0) * per_step
+        salu += c.get("SQ_INSTS_SALU", 0.0) * per_step
     with open(os.path.join(out, f"{tag}_sq_summary.json"), "w") as f:
         json.dump({"command": "tools/prof_cfg.sh (rocprofv3 --pmc SQ_*, two passes of <= 6 counters, no trace domain)",
                    "unit": "wave-level instruction counts / SQ cycles summed over the chip, mean per launch",
-                   "kernels": kernels, "insts_valu_per_step": valu, "waves_per_step": waves,
+                   "kernels": kernels, "insts_valu_per_step": valu, "insts_salu_per_step": salu, "waves_per_step": waves,
                    "insts_valu_per_wave": valu / waves if waves else None}, f, indent=1)
     print(tag, "SQ_INSTS_VALU per step", round(valu), "waves", round(waves), "per wave", round(valu / waves) if waves else None)
 
