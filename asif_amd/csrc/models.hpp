@@ -126,11 +126,19 @@ __device__ __forceinline__ void sincos_fast(double x, double &s, double &c)
 	                                                    -2.75573143513906633035e-07), 2.48015872894767294178e-05),
 	                                -1.38888888888741095749e-03), 4.16666666666666019037e-02);
 	const double cr = 1.0 - (0.5 * z - z * (z * pc));
-	const int q = (int)n & 3;
-	s = (q & 1) ? cr : sr;
-	c = (q & 1) ? sr : cr;
-	if (q & 2) s = -s;
-	if ((q + 1) & 2) c = -c;
+	// quadrant q = n mod 4: odd q swaps the two, bit 1 of q negates the sine, bit 1 of q + 1 the cosine -- the signs
+	// as XORs of bit 31 (shift the quadrant bit there) instead of compare + negate + select
+	const int qi = (int)n;
+	const bool odd = (qi & 1) != 0;
+	const double ss = odd ? cr : sr, cc = odd ? sr : cr;
+#if defined(__HIP_DEVICE_COMPILE__)
+	const unsigned t = (unsigned)qi << 30;
+	s = __hiloint2double(__double2hiint(ss) ^ (int)(t & 0x80000000u), __double2loint(ss));
+	c = __hiloint2double(__double2hiint(cc) ^ (int)((t + 0x40000000u) & 0x80000000u), __double2loint(cc));
+#else
+	s = (qi & 2) ? -ss : ss;
+	c = ((qi + 1) & 2) ? -cc : cc;
+#endif
 	if constexpr (POISON == kTrigUnchecked) return;
 	if constexpr (POISON == kTrigPoison) {
 		const bool big = !(fabs(x) <= kTrigFastRange);

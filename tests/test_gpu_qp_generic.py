@@ -117,3 +117,38 @@ def test_unsupported_shape_is_an_error(hip):
     with pytest.raises(hip.AsifHipError):
         hip.qp_solve_batch(z(nv) + 1, z(nv), z(nc * nv), z(nc), z(nv) - 1, z(nv) + 1, z(nv),
                            torch.zeros(B, dtype=torch.int32, device=dev))
+
+
+@pytest.mark.parametrize("nv,nc,pins,eqrow,bmean", [(2, 4, (1,), False, -1.0), (2, 4, (0,), False, -1.0),
+                                                     (3, 41, (1, 2), False, -2.5), (3, 41, (2,), False, -2.0),
+                                                     (2, 18, (1,), True, -3.0), (3, 41, (0, 1), True, -4.0)])
+def test_pinned_variables_are_eliminated(hip, oracle, nv, nc, pins, eqrow, bmean):
+    """Variables pinned by their bounds in every QP of the batch: the dual active-set stage eliminates them (wave-
+    uniformly) and, when one variable is left, solves the problem as its one-variable fixed point (gi_small.hpp).
+    Random problems, some infeasible, rows with a zero coefficient on the free variable, optionally an equality row;
+    verdict and optimum against the exact enumeration."""
+    rng = np.random.default_rng(100 * nv + nc + 7 * len(pins) + (1 if eqrow else 0))
+    B = 4096
+    Hd = np.exp(rng.uniform(np.log(0.5), np.log(50), (B, nv)))
+    c = rng.normal(0, 3, (B, nv))
+    A = rng.normal(0, 1, (B, nv, nc))
+    A[rng.random((B, nv, nc)) < 0.1] = 0.0
+    b = rng.normal(bmean, 1, (B, nc))  # bmean tuned per shape for a mix of feasible and infeasible problems
+    lb = -rng.uniform(0.5, 3, (B, nv))
+    ub = rng.uniform(0.5, 3, (B, nv))
+    for j in pins:
+        lb[:, j] = ub[:, j] = rng.uniform(-1, 1, B)
+    be = np.zeros(nc, dtype=np.uint8)
+    if eqrow:
+        be[1] = 1
+        free = [j for j in range(nv) if j not in pins]
+        A[:, free[0], 1] = rng.choice([-1.0, 1.0], B) * rng.uniform(0.5, 2, B)  # keep the equality row solvable
+    Af = np.ascontiguousarray(A.reshape(B, nv * nc))
+    ex, stex, _ = oracle.qp_solve_batch(nv, nc, Hd, c, Af, b, lb, ub, be, oracle.SOLVER_EXACT)
+    sol, st, it = _solve(hip, Hd, c, Af, b, lb, ub, be)
+    assert 0.02 < (stex == 1).mean() < 0.98, "the family should mix feasible and infeasible problems"
+    assert np.array_equal(st == 1, stex == 1), f"{((st == 1) != (stex == 1)).sum()} verdicts differ"
+    ok = st == 1
+    assert np.abs(sol[ok] - ex[ok]).max() <= 1e-6
+    for j in pins:
+        assert np.array_equal(sol[ok][:, j], lb[ok][:, j])
