@@ -93,7 +93,14 @@ struct LdsQp {
 	double l[RPT], u[RPT], E[RPT], y[RPT], mu[RPT];
 	double cs;
 
-	__device__ __forceinline__ void sync() { __syncthreads(); }
+	// The workgroup IS one wavefront, and a wavefront's LDS instructions execute in issue order: a write by one lane
+	// is visible to a later read by another without a hardware barrier.  What is needed is that the compiler keeps
+	// that order -- a wavefront-scope fence -- not s_barrier with its full drain of the LDS queue at every phase.
+	__device__ __forceinline__ void sync()
+	{
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
 	__device__ __forceinline__ int vj(int v) const { return lane + 64 * v; }
 	__device__ __forceinline__ static int pidx(int a, int b) { return a <= b ? b * (b + 1) / 2 + a : a * (a + 1) / 2 + b; }
 
@@ -253,7 +260,7 @@ struct LdsQp {
 
 	// S <- P + I/gamma + sum_{i active} mu_i a_i a_i' + diag(active bounds), then LDL' in place.
 	// actr / actb: this lane's rows / bounds currently outside their interval.
-	__device__ __forceinline__ bool build_and_factor(const bool (&actr)[RPT], const bool (&actb)[VPT])
+	__device__ __forceinline__ void build(const bool (&actr)[RPT], const bool (&actb)[VPT])
 	{
 		// compact list of the active general rows + their weights
 		int base = 0;
@@ -275,7 +282,18 @@ struct LdsQp {
 		for (int k = 0; k < VPT; k++) {
 			const int j = vj(k);
 			if (isv[k]) {
-				for (int c0 = 0; c0 <= j; c0 += 8) {
+				auto finish = [&](int c, double sv) { // entry (c, j) of K_J, c <= j
+					if constexpr (FULLH) sv += Pp[pidx(c, j)];
+					if (c == j) {
+						if constexpr (!FULLH) sv += Pd[k];
+						sv += 1.0 / kLdsGamma + (actb[k] ? mub[k] * ab[k] * ab[k] : 0.0);
+					}
+					S[c * NVP + j] = sv;
+				};
+				// uniform control flow (every lane walks all rows c < nv; the store is what c <= j masks): full blocks of
+				// eight rows without index clamps, then the last nv mod 8 rows one at a time
+				int c0 = 0;
+				for (; c0 + 8 <= nv; c0 += 8) {
 					double acc[8];
 #pragma unroll
 					for (int u = 0; u < 8; u++) acc[u] = 0.0;
@@ -283,33 +301,37 @@ struct LdsQp {
 						const int i = alist[t];
 						const double w = vr[i] * At[j * RS + i];
 #pragma unroll
-						for (int u = 0; u < 8; u++) {
-							const int c = c0 + u < nv ? c0 + u : nv - 1;
-							acc[u] += w * At[c * RS + i];
-						}
+						for (int u = 0; u < 8; u++) acc[u] += w * At[(c0 + u) * RS + i];
 					}
 #pragma unroll
-					for (int u = 0; u < 8; u++) {
-						const int c = c0 + u;
-						if (c <= j) {
-							double sv = acc[u];
-							if constexpr (FULLH) sv += Pp[pidx(c, j)];
-							if (c == j) {
-								if constexpr (!FULLH) sv += Pd[k];
-								sv += 1.0 / kLdsGamma + (actb[k] ? mub[k] * ab[k] * ab[k] : 0.0);
-							}
-							S[c * NVP + j] = sv;
-						}
+					for (int u = 0; u < 8; u++)
+						if (c0 + u <= j) finish(c0 + u, acc[u]);
+				}
+				for (; c0 < nv; c0++) {
+					double acc = 0.0;
+#pragma unroll 4
+					for (int t = 0; t < nact; t++) {
+						const int i = alist[t];
+						acc += vr[i] * At[j * RS + i] * At[c0 * RS + i];
 					}
+					if (c0 <= j) finish(c0, acc);
 				}
 			}
 		}
 		sync();
+	}
+	// LDL' of S in place (right-looking); false if a pivot is not positive
+	__device__ __forceinline__ bool factor()
+	{
 		bool ok = true;
 		for (int k = 0; k < nv; k++) {
 			const double dk = S[k * NVP + k];
 			ok = ok && (dk > 0.0);
-			const double inv = 1.0 / dk;
+			// reciprocal of the pivot by the hardware seed and two Newton steps (full precision for a positive, normal
+			// pivot; the IEEE division's rescaling and fix-up steps are for operands a factorisation does not survive)
+			double inv = __builtin_amdgcn_rcp(dk);
+			inv = fma(fma(-dk, inv, 1.0), inv, inv);
+			inv = fma(fma(-dk, inv, 1.0), inv, inv);
 			double ljk[VPT];
 #pragma unroll
 			for (int v = 0; v < VPT; v++) {
@@ -322,18 +344,18 @@ struct LdsQp {
 			for (int v = 0; v < VPT; v++) {
 				const int j = vj(v);
 				if (isv[v] && j > k) {
-					for (int c0 = k + 1; c0 < nv; c0 += 8) { // all sixteen reads before the first write
+					int c0 = k + 1;
+					for (; c0 + 8 <= nv; c0 += 8) { // full blocks: all sixteen reads before the first write
 						double sc[8], sv[8];
 #pragma unroll
 						for (int u = 0; u < 8; u++) {
-							const int c = c0 + u < nv ? c0 + u : nv - 1;
-							sc[u] = S[k * NVP + c];
-							sv[u] = S[c * NVP + j];
+							sc[u] = S[k * NVP + c0 + u];
+							sv[u] = S[(c0 + u) * NVP + j];
 						}
 #pragma unroll
-						for (int u = 0; u < 8; u++)
-							if (c0 + u < nv) S[(c0 + u) * NVP + j] = sv[u] - ljk[v] * sc[u];
+						for (int u = 0; u < 8; u++) S[(c0 + u) * NVP + j] = sv[u] - ljk[v] * sc[u];
 					}
+					for (; c0 < nv; c0++) S[c0 * NVP + j] -= ljk[v] * S[k * NVP + c0];
 				}
 			}
 			sync();
@@ -498,7 +520,7 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 	double pri_prev = -1.0, best_res = 1e300;
 	// section timers of a scratch build (tools/dev_lds_sections.py); compiled out of the library
 #ifdef ASIF_LDS_PROFILE
-	long long tsec[6] = {0, 0, 0, 0, 0, 0}, tmark = __builtin_readcyclecounter();
+	long long tsec[7] = {0, 0, 0, 0, 0, 0, 0}, tmark = __builtin_readcyclecounter();
 #define LDS_T(k) { const long long tn_ = __builtin_readcyclecounter(); tsec[k] += tn_ - tmark; tmark = tn_; }
 #else
 #define LDS_T(k)
@@ -575,7 +597,9 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 			if (newton >= max_newton) break;
 			// ---- Newton direction on the current active set
 			if (__any(changed)) {
-				fact_ok = s.build_and_factor(actr, actb) && fact_ok;
+				s.build(actr, actb);
+				LDS_T(6)
+				fact_ok = s.factor() && fact_ok;
 				have_factor = true;
 #pragma unroll
 				for (int r = 0; r < RPT; r++) pactr[r] = actr[r];
@@ -797,7 +821,7 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 	}
 #ifdef ASIF_LDS_PROFILE
 	if (lane == 0)
-		for (int k = 0; k < 6; k++) a.sol[(int64_t)k * ld + qi] = (double)tsec[k]; // scratch build: times instead of x
+		for (int k = 0; k < 7; k++) a.sol[(int64_t)k * ld + qi] = (double)tsec[k]; // scratch build: times instead of x
 #endif
 #undef LDS_T
 }

@@ -1,6 +1,6 @@
 """Scratch: per-section cycle counts of the LDS kernel (variant library built with -DASIF_LDS_PROFILE, which writes
-its section timers where the solution goes).  Sections: 0 gradient, 1 build+factor, 2 solve, 3 line search, 4 outer
-update, 5 rest.  Not product code, not a test."""
+its section timers where the solution goes).  Sections: 0 gradient, 1 factor, 2 solve, 3 line search, 4 outer
+update, 5 rest, 6 build.  Not product code, not a test."""
 import os
 import sys
 
@@ -22,10 +22,10 @@ it = torch.zeros(B, dtype=torch.int32, device=dev)
 for _ in range(2):
     capi.qp_solve_batch(P["Hd"], P["c"], P["A"], P["b"], P["lb"], P["ub"], sol, st, it, be=P["be"])
 torch.cuda.synchronize()
-t = sol[:6].cpu().numpy()
+t = sol[:7].cpu().numpy()
 n = it.cpu().numpy()
-names = ["gradient", "build+factor", "solve", "line search", "outer update", "rest"]
+names = ["gradient", "factor", "solve", "line search", "outer update", "rest", "build"]
 tot = t.sum(0)
 print("newton mean", n.mean(), "cycles/QP mean", tot.mean())
-for k in range(6):
+for k in range(7):
     print(f"{names[k]:14s} {t[k].mean():12.0f} cycles  {100 * t[k].sum() / tot.sum():5.1f} %   per newton {t[k].sum() / n.sum():9.0f}")
