@@ -6,6 +6,7 @@
 // solved by the in-register ADMM, then inputSaturate (:343-352) and the return code (:199-209).
 // HBM traffic is the algorithmic minimum: 8(nx+nu) bytes in, 8(nu+1)+4 bytes out per instance, SoA,
 // consecutive lanes -> consecutive instances (G = 1) so every load/store is a fully coalesced line.
+#include <type_traits>
 #include "admm_small.hpp"
 #include "launchers.hpp"
 
@@ -177,8 +178,10 @@ __global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_f
 // filter saw.  When the filter fails uAct keeps its previous value -- the example never resets it (:89-94).
 // The state stays in registers for the whole rollout; HBM traffic is 8(nx+2nu+1)+4 bytes in and out per
 // instance per LAUNCH (plus the optional logs), not per step.
-template <class M>
-__global__ __launch_bounds__(64) void explicit_rollout_kernel(DevOptions o, asif_hip_solver S, RolloutArgs a)
+// LIGHT: as explicit_filter_kernel's PRE -- one input, the dual active-set stage decides every step's QP on its own
+// (relaxation variable eliminated, one variable left); no ADMM / finish code in the instantiation.
+template <class M, bool LIGHT = false>
+__global__ __launch_bounds__(LIGHT ? 256 : 64) void explicit_rollout_kernel(DevOptions o, asif_hip_solver S, RolloutArgs a)
 {
 	constexpr int NX = M::NX, NU = M::NU, NP = M::NPSS, NV = NU + 1, NC = NP;
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -195,7 +198,8 @@ __global__ __launch_bounds__(64) void explicit_rollout_kernel(DevOptions o, asif
 	}
 	relax = a.relax[i];
 	int nfail = 0;
-	AdmmSmall<NV, NC, 1> admm; // one object for the rollout: it carries the working set from step to step
+	// one object for the rollout: it carries the working set from step to step (the light instantiation has none)
+	std::conditional_t<LIGHT, int, AdmmSmall<NV, NC, 1>> admm{};
 #pragma unroll 1
 	for (int t = 0; t < a.T; t++) { // wave-uniform trip count
 		double h[NP], Dh[NP * NX], f[NX], gm[NX * NU];
@@ -231,7 +235,13 @@ __global__ __launch_bounds__(64) void explicit_rollout_kernel(DevOptions o, asif
 		qp.ub[NU] = o.relaxLb;
 		double sol[NV];
 		int status, iters;
-		admm.solve(qp, S, sol, status, iters, S.warm_start != 0 && t > 0, S.polish == 2);
+		if constexpr (LIGHT) {
+			static_assert(NU == 1, "one input: the pinned relaxation variable leaves a one-variable problem");
+			const int verdict = GiSmall<NV, NC, 1>::template solve_with_pinned<NU>(qp, 0, 8 * NV + 4, sol, iters);
+			status = verdict == kGiOptimal ? kStatusSolved : kStatusPrimalInf;
+		} else {
+			admm.solve(qp, S, sol, status, iters, S.warm_start != 0 && t > 0, S.polish == 2);
+		}
 		if (live && a.xlog) {
 #pragma unroll
 			for (int k = 0; k < NX; k++) a.xlog[((int64_t)t * NX + k) * ld + i] = x[k];
@@ -272,8 +282,12 @@ int launch_rollout_explicit_di(const DevOptions &o, const asif_hip_solver &S0, c
 {
 	if (a.B <= 0 || a.T <= 0) return 0;
 	const asif_hip_solver S = resolve_scaling(S0, 1, 1);
-	hipLaunchKernelGGL((explicit_rollout_kernel<DoubleIntegrator>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, S,
-	                   a);
+	if (S.polish == 2 || S.presolve) // the dual active-set stage alone decides this class's one-input problems
+		hipLaunchKernelGGL((explicit_rollout_kernel<DoubleIntegrator, true>), dim3(grid_for(a.B, 1, 256)), dim3(256), 0,
+		                   stream, o, S, a);
+	else
+		hipLaunchKernelGGL((explicit_rollout_kernel<DoubleIntegrator, false>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0,
+		                   stream, o, S, a);
 	return (int)hipGetLastError();
 }
 
