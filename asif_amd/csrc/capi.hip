@@ -374,13 +374,19 @@ extern "C" int asif_hip_set_learning(asif_hip_ctx *ctx, const asif_hip_learning_
 	if (!ctx || (ctx->variant != ASIF_HIP_IMPLICIT_RB && ctx->variant != ASIF_HIP_IMPLICIT)) return ASIF_HIP_EINVAL;
 	hipError_t e = hipSetDevice(ctx->device);
 	if (e != hipSuccess) return (int)e;
-	if (ctx->d_learn) {
-		(void)hipDeviceSynchronize(); // a launch in flight may still read the old weights
-		(void)hipFree(ctx->d_learn);
-		ctx->d_learn = nullptr;
+	// validate and upload the new weights first; the handle keeps its old ones if the call is rejected
+	auto drop_old = [&]() {
+		if (ctx->d_learn) {
+			(void)hipDeviceSynchronize(); // a launch in flight may still read the old weights
+			(void)hipFree(ctx->d_learn);
+			ctx->d_learn = nullptr;
+		}
+		std::memset(&ctx->learn, 0, sizeof(ctx->learn));
+	};
+	if (!L) {
+		drop_old();
+		return ASIF_HIP_OK;
 	}
-	std::memset(&ctx->learn, 0, sizeof(ctx->learn));
-	if (!L) return ASIF_HIP_OK;
 	const int nx = ctx->dims.nx, nu = ctx->dims.nu;
 	const uint32_t din[2] = {L->d_drift_in, L->d_act_in}, h1[2] = {L->d_drift_hidden, L->d_act_hidden},
 	               h2[2] = {L->d_drift_hidden_2, L->d_act_hidden_2}, dout[2] = {L->d_drift_out, L->d_act_out};
@@ -413,12 +419,14 @@ extern "C" int asif_hip_set_learning(asif_hip_ctx *ctx, const asif_hip_learning_
 		o3[n] = put(w3[n], (size_t)dout[n] * h2[n]);
 		ob3[n] = put(b3[n], dout[n]);
 	}
-	if ((e = hipMalloc((void **)&ctx->d_learn, total * sizeof(double))) != hipSuccess) return (int)e;
-	if ((e = hipMemcpy(ctx->d_learn, host.data(), total * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) {
-		(void)hipFree(ctx->d_learn);
-		ctx->d_learn = nullptr;
+	double *fresh = nullptr;
+	if ((e = hipMalloc((void **)&fresh, total * sizeof(double))) != hipSuccess) return (int)e;
+	if ((e = hipMemcpy(fresh, host.data(), total * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) {
+		(void)hipFree(fresh);
 		return (int)e;
 	}
+	drop_old();
+	ctx->d_learn = fresh;
 	for (int n = 0; n < 2; n++) {
 		ctx->learn.dHidden[n] = (int)h1[n];
 		ctx->learn.dHidden2[n] = (int)h2[n];

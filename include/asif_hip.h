@@ -202,7 +202,10 @@ int asif_hip_default_options(int model, int variant, asif_hip_options *o);
 int asif_hip_default_solver(asif_hip_solver *s);
 
 /* One handle = one (model, variant, options) triple on one device: the analogue of constructing an
- * ASIF* object and calling initialize(lb,ub,opts).  solver may be NULL (defaults). */
+ * ASIF* object and calling initialize(lb,ub,opts).  solver may be NULL (defaults).
+ * A handle owns staging buffers (assembled rows, trajectory checkpoints) that its launches write: calls on ONE handle
+ * must be ordered -- one stream per handle, or the caller's own events between streams.  Handles are independent of
+ * one another (asif_hip_create_multi makes one per device and drives each on its own stream). */
 int asif_hip_create(asif_hip_ctx **out, int model, int variant, const asif_hip_options *opts,
                     const asif_hip_solver *solver, int device);
 int asif_hip_destroy(asif_hip_ctx *ctx);

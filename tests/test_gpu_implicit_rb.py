@@ -4,6 +4,7 @@ residual on the first row, the n_debug sample selection, and the reduction to AS
 Same bar as C3: rows at rtol 1e-9, u* <= 1e-6 against the exact optimum, rc identical."""
 import numpy as np
 import pytest
+import torch
 
 import gpu_util
 from asif_amd import workloads
@@ -148,6 +149,27 @@ def test_learning_without_weights_fails_loudly(hip, oracle):
     w["d_drift_in"] = 3
     with pytest.raises(Exception):
         flt.set_learning(w)
+    flt.close()
+
+
+def test_rejected_weights_leave_the_handle_as_it_was(hip, oracle):
+    """asif_hip_set_learning validates and uploads before it swaps: a refused call keeps the previous networks."""
+    od, _, _ = _both_options(hip, oracle, 1, oracle.MODEL_IP)
+    good = workloads.make_learning()
+    before = gpu_util.run_assemble(CFG, 256, options=od, learning=good)
+    flt = hip.Filter(1, RB, options=od)
+    flt.set_learning(good)
+    with pytest.raises(Exception):
+        flt.set_learning(workloads.make_learning(hidden=(48, 16)))
+    d = flt.dims
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(before["x"]).to(dev)
+    A = torch.zeros(d.nc * d.nv, 256, dtype=torch.float64, device=dev)
+    b = torch.zeros(d.nc, 256, dtype=torch.float64, device=dev)
+    code = torch.zeros(256, dtype=torch.int32, device=dev)
+    flt.assemble(x, A, b, code)
+    torch.cuda.synchronize()
+    assert np.array_equal(A.cpu().numpy(), before["A"]) and np.array_equal(b.cpu().numpy(), before["b"])
     flt.close()
 
 
