@@ -13,9 +13,26 @@
 
 namespace asif {
 
+template <class M, class = void>
+struct unit_row_mask : std::integral_constant<unsigned, 0u> {};
+template <class M>
+struct unit_row_mask<M, std::void_t<decltype(M::kDfUnitRowMask)>> : std::integral_constant<unsigned, M::kDfUnitRowMask> {};
+template <class M, class = void>
+struct dg_mask : std::integral_constant<unsigned, 0xffffffffu> {};
+template <class M>
+struct dg_mask<M, std::void_t<decltype(M::kDgMask)>> : std::integral_constant<unsigned, M::kDgMask> {};
+
 template <class M>
 struct BackupLoop {
 	static constexpr int NX = M::NX, NZ = NX + NX * NX;
+	// Structure the models declare (models.hpp) so that the loop can drop products with literal zeros and ones -- the
+	// compiler may not (0 * x is not 0 for every x); for finite operands the values are the same:
+	//   row i of Df is the unit row e_{i+1}' with g_i = 0 and row i of Dg zero  ->  row i of DfCL Q is row i+1 of Q
+	//   and fCL_i = f_i (kDfUnitRowMask; kDfFirstRowShift is the two-state models' older name for row 0);
+	//   entries of Dg that can be non-zero (kDgMask; default: all).
+	static constexpr unsigned unitRowMask() { return unit_row_mask<M>::value | ((M::kDfFirstRowShift && NX == 2) ? 1u : 0u); }
+	static constexpr bool unitRow(int i) { return ((unitRowMask() >> i) & 1u) != 0; }
+	static constexpr bool dgEntry(int e) { return ((dg_mask<M>::value >> e) & 1u) != 0; }
 	static_assert(M::NU == 1, "backup loop is written for single-input models (every shipped example)");
 
 	// sqrt and divide as the compiler expands them (v_rsq / v_rcp, Newton steps in FMA, v_div_fixup), minus the
@@ -155,9 +172,17 @@ struct BackupLoop {
 		} else {
 #pragma unroll
 			for (int i = 0; i < NX; i++) {
+				if (unitRow(i)) { // row i of DfCL is not formed: the products below copy row i+1 of Q instead
 #pragma unroll
-				for (int j = 0; j < NX; j++)
-					DfCL[i + j * NX] = Df[i + j * NX] + (Dg[i + j * NX] * uSat + g[i] * DuSat * Du[j]);
+					for (int j = 0; j < NX; j++) DfCL[i + j * NX] = Df[i + j * NX];
+					fCL[i] = f[i];
+					continue;
+				}
+#pragma unroll
+				for (int j = 0; j < NX; j++) {
+					const double gd = g[i] * DuSat * Du[j];
+					DfCL[i + j * NX] = Df[i + j * NX] + (dgEntry(i + j * NX) ? Dg[i + j * NX] * uSat + gd : gd);
+				}
 				fCL[i] = g[i] * uSat + f[i];
 			}
 		}
@@ -183,8 +208,8 @@ struct BackupLoop {
 		for (int i = 0; i < NX; i++)
 #pragma unroll
 			for (int j = 0; j < NX; j++) {
-				if (M::kDfFirstRowShift && NX == 2 && i == 0) { // 0 * Q(0,j) + 1 * Q(1,j): the same value without the FMAs
-					zd[NX + i + j * NX] = z[NX + 1 + j * NX];
+				if (unitRow(i)) { // 0 * Q(0,j) + ... + 1 * Q(i+1,j) + ...: the same value without the FMAs
+					zd[NX + i + j * NX] = z[NX + i + 1 + j * NX];
 					continue;
 				}
 				double s = 0.0;
@@ -216,8 +241,8 @@ struct BackupLoop {
 		for (int i = 0; i < NX; i++)
 #pragma unroll
 			for (int j = 0; j < NX; j++) {
-				if (M::kDfFirstRowShift && NX == 2 && i == 0) { // 0 * Q(0,j) + 1 * Q(1,j): the same value without the FMAs
-					zd[NX + i + j * NX] = z[NX + 1 + j * NX];
+				if (unitRow(i)) { // 0 * Q(0,j) + ... + 1 * Q(i+1,j) + ...: the same value without the FMAs
+					zd[NX + i + j * NX] = z[NX + i + 1 + j * NX];
 					continue;
 				}
 				double s = 0.0;

@@ -440,6 +440,10 @@ struct Segway {
 	static constexpr bool kDfFirstRowShift = false;
 
 	__device__ static double xb(int i) { return i < 2 ? 3.0 : (i == 2 ? kPi / 6 : kPi); }
+	// f0 = x1 and f2 = x3 with g0 = g2 = 0: rows 0 and 2 of Df are unit rows, of Dg zero (BackupLoop: rows 0 and 2 of
+	// DfCL Q are rows 1 and 3 of Q); Dg is non-zero at (1,2) and (3,2) only (column-major entries 9 and 11)
+	static constexpr unsigned kDfUnitRowMask = 0x5u;
+	static constexpr unsigned kDgMask = (1u << 9) | (1u << 11);
 
 	// :27-38  h_i = xBound_i^2 - x_i^2
 	__device__ static void safetySet(const DevOptions &, const double (&x)[NX], double (&h)[NPSS], double (&Dh)[NPSS * NX])

@@ -52,6 +52,11 @@ def child(cfg, lib, steps, batch):
     h = hashlib.sha256()
     for t in (A, b, code, uact, relax, rc):
         h.update(t.cpu().numpy().tobytes())
+    if os.environ.get("DEV_VARIANTS_DUMP"):  # numeric comparison of two builds (bits may differ in the sign of a zero)
+        os.makedirs(os.environ["DEV_VARIANTS_DUMP"], exist_ok=True)
+        np.savez(os.path.join(os.environ["DEV_VARIANTS_DUMP"], f"c{cfg}_" + os.path.basename(lib) + ".npz"),
+                 A=A.cpu().numpy(), b=b.cpu().numpy(), code=code.cpu().numpy(), uact=uact.cpu().numpy(),
+                 relax=relax.cpu().numpy(), rc=rc.cpu().numpy())
     vals, cnt = np.unique(rc.cpu().numpy(), return_counts=True)
     print(json.dumps({"lib": lib, "config": cfg, "batch": B, "ms_per_step": e0.elapsed_time(e1) / steps,
                       "sha256": h.hexdigest()[:16], "rc": {int(v): int(c) for v, c in zip(vals, cnt)}}), flush=True)
