@@ -272,6 +272,47 @@ struct InvertedPendulum {
 	}
 };
 
+// tanh for the segway's friction term tanh(1000 v): (1 - E) / (1 + E) with E = exp(-2|y|) -- |y| clipped at 25, where
+// E is far below half an ulp of 1 -- E by ln2 reduction and a degree-12 Taylor polynomial on |r| <= ln2 / 2 (truncation
+// 1.7e-16 relative), the quotient by reciprocal seed, two Newton steps and one residual correction.  Absolute error
+// below 4e-16 over the whole line, which is what matters here: the model uses th and th^2 additively (a relative
+// error bound near y = 0 would cost the expm1 form).  ocml's tanh is ~160 vector instructions of double-double
+// arithmetic, a fifth of the segway's Euler step; this is ~35.  NaN stays NaN.
+__device__ __forceinline__ double tanh_abs_accurate(double y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	const double a = fabs(y);
+	const double x = -2.0 * (a < 25.0 ? a : 25.0);
+	const double n = rint(x * 1.44269504088896338700e+00);
+	double r = fma(-n, 6.93147180369123816490e-01, x);
+	r = fma(-n, 1.90821492927058770002e-10, r);
+	double p = 2.08767569878680989792e-09; // 1/12!
+	p = fma(p, r, 2.50521083854417187751e-08);
+	p = fma(p, r, 2.75573192239858906526e-07);
+	p = fma(p, r, 2.75573192239858906526e-06);
+	p = fma(p, r, 2.48015873015873015873e-05);
+	p = fma(p, r, 1.98412698412698412698e-04);
+	p = fma(p, r, 1.38888888888888888889e-03);
+	p = fma(p, r, 8.33333333333333333333e-03);
+	p = fma(p, r, 4.16666666666666666667e-02);
+	p = fma(p, r, 1.66666666666666666667e-01);
+	p = fma(p, r, 0.5);
+	p = fma(p, r, 1.0);
+	p = fma(p, r, 1.0);
+	const double E = ldexp(p, (int)n);
+	const double num = 1.0 - E, den = 1.0 + E;
+	double rc = __builtin_amdgcn_rcp(den);
+	rc = fma(fma(-den, rc, 1.0), rc, rc);
+	rc = fma(fma(-den, rc, 1.0), rc, rc);
+	double q = num * rc;
+	q = fma(fma(-den, q, num), rc, q);
+	q = copysign(q, y);
+	return (y != y) ? y : q;
+#else
+	return tanh(y);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // Synthetic two-input model for class ASIF.  NOT one of the reference's examples (none of them has nu > 1); it
 // exists so that the nu > 1 code of src/asif.cpp (:279-303 Lgh = Dh g with nu columns, :314-352 cost and clamp per
@@ -570,7 +611,7 @@ struct Segway {
 		dynamicsT(x, t, f, g);
 		const double c1 = t.c1, s1 = t.s1, c2 = t.c2, s2 = t.s2;
 		const double w2 = x[3] * x[3];
-		const double th = tanh(x[1] * 1000.0);
+		const double th = tanh_abs_accurate(x[1] * 1000.0);
 		const double th2 = th * th;
 		const double t25 = th * 15.13175750513302 - 40.918271887954823;
 		const double t26 = w2 * 3.3849959169972448 + th * 30.26351501026604;
