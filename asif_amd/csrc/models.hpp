@@ -272,6 +272,20 @@ struct InvertedPendulum {
 	}
 };
 
+// 1 / d by the hardware seed and two Newton steps: within an ulp of the IEEE quotient for a normal d (no rescaling, no
+// fix-up: a third of the division's instructions).  For the segway's four reciprocals of O(1-10) denominators.
+__device__ __forceinline__ double rcp_newton(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	double r = __builtin_amdgcn_rcp(d);
+	r = fma(fma(-d, r, 1.0), r, r);
+	r = fma(fma(-d, r, 1.0), r, r);
+	return r;
+#else
+	return 1.0 / d;
+#endif
+}
+
 // tanh for the segway's friction term tanh(1000 v): (1 - E) / (1 + E) with E = exp(-2|y|) -- |y| clipped at 25, where
 // E is far below half an ulp of 1 -- E by ln2 reduction and a degree-12 Taylor polynomial on |r| <= ln2 / 2 (truncation
 // 1.7e-16 relative), the quotient by reciprocal seed, two Newton steps and one residual correction.  Absolute error
@@ -571,14 +585,21 @@ struct Segway {
 	{
 		Trig t;
 		sincos_fast<POISON>(pitch, t.s1, t.c1);
+#if defined(__HIP_DEVICE_COMPILE__)
+		// sin 2p = 2 sin p cos p, cos 2p = (cos p - sin p)(cos p + sin p): within 3e-16 (absolute) of the separate
+		// sin / cos of 2p the example calls, for four multiplies instead of a second 35-instruction evaluation
+		t.s2 = 2.0 * t.s1 * t.c1;
+		t.c2 = (t.c1 - t.s1) * (t.c1 + t.s1);
+#else
 		sincos_fast<POISON>(2.0 * pitch, t.s2, t.c2);
+#endif
 		return t;
 	}
 	// :70-111
 	__device__ static void dynamicsT(const double (&X)[NX], const Trig &t, double (&f)[NX], double (&g)[NX * NU])
 	{
 		const double w2 = X[3] * X[3];
-		const double iden = 1.0 / ((14.553176960783997 + -2.0831375273848773 * t.c2) + -0.59146430898882 * t.s2);
+		const double iden = rcp_newton((14.553176960783997 + -2.0831375273848773 * t.c2) + -0.59146430898882 * t.s2);
 		f[0] = X[1];
 		f[1] = 0.0975 * ((((((44.798 * (((-0.2693850964936445 * w2) + -0.0022454764220255392 * w2) +
 		                                 -0.11586336477125109 * w2) * 0.195 * t.c1 +
@@ -593,7 +614,7 @@ struct Segway {
 		const double gc = 1.4575004011882324 * t.c1;
 		const double gs = 0.20290365220710288 * t.s1;
 		g[1] = 0.551244194154502 * ((4.1706936767483551 + gc) + gs) *
-		       (1.0 / (((8.3593271361634187 + -2.1243074194638587 * (t.c1 * t.c1)) +
+		       rcp_newton((((8.3593271361634187 + -2.1243074194638587 * (t.c1 * t.c1)) +
 		                -0.04116989207898096 * (t.s1 * t.s1)) + -0.29573215449441 * t.s2));
 		g[2] = 0.0;
 		g[3] = -5.65378660671284 * ((2.0043013906215941 + gc) + gs) * iden;
@@ -615,7 +636,7 @@ struct Segway {
 		const double th2 = th * th;
 		const double t25 = th * 15.13175750513302 - 40.918271887954823;
 		const double t26 = w2 * 3.3849959169972448 + th * 30.26351501026604;
-		const double t23 = 1.0 / ((c2 * 2.0831375273848769 + s2 * 0.59146430898882) - 14.553176960784);
+		const double t23 = rcp_newton((c2 * 2.0831375273848769 + s2 * 0.59146430898882) - 14.553176960784);
 #pragma unroll
 		for (int i = 0; i < NX * NX; i++) Df[i] = 0.0;
 		Df[4] = 1.0;
@@ -649,7 +670,7 @@ struct Segway {
 		// the example divides by d26, d26^2, d4 and d4^2 (:205-210); d4 is t23's denominator, so one reciprocal of
 		// d26 and t23 serve all four (each quotient within an ulp of the divided form; the rows are compared at 1e-9)
 		(void)d4;
-		const double r26 = 1.0 / d26;
+		const double r26 = rcp_newton(d26);
 		Dg[9] = -(c1 * 0.1118494602519098 - s1 * 0.80343863413287053) * r26 +
 		        (r26 * r26) * (c2 * 0.59146430898882 - c1 * s1 * 4.1662750547697547) *
 		            ((c1 * 0.80343863413287053 + s1 * 0.1118494602519098) + 2.2990706749044238);
