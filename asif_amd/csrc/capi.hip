@@ -1058,6 +1058,32 @@ static int filter_host_strided(asif_hip_ctx *ctx, int64_t B, int64_t ldh, const 
 	if (e != hipSuccess) return (int)e;
 	const asif_hip_dims &d = ctx->dims;
 	const int nin = d.nx + d.nu, nout = d.nu + d.nrelax;
+	// Zero copy: when every buffer is page-locked host memory the device can address (hipHostMalloc / hipHostRegister,
+	// what a host that cares about transfer time hands over), the kernels read the inputs and write the results in
+	// place across the link -- one launch instead of seven staged copies and their launch latencies, and the slots
+	// the filter leaves untouched keep the caller's values by construction.  Coalesced 512-byte requests per wave, each
+	// byte crosses the link once: the call takes what the link takes.
+	{
+		void *dp[5];
+		const void *hp[5] = {x, udes, uact, relax, rc};
+		bool mapped = true;
+		for (int k = 0; k < 5 && mapped; k++) {
+			hipPointerAttribute_t at;
+			if (hipPointerGetAttributes(&at, hp[k]) != hipSuccess) {
+				(void)hipGetLastError(); // plain pageable memory: not an error, just not this path
+				mapped = false;
+			} else {
+				mapped = at.type == hipMemoryTypeHost && at.devicePointer != nullptr;
+				dp[k] = at.devicePointer;
+			}
+		}
+		if (mapped) {
+			const int r = asif_hip_filter_batch(ctx, B, ldh, (const double *)dp[0], (const double *)dp[1], (double *)dp[2],
+			                                    (double *)dp[3], (int32_t *)dp[4], nullptr, s);
+			if (r) return r;
+			return (int)hipStreamSynchronize(s);
+		}
+	}
 	if (B > ctx->cap) {
 		if (ctx->d_in) {
 			(void)hipFree(ctx->d_in);
