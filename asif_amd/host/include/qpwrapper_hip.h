@@ -46,7 +46,7 @@ private:
 	int device_;
 	double *host_; // pinned: [H (nv or nv*nv) | c | A | b | lb | ub | sol | status, iterations]
 	std::vector<uint8_t> be8_;
-	double *dev_;  // same layout on the device
+	double *dev_;  // the device-side address of that same block (zero copy: the kernel reads and writes it in place)
 	void *stream_;
 	int32_t status_, iters_;
 	int error_;

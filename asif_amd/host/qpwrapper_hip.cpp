@@ -16,7 +16,6 @@ QPWrapperHip::QPWrapperHip(const uint32_t nv, const uint32_t nc, const bool diag
 
 QPWrapperHip::~QPWrapperHip(void)
 {
-	if (dev_) (void)hipFree(dev_);
 	if (host_) (void)hipHostFree(host_);
 	if (stream_) (void)hipStreamDestroy((hipStream_t)stream_);
 }
@@ -31,7 +30,9 @@ int QPWrapperHip::setup(void)
 		return ASIF_HIP_ENODEVICE;
 	}
 	std::memset(host_, 0, sizeof(double) * total());
-	if ((e = hipMalloc((void **)&dev_, sizeof(double) * total())) != hipSuccess) return (int)e;
+	// the problem is a few hundred bytes: the kernel reads it from, and writes the solution to, the page-locked block
+	// itself (its device-side address) -- a solve is one launch and one synchronisation, no copies
+	if ((e = hipHostGetDevicePointer((void **)&dev_, host_, 0)) != hipSuccess) return (int)e;
 	hipStream_t s;
 	if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) return (int)e;
 	stream_ = (void *)s;
@@ -98,7 +99,6 @@ int32_t QPWrapperHip::solve(void)
 	}
 	hipStream_t s = (hipStream_t)stream_;
 	hipError_t e = hipSetDevice(device_);
-	if (e == hipSuccess) e = hipMemcpyAsync(dev_, host_, sizeof(double) * offSol(), hipMemcpyHostToDevice, s);
 	if (e != hipSuccess) {
 		error_ = (int)e;
 		return STATUS_UNSOLVED;
@@ -118,8 +118,7 @@ int32_t QPWrapperHip::solve(void)
 		error_ = r;
 		return STATUS_UNSOLVED;
 	}
-	e = hipMemcpyAsync(host_ + offSol(), dev_ + offSol(), sizeof(double) * (nv_ + 1), hipMemcpyDeviceToHost, s);
-	if (e == hipSuccess) e = hipStreamSynchronize(s);
+	e = hipStreamSynchronize(s);
 	if (e != hipSuccess) {
 		error_ = (int)e;
 		return STATUS_UNSOLVED;

@@ -1,6 +1,7 @@
 // host_qpwrapper_driver.cpp -- TEST DRIVER for ASIF::QPWrapperHip (asif_amd/host): the plug-in contract of
 // include/qpwrapper_abstract.h:16-51 as QPWrapperOsqp keeps it (src/qpwrapper_osqp.cpp:55-261).
 // Prints one "name value..." line per check; tests/test_gpu_host_cpp.py compares.
+#include <chrono>
 #include <cstdio>
 #include <vector>
 #include "qpwrapper_hip.h"
@@ -50,6 +51,26 @@ int main()
 		double mn = x[0], mx = x[0];
 		for (double v : x) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
 		std::printf("big %d %d %.15g %.15g\n", r, st, mn, mx);
+	}
+	// 3b. what one agent's control step costs at the plug-in: update + solve + read back of the 2 x 4 explicit-class QP
+	{
+		QPWrapperHip w(2, 4, true);
+		const double H[4] = {1, 0, 0, 10}, c[2] = {-1, -20}, lb[2] = {-1, 1}, ub[2] = {1, 1};
+		double A[8] = {0.5, -0.5, 1, -1, 1, 1, 1, 1}, b[4] = {-1, -1, -2, -2};
+		w.initialize(H, c, A, b, lb, ub);
+		double x[2];
+		for (int k = 0; k < 20; k++) w.solve();
+		const auto t0 = std::chrono::steady_clock::now();
+		const int n = 200;
+		int st = 0;
+		for (int k = 0; k < n; k++) {
+			b[0] = -1.0 - 1e-3 * k;
+			w.updateb(b);
+			st = w.solve();
+			w.getSolution(x);
+		}
+		const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / n;
+		std::printf("latency_us %d %.2f\n", st, us);
 	}
 	// 4. a shape beyond the kernels is a set-up error, not a solver verdict
 	{
