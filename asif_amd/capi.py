@@ -46,6 +46,7 @@ EXPORTS = [
     "asif_hip_partition", "asif_hip_create_multi", "asif_hip_multi_destroy", "asif_hip_multi_size",
     "asif_hip_multi_handle", "asif_hip_multi_update_options", "asif_hip_filter_batch_host_multi",
     "asif_hip_filter_batch_lie",
+    "asif_hip_math_probe",
 ]
 
 MODEL_DOUBLE_INTEGRATOR_SAMPLED = 4
@@ -255,6 +256,18 @@ class Filter:
         B = x.shape[1]
         check(self.lib.asif_hip_assemble_batch(self.handle, B, x.stride(0), _ptr(x), _ptr(A), _ptr(b), _ptr(code),
                                                _ptr(diag), _stream()))
+
+
+def math_probe(kind, a, b=None, device=0):
+    """asif_hip_math_probe: numpy float64 in, (out0, out1) out."""
+    import numpy as np
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    n = a.size
+    o0, o1 = np.zeros(n), np.zeros(n)
+    p = lambda v: v.ctypes.data_as(C.c_void_p) if v is not None else None
+    bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
+    check(load().asif_hip_math_probe(device, kind, C.c_int64(n), p(a), p(bb), p(o0), p(o1)))
+    return o0, o1
 
 
 def partition(B, nblocks, r):

@@ -322,6 +322,21 @@ typedef struct asif_hip_affine_instr {
 int asif_hip_affine_replay(int device, const asif_hip_affine_instr *prog, int32_t nprog, int32_t nreg, double *center,
                            int32_t *n, double *lo, double *hi, uint32_t *idx, double *coef);
 
+/* Self-test of the device math the trajectory kernels use in place of library calls: n values through one of
+ * the functions below, HOST pointers.  kind: 0 sin / cos of a by the fast path (out0 = sin, out1 = cos; |a| <= 1e5),
+ * 1 the same with the library fallback beyond that range, 2 tanh (absolute accuracy), 3 1 / a by seed + Newton steps,
+ * 4 sqrt(a) and 5 a / b without the IEEE sequences' rescaling steps (their stated operand ranges). */
+enum asif_hip_probe {
+	ASIF_HIP_PROBE_SINCOS = 0,
+	ASIF_HIP_PROBE_SINCOS_CHECKED = 1,
+	ASIF_HIP_PROBE_TANH = 2,
+	ASIF_HIP_PROBE_RCP = 3,
+	ASIF_HIP_PROBE_SQRT_PLAIN = 4,
+	ASIF_HIP_PROBE_DIV_PLAIN = 5
+};
+int asif_hip_math_probe(int device, int32_t kind, int64_t n, const double *a, const double *b, double *out0,
+                        double *out1);
+
 /* B pre-assembled QPs of one shape.  Hd[nv][ld] (diagonal of H), c[nv][ld], A[(nc*nv)][ld], b[nc][ld],
  * lb[nv][ld], ub[nv][ld]; be: HOST array of nc flags shared by the batch (NULL = none);
  * sol[nv][ld], status[B], iters[B] (may be NULL).  Cold start per instance.  nv <= 128, nc <= 128.
