@@ -33,7 +33,9 @@
 
 namespace asif {
 
-constexpr double kLdsGamma = 1e4;     // proximal weight 1/gamma on |x - xhat|^2
+constexpr double kLdsGamma = 1e7;     // proximal weight 1/gamma on |x - xhat|^2: weak -- the multiplier iteration, not the
+                                      // proximal term, is what should pace the outer loop (1e4 cost 3.5x the Newton steps;
+                                      // 1e8 leaves stragglers of 80 steps on near-singular K_J)
 constexpr double kLdsMu0 = 10.0;      // initial penalty; equalities 100x
 constexpr double kLdsMuMax = 1e4;     // cap: beyond it the rounding of mu (s - proj s) sets the residual floor
 constexpr int kLdsMaxOuter = 80;
