@@ -22,7 +22,7 @@ def main():
     sol = torch.zeros((P["nv"], B), dtype=torch.float64, device=dev)
     st = torch.zeros(B, dtype=torch.int32, device=dev)
     it = torch.zeros(B, dtype=torch.int32, device=dev)
-    for kw in (dict(), dict(scaling_iters=0), dict(scaling_iters=4), dict(max_iter=1), dict(max_iter=4), dict(max_iter=8)):
+    for kw in (dict(), dict(scaling_iters=-1), dict(scaling_iters=1), dict(scaling_iters=2), dict(scaling_iters=8), dict(max_iter=1)):
         s = capi.default_solver(**kw)
         for _ in range(2):
             capi.qp_solve_batch(P["Hd"], P["c"], P["A"], P["b"], P["lb"], P["ub"], sol, st, it, be=P["be"], solver=s)
