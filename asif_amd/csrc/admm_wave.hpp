@@ -205,7 +205,8 @@ __global__ __launch_bounds__(64) void qp_wave_kernel(asif_hip_solver S_, QpArgs 
 	s.Lm = s.Sm + NVMAX * W::NVP;
 	s.tv = s.Lm + NVMAX * W::NVP;
 	const int lane = threadIdx.x;
-	const int64_t qi = blockIdx.x;
+	const int64_t qi = xcd_contiguous_index(blockIdx.x, a.B);
+	if (qi >= a.B) return; // wave-uniform (one wave per workgroup)
 	const int nv = a.nv, nc = a.nc, m = nc + nv;
 	const int64_t ld = a.ld;
 	s.lane = lane;

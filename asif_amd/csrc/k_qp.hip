@@ -118,7 +118,7 @@ static int launch_wave(const asif_hip_solver &S0, const QpArgs &a, hipStream_t s
 	// the unscaled tolerances mean: never fewer than four Ruiz passes here
 	asif_hip_solver S = S0;
 	if (S.scaling_iters < 4) S.scaling_iters = 4;
-	hipLaunchKernelGGL((qp_wave_kernel<NVMAX>), dim3((unsigned)a.B), dim3(64), 0, stream, S, a);
+	hipLaunchKernelGGL((qp_wave_kernel<NVMAX>), dim3(xcd_grid(a.B)), dim3(64), 0, stream, S, a);
 	return (int)hipGetLastError();
 }
 
@@ -149,7 +149,7 @@ static int launch_lds(const asif_hip_solver &S0, const QpArgs &a, hipStream_t st
 		hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 		if (e != hipSuccess) return (int)e;
 	}
-	hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(64), bytes, stream, S, a);
+	hipLaunchKernelGGL(kern, dim3(xcd_grid(a.B)), dim3(64), bytes, stream, S, a);
 	return (int)hipGetLastError();
 }
 

@@ -431,7 +431,8 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 	using W = LdsQp<VPT, RPT, FULLH>;
 	W s;
 	const int lane = threadIdx.x;
-	const int64_t qi = blockIdx.x;
+	const int64_t qi = xcd_contiguous_index(blockIdx.x, a.B);
+	if (qi >= a.B) return; // wave-uniform (one wave per workgroup)
 	const int nv = a.nv, nc = a.nc;
 	const int64_t ld = a.ld;
 	s.lane = lane;
