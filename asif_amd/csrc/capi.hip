@@ -837,9 +837,9 @@ static int stage_rows(asif_hip_ctx *ctx, FilterArgs &a)
 }
 
 // The trajectory kernels keep checkpoints of the backup trajectory in HBM (pass 1) and re-integrate the few blocks
-// that hold the critical samples from them (pass 2); sized per handle, grown on demand.  Small states (nx = 2: the
-// pendulum and double-integrator models) keep only the npBTSS selected checkpoints, [npBTSS][nz + 2][ld]; the segway
-// (20-double state, 4-sample blocks) keeps one per block, [blocks][nz][ld].
+// that hold the critical samples from them (pass 2); sized per handle, grown on demand: the npBTSS selected
+// checkpoints, [npBTSS][nz + 2][ld] (the block-start state rides in registers over the block and is stored only
+// when the block enters the selection).
 static int stage_ckpt(asif_hip_ctx *ctx, FilterArgs &a)
 {
 	const int64_t nz = ctx->dims.nx + ctx->dims.nx * ctx->dims.nx;
@@ -847,10 +847,8 @@ static int stage_ckpt(asif_hip_ctx *ctx, FilterArgs &a)
 	switch (ctx->model) {
 	case ASIF_HIP_MODEL_INVERTED_PENDULUM:
 	case ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT:
-	case ASIF_HIP_MODEL_INVERTED_PENDULUM_TB: need = (int64_t)ctx->dims.npBTSS * (nz + 2) * a.ld; break;
-	case ASIF_HIP_MODEL_SEGWAY:
-		need = ((ctx->dims.npBT + Segway::kTrajBlock - 1) / Segway::kTrajBlock) * (nz + 2) * a.ld;
-		break;
+	case ASIF_HIP_MODEL_INVERTED_PENDULUM_TB:
+	case ASIF_HIP_MODEL_SEGWAY: need = (int64_t)ctx->dims.npBTSS * (nz + 2) * a.ld; break;
 	default: return ASIF_HIP_EINVAL;
 	}
 	if (need > ctx->s_ckpt_cap) {

@@ -54,24 +54,21 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 	// the K blocks with the smallest minima (ties -> earlier block): the K most critical samples of [0, idxHit]
 	// all lie in those blocks (see k_implicit.hip).  The per-sample selection this replaces (branch, K-entry
 	// network, NZ LDS writes) ran on most steps: 10 % of the segway kernel, 24 % of the pendulum's.
-	// Small states (NZ <= 8) keep the block-start state in registers over the block and store it only when the
-	// block enters the selection, into the displaced entry's slot: a.ckpt is [K][NZ][ld]; the segway's 20-double
-	// state would not fit the register budget and keeps one checkpoint per block, [blocks][NZ][ld].
+	// The block-start state rides in registers over the block and is stored only when the block enters the selection,
+	// into the displaced entry's slot: a.ckpt is [K][NZ][ld] (the segway's 20-double state included: it fits since
+	// the model's arithmetic was shortened; one checkpoint per block was 414 MB of writes per launch at 32 768).
 	constexpr int MB = M::kTrajBlock;
-	constexpr bool BYSLOT = NZ <= 8;
 	TopK<K> topB;
 	double *ck = a.ckpt + i;
-	double zs[BYSLOT ? NZ : 1];
+	double zs[NZ]; // state at the first sample of the current block
 	double bmin;
 	auto commit = [&](int blk) { // close block blk
 		if (__any(bmin < topB.key[K - 1])) {
 			const int slot = topB.insert(bmin, blk);
-			if constexpr (BYSLOT) {
-				if (slot >= 0) {
-					double *c = ck + (int64_t)slot * NZ * ld;
+			if (slot >= 0) {
+				double *c = ck + (int64_t)slot * NZ * ld;
 #pragma unroll
-					for (int k = 0; k < NZ; k++) c[k * ld] = zs[k];
-				}
+				for (int k = 0; k < NZ; k++) c[k * ld] = zs[k];
 			}
 		}
 	};
@@ -93,13 +90,8 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 			z[NX + k * (NX + 1)] = 1.0;
 		}
 		topB.init();
-		if constexpr (BYSLOT) {
 #pragma unroll
-			for (int k = 0; k < NZ; k++) zs[k] = z[k];
-		} else {
-#pragma unroll
-			for (int k = 0; k < NZ; k++) ck[k * ld] = z[k]; // block 0 starts at sample 0
-		}
+		for (int k = 0; k < NZ; k++) zs[k] = z[k]; // block 0 starts at sample 0
 		bmin = M::safetyMin(o, x0);
 		hall = bmin;
 		done = inside || !live;
@@ -119,14 +111,8 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 				if (s % MB == 0) { // wave-uniform: close the previous block, open the next
 					commit(s / MB - 1);
 					bmin = __builtin_huge_val();
-					if constexpr (BYSLOT) {
 #pragma unroll
-						for (int k = 0; k < NZ; k++) zs[k] = z[k];
-					} else {
-						double *c = ck + (int64_t)(s / MB) * NZ * ld;
-#pragma unroll
-						for (int k = 0; k < NZ; k++) c[k * ld] = z[k];
-					}
+					for (int k = 0; k < NZ; k++) zs[k] = z[k];
 				}
 				double xs[NX];
 #pragma unroll
@@ -180,7 +166,7 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 		if (!__any(have)) break;
 		cur = have ? nb : cur;
 		const int blk = have ? nb : 0;
-		const double *c = ck + (int64_t)(BYSLOT ? (have ? sl : 0) : blk) * NZ * ld;
+		const double *c = ck + (int64_t)(have ? sl : 0) * NZ * ld;
 #pragma unroll
 		for (int k = 0; k < NZ; k++) z[k] = c[k * ld];
 #pragma unroll 1
