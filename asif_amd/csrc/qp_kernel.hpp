@@ -33,7 +33,13 @@ template <int NV, int NC, int G, class Policy>
 __global__ __launch_bounds__(64) void qp_policy_kernel(asif_hip_solver S, Policy pol)
 {
 	constexpr int RPL = (NC + G - 1) / G;
-	const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	// G > 1: a wave covers 64 / G consecutive instances, i.e. 8 * 64 / G bytes of every SoA row -- less than the 128-byte
+	// line for G >= 8, so neighbouring workgroups share lines; with the dispatcher's round-robin over the XCDs they sit
+	// on different L2s and each fetches the line for itself.  The XCD-contiguous numbering puts them on the same XCD.
+	const int64_t nblk = (pol.B * G + blockDim.x - 1) / blockDim.x;
+	const int64_t blk = G > 1 ? xcd_contiguous_index(blockIdx.x, nblk) : (int64_t)blockIdx.x;
+	if (blk >= nblk) return; // wave-uniform: padding block of the XCD-rounded grid
+	const int64_t tid = blk * blockDim.x + threadIdx.x;
 	const int g = (int)(tid % G);
 	int64_t i = tid / G;
 	const bool live = i < pol.B;
@@ -52,8 +58,9 @@ static int launch_policy(const asif_hip_solver &S0, const Policy &pol, hipStream
 {
 	const int block = 64;
 	const asif_hip_solver S = resolve_scaling(S0, default_scaling);
-	hipLaunchKernelGGL((qp_policy_kernel<NV, NC, G, Policy>), dim3(grid_for(pol.B, G, block)), dim3(block), 0, stream,
-	                   S, pol);
+	const unsigned nblk = grid_for(pol.B, G, block);
+	hipLaunchKernelGGL((qp_policy_kernel<NV, NC, G, Policy>), dim3(G > 1 ? xcd_grid(nblk) : nblk), dim3(block), 0,
+	                   stream, S, pol);
 	return (int)hipGetLastError();
 }
 
