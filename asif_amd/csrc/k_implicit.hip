@@ -391,6 +391,7 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 
 template <class M>
 struct ImplicitPolicy {
+	static constexpr bool kStagedRows = true; // load() reads rows from HBM (qp_kernel.hpp: XCD-contiguous blocks)
 	int64_t B;
 	DevOptions o;
 	FilterArgs a; // a.A / a.b = staged rows

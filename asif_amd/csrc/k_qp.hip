@@ -12,6 +12,7 @@ int launch_qp_wave(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream
 int launch_qp_lds(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream);
 
 struct GenericQpPolicy {
+	static constexpr bool kStagedRows = true; // load() reads rows from HBM (qp_kernel.hpp: XCD-contiguous blocks)
 	int64_t B, ld;
 	const double *Hd, *c, *A, *b, *lb, *ub;
 	uint64_t be_mask;

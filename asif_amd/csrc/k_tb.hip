@@ -332,6 +332,7 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 
 template <class M>
 struct TbPolicy {
+	static constexpr bool kStagedRows = true; // load() reads rows from HBM (qp_kernel.hpp: XCD-contiguous blocks)
 	int64_t B;
 	DevOptions o;
 	FilterArgs a; // a.A / a.b = staged rows, a.code = staged branch codes

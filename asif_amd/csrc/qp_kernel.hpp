@@ -2,6 +2,7 @@
 // where the answer goes.  The generic C-ABI entry (k_qp.hip) and the two-stage filters (implicit, TB:
 // rows staged in HBM by the trajectory kernel) instantiate it with different policies.
 #pragma once
+#include <type_traits>
 #include "admm_small.hpp"
 #include "launchers.hpp"
 
@@ -29,15 +30,24 @@ __device__ __forceinline__ void load_rows(const double *A, const double *b, int6
 	}
 }
 
+// policies whose load() reads rows staged in HBM declare kStagedRows: their neighbouring workgroups share cache lines
+template <class P, class = void>
+struct reads_staged_rows : std::false_type {};
+template <class P>
+struct reads_staged_rows<P, std::enable_if_t<P::kStagedRows>> : std::true_type {};
+
 template <int NV, int NC, int G, class Policy>
 __global__ __launch_bounds__(64) void qp_policy_kernel(asif_hip_solver S, Policy pol)
 {
 	constexpr int RPL = (NC + G - 1) / G;
 	// G > 1: a wave covers 64 / G consecutive instances, i.e. 8 * 64 / G bytes of every SoA row -- less than the 128-byte
 	// line for G >= 8, so neighbouring workgroups share lines; with the dispatcher's round-robin over the XCDs they sit
-	// on different L2s and each fetches the line for itself.  The XCD-contiguous numbering puts them on the same XCD.
+	// on different L2s and each fetches the line for itself.  The XCD-contiguous numbering puts them on the same XCD
+	// (C3's QP kernel: 44 -> 23 MB, 26.1 -> 25.4 us; C4's 14.2 -> 12.6 us).  Only for policies that read staged rows: a
+	// policy that reads 24 bytes per instance has nothing to share, and C5's 7.5 us kernel lost 0.75 us to it.
+	constexpr bool kRemap = G > 1 && reads_staged_rows<Policy>::value;
 	const int64_t nblk = (pol.B * G + blockDim.x - 1) / blockDim.x;
-	const int64_t blk = G > 1 ? xcd_contiguous_index(blockIdx.x, nblk) : (int64_t)blockIdx.x;
+	const int64_t blk = kRemap ? xcd_contiguous_index(blockIdx.x, nblk) : (int64_t)blockIdx.x;
 	if (blk >= nblk) return; // wave-uniform: padding block of the XCD-rounded grid
 	const int64_t tid = blk * blockDim.x + threadIdx.x;
 	const int g = (int)(tid % G);
@@ -59,7 +69,7 @@ static int launch_policy(const asif_hip_solver &S0, const Policy &pol, hipStream
 	const int block = 64;
 	const asif_hip_solver S = resolve_scaling(S0, default_scaling);
 	const unsigned nblk = grid_for(pol.B, G, block);
-	hipLaunchKernelGGL((qp_policy_kernel<NV, NC, G, Policy>), dim3(G > 1 ? xcd_grid(nblk) : nblk), dim3(block), 0,
+	hipLaunchKernelGGL((qp_policy_kernel<NV, NC, G, Policy>), dim3((G > 1 && reads_staged_rows<Policy>::value) ? xcd_grid(nblk) : nblk), dim3(block), 0,
 	                   stream, S, pol);
 	return (int)hipGetLastError();
 }
