@@ -144,7 +144,8 @@ struct BackupLoop {
 
 	template <bool HOLD, int POISON = kTrigChecked>
 	__device__ __forceinline__ static void closedLoopT(const DevOptions &o, const double (&x)[NX], double (&fCL)[NX],
-	                                                   double (&DfCL)[NX * NX], Hold &hold, double t)
+	                                                   double (&DfCL)[NX * NX], Hold &hold, double t,
+	                                                   TrigCarry *cy = nullptr, bool reset = true)
 	{
 		double f[NX], g[NX], Df[NX * NX], Dg[NX * NX], u[1], Du[NX], uSat, DuSat;
 		M::backupController(o, x, u, Du);
@@ -158,7 +159,8 @@ struct BackupLoop {
 			us = hold.u;
 		}
 		saturateSoft<POISON != kTrigChecked>(o, us, uSat, DuSat);
-		M::template dynamicsAndGradients<POISON>(o, x, f, g, Df, Dg);
+		if constexpr (POISON == kTrigCarried) M::dynamicsAndGradientsCarried(o, x, f, g, Df, Dg, *cy, reset);
+		else M::template dynamicsAndGradients<POISON>(o, x, f, g, Df, Dg);
 		if constexpr (M::kInputOnLastState) {
 			// g = e_last, Dg = 0: the general expression below with its constant factors folded by hand
 			// (the compiler may not fold x*0 or 0+x for doubles)
@@ -229,12 +231,13 @@ struct BackupLoop {
 	// the reference stamps on this rhs (src/asif_implicit_robust.cpp:567: i*backTrajDt for the step INTO sample i)
 	// POISON: the model's sin / cos never branch; out-of-range arguments turn the state into NaN (see sincos_fast)
 	template <bool HOLD, int POISON = kTrigChecked>
-	__device__ __forceinline__ static void eulerStepT(const DevOptions &o, double (&z)[NZ], Hold &hold, double t)
+	__device__ __forceinline__ static void eulerStepT(const DevOptions &o, double (&z)[NZ], Hold &hold, double t,
+	                                                  TrigCarry *cy = nullptr, bool reset = true)
 	{
 		double x[NX], fCL[NX], DfCL[NX * NX], zd[NZ];
 #pragma unroll
 		for (int i = 0; i < NX; i++) x[i] = z[i];
-		closedLoopT<HOLD, POISON>(o, x, fCL, DfCL, hold, t);
+		closedLoopT<HOLD, POISON>(o, x, fCL, DfCL, hold, t, cy, reset);
 #pragma unroll
 		for (int i = 0; i < NX; i++) zd[i] = fCL[i];
 #pragma unroll

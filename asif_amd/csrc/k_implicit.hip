@@ -171,6 +171,9 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 	// wave-level branch (and, by margin, without any per-step work) in the common step.
 	// The fast path also takes the soft saturation's short forms (BackupLoop::saturateSoft<FAST>), valid for ordinary
 	// saturation constants (DevOptions::satFastOk, checked on the host); other options run the generic step.
+	// the fast step's trig mode: carried along the block, bounded by the margin, or poisoning (models.hpp)
+	constexpr int kFastTrig = trig_carry<M>::value ? kTrigCarried : (trig_by_margin<M>::value ? kTrigUnchecked : kTrigPoison);
+	TrigCarry carry = {0.0, 0.0, 1.0};
 	const int nblk = (o.npBT + MB - 1) / MB;
 	bool anyRedo = false; // some block of this wave ran on the generic step (pass 2 then does too)
 #pragma unroll 1
@@ -179,11 +182,13 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 		const int n = (o.npBT - s0) < MB ? (o.npBT - s0) : MB; // samples of this block
 		const bool more = s0 + n < o.npBT;
 		auto run = [&](auto fast) {
-			constexpr int P = !decltype(fast)::value ? kTrigChecked : (trig_by_margin<M>::value ? kTrigUnchecked : kTrigPoison);
+			constexpr int P = !decltype(fast)::value ? kTrigChecked : kFastTrig;
 			bmin = __builtin_huge_val();
-			auto sample = [&](int k) {
+			// reset: the step out of the block's first sample evaluates sin / cos afresh (kTrigCarried); a literal at every
+			// call site, so that the step is compiled in its two forms instead of choosing at run time
+			auto sample = [&](int k, bool reset) {
 				const int sidx = s0 + k;
-				if (k > 0) BackupLoop<M>::template eulerStepT<RB, P>(o, z, hold, (double)(unsigned)sidx * o.trajDt);
+				if (k > 0) BackupLoop<M>::template eulerStepT<RB, P>(o, z, hold, (double)(unsigned)sidx * o.trajDt, &carry, reset);
 				if (RB && sidx == o.nDebug) {
 #pragma unroll
 					for (int c = 0; c < NZ; c++) zDbg[c] = z[c];
@@ -193,14 +198,28 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 				for (int c = 0; c < NX; c++) xs[c] = z[c];
 				bmin = fmin(bmin, M::safetyMin(o, xs));
 			};
+			static_assert(MB >= 4 && MB % 4 == 0, "blocks of a multiple of four samples");
 			if (n == MB) { // full block: compile-time trip count, unrolled by four (loop control is SALU + a branch per step)
+				if constexpr (trig_carry<M>::value) {
+					sample(0, false);
+					sample(1, true);
+					sample(2, false);
+					sample(3, false);
 #pragma unroll 4
-				for (int k = 0; k < MB; k++) sample(k);
+					for (int k = 4; k < MB; k++) sample(k, false);
+				} else {
+#pragma unroll 4
+					for (int k = 0; k < MB; k++) sample(k, false);
+				}
 			} else {
+				sample(0, false);
+				if (n > 1) sample(1, true);
 #pragma unroll 1
-				for (int k = 0; k < n; k++) sample(k);
+				for (int k = 2; k < n; k++) sample(k, false);
 			}
-			if (more) BackupLoop<M>::template eulerStepT<RB, P>(o, z, hold, (double)(unsigned)(s0 + n) * o.trajDt);
+			if (more) { // n == MB here (only the last block is partial)
+				BackupLoop<M>::template eulerStepT<RB, P>(o, z, hold, (double)(unsigned)(s0 + n) * o.trajDt, &carry, false);
+			}
 		};
 		bool redo = !o.satFastOk; // options outside the fast step's preconditions (uniform): generic step throughout
 		if (!redo) {
@@ -208,7 +227,8 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 			bool bad = false;
 #pragma unroll
 			for (int c = 0; c < NZ; c++) bad = bad || (z[c] != z[c]);
-			if constexpr (trig_by_margin<M>::value) bad = bad || !M::trigArgsBounded(bmin);
+			if constexpr (trig_carry<M>::value) bad = bad || !M::trigCarryBounded(o, bmin);
+			else if constexpr (trig_by_margin<M>::value) bad = bad || !M::trigArgsBounded(bmin);
 			redo = __any(bad); // never on sane trajectories
 			if (redo) {
 #pragma unroll
@@ -259,8 +279,10 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 			if (t > 0) {
 				// the samples of a selected block went through pass 1's range check with these very states: the fast step
 				// is valid for them again (steps past the horizon or of a lane without a block feed nothing)
-				constexpr int P = trig_by_margin<M>::value ? kTrigUnchecked : kTrigPoison;
-				if (fast2) BackupLoop<M>::template eulerStepT<RB, P>(o, z, hold, (double)(unsigned)s * o.trajDt);
+				if (fast2) {
+					if (t == 1) BackupLoop<M>::template eulerStepT<RB, kFastTrig>(o, z, hold, (double)(unsigned)s * o.trajDt, &carry, true);
+					else BackupLoop<M>::template eulerStepT<RB, kFastTrig>(o, z, hold, (double)(unsigned)s * o.trajDt, &carry, false);
+				}
 				else BackupLoop<M>::template eulerStepT<RB>(o, z, hold, (double)(unsigned)s * o.trajDt);
 			}
 			double xs[NX];

@@ -22,6 +22,19 @@ __global__ void math_probe_kernel(int kind, int64_t n, const double *a, const do
 	case ASIF_HIP_PROBE_RCP: r0 = rcp_newton(x); break;
 	case ASIF_HIP_PROBE_SQRT_PLAIN: r0 = BackupLoop<InvertedPendulum>::sqrt_plain_range(x); break;
 	case ASIF_HIP_PROBE_DIV_PLAIN: r0 = BackupLoop<InvertedPendulum>::div_plain_range(x, y); break;
+	case ASIF_HIP_PROBE_SINCOS_CARRY: { // one block of the trajectory loop: fresh evaluation at x, then 15 carried steps of y
+		TrigCarry cy;
+		sincos_fast<kTrigUnchecked>(x, cy.s, cy.c);
+		cy.x = x;
+		double xx = x;
+		for (int k = 0; k < 15; k++) {
+			xx += y;
+			sincos_carry(xx, cy);
+		}
+		r0 = cy.s;
+		r1 = cy.c;
+		break;
+	}
 	default: break;
 	}
 	o0[i] = r0;
@@ -33,8 +46,8 @@ __global__ void math_probe_kernel(int kind, int64_t n, const double *a, const do
 extern "C" int asif_hip_math_probe(int device, int32_t kind, int64_t n, const double *a, const double *b, double *out0,
                                    double *out1)
 {
-	if (n < 0 || kind < 0 || kind > ASIF_HIP_PROBE_DIV_PLAIN || (n > 0 && (!a || !out0))) return ASIF_HIP_EINVAL;
-	if (kind == ASIF_HIP_PROBE_DIV_PLAIN && n > 0 && !b) return ASIF_HIP_EINVAL;
+	if (n < 0 || kind < 0 || kind > ASIF_HIP_PROBE_SINCOS_CARRY || (n > 0 && (!a || !out0))) return ASIF_HIP_EINVAL;
+	if ((kind == ASIF_HIP_PROBE_DIV_PLAIN || kind == ASIF_HIP_PROBE_SINCOS_CARRY) && n > 0 && !b) return ASIF_HIP_EINVAL;
 	if (n == 0) return ASIF_HIP_OK;
 	hipError_t e = hipSetDevice(device);
 	if (e != hipSuccess) return ASIF_HIP_ENODEVICE;

@@ -80,8 +80,12 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 	// by NaN poisoning (kTrigPoison: an argument outside the range turns the lane's state into NaN -- NaN never enters
 	// the backup set).  A lane out of range has the pass repeated with the checking version.
 	double hall; // smallest safety margin of the whole pass (kTrigUnchecked: it bounds the trig arguments)
+	// the fast step's trig mode: bounded by the margin, or poisoning (models.hpp).  (kTrigCarried, which pays in the
+	// block-structured loop of k_implicit.hip, does not here: this loop has per-lane exits at every sample, the two step
+	// forms double its body, and the pendulum's 11 551-step pass came out 10 % slower.)
+	constexpr int kFastTrig = trig_by_margin<M>::value ? kTrigUnchecked : kTrigPoison;
 	auto pass1 = [&](auto fast) {
-		constexpr int P = !decltype(fast)::value ? kTrigChecked : (trig_by_margin<M>::value ? kTrigUnchecked : kTrigPoison);
+		constexpr int P = !decltype(fast)::value ? kTrigChecked : kFastTrig;
 #pragma unroll
 		for (int k = 0; k < NZ; k++) z[k] = 0.0;
 #pragma unroll
@@ -174,9 +178,8 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 			const int s = blk * MB + tt;
 			if (tt > 0) {
 				// pass 1 has range-checked these very states (unless it had to be redone): the fast step is valid again
-				constexpr int P = trig_by_margin<M>::value ? kTrigUnchecked : kTrigPoison;
 				typename BackupLoop<M>::Hold none2 = {0.0, 0.0};
-				if (fast2) BackupLoop<M>::template eulerStepT<false, P>(o, z, none2, 0.0);
+				if (fast2) BackupLoop<M>::template eulerStepT<false, kFastTrig>(o, z, none2, 0.0);
 				else BackupLoop<M>::eulerStep(o, z);
 			}
 			double xs[NX];

@@ -83,3 +83,20 @@ def test_bevel_sqrt_and_divide_are_the_ieee_results_on_their_ranges(hip):
                         rng.uniform(0.1, 2, 10)])
     q, _ = hip.math_probe(5, a, b)
     assert np.array_equal(q, a / b)
+
+
+def test_carried_sincos_over_one_block(hip):
+    """kTrigCarried (models.hpp): sin / cos evaluated at the block's first sample and rotated by the angle's increments
+    for the 15 steps of a block: at the accumulated angle, within 1.5 + 15/2 ulp of 1 by construction, a few ulp in
+    practice; increments up to kTrigCarryMaxStep."""
+    rng = np.random.default_rng(5)
+    x0 = rng.uniform(-4, 4, 400000)
+    d = np.concatenate([rng.uniform(-0.03, 0.03, 200000), rng.normal(0, 2e-3, 200000)])
+    s, c = hip.math_probe(6, x0, d)
+    x = x0.copy()
+    for _ in range(15):
+        x = x + d  # the angle the loop holds (accumulated in double, as the Euler state is)
+    es = np.abs(s.astype(LD) - np.sin(x.astype(LD)))
+    ec = np.abs(c.astype(LD) - np.cos(x.astype(LD)))
+    assert max(es.max(), ec.max()) <= 9.5 * EPS
+    assert np.sqrt(np.mean(es.astype(np.float64) ** 2)) <= 2.0 * EPS  # typical error: an ulp or two
