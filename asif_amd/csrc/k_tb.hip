@@ -80,10 +80,19 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 	// by NaN poisoning (kTrigPoison: an argument outside the range turns the lane's state into NaN -- NaN never enters
 	// the backup set).  A lane out of range has the pass repeated with the checking version.
 	double hall; // smallest safety margin of the whole pass (kTrigUnchecked: it bounds the trig arguments)
-	// the fast step's trig mode: bounded by the margin, or poisoning (models.hpp).  (kTrigCarried, which pays in the
-	// block-structured loop of k_implicit.hip, does not here: this loop has per-lane exits at every sample, the two step
-	// forms double its body, and the pendulum's 11 551-step pass came out 10 % slower.)
-	constexpr int kFastTrig = trig_by_margin<M>::value ? kTrigUnchecked : kTrigPoison;
+	// the fast step's trig mode (models.hpp): carried along the steps, bounded by the margin, or poisoning.  Carried:
+	// ONE form of the step (always the rotation); sin / cos are re-synchronised with a fresh evaluation where a block
+	// starts -- here at the block boundary, in pass 2 after loading a block's checkpoint: the same arithmetic from the
+	// same state, so both passes see the same bits.  (Choosing between two forms of the step inside this loop, with its
+	// per-lane exits at every sample, doubled its body and cost the pendulum's 11 551-step pass 10 %.)
+	constexpr int kFastTrig = trig_carry<M>::value ? kTrigCarried : (trig_by_margin<M>::value ? kTrigUnchecked : kTrigPoison);
+	TrigCarry carry = {0.0, 0.0, 1.0};
+	auto resync = [&]() {
+		if constexpr (trig_carry<M>::value) {
+			sincos_fast<kTrigUnchecked>(z[M::kTrigAngle], carry.s, carry.c);
+			carry.x = z[M::kTrigAngle];
+		}
+	};
 	auto pass1 = [&](auto fast) {
 		constexpr int P = !decltype(fast)::value ? kTrigChecked : kFastTrig;
 #pragma unroll
@@ -96,6 +105,7 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 		topB.init();
 #pragma unroll
 		for (int k = 0; k < NZ; k++) zs[k] = z[k]; // block 0 starts at sample 0
+		if (P == kTrigCarried) resync();
 		bmin = M::safetyMin(o, x0);
 		hall = bmin;
 		done = inside || !live;
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 		for (int s = 1; s < o.npBT; s++) {
 			if (__all(done)) break;
 			if (!done) {
-				BackupLoop<M>::template eulerStepT<false, P>(o, z, none, 0.0);
+				BackupLoop<M>::template eulerStepT<false, P>(o, z, none, 0.0, &carry, false);
 				t = t + o.trajDt; // backTraj_[i].first accumulates, :475
 				sLast = s;
 				if (s % MB == 0) { // wave-uniform: close the previous block, open the next
@@ -117,6 +127,7 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 					bmin = __builtin_huge_val();
 #pragma unroll
 					for (int k = 0; k < NZ; k++) zs[k] = z[k];
+					if (P == kTrigCarried) resync();
 				}
 				double xs[NX];
 #pragma unroll
@@ -142,7 +153,8 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 		bool bad = false;
 #pragma unroll
 		for (int k = 0; k < NZ; k++) bad = bad || (z[k] != z[k]);
-		if constexpr (trig_by_margin<M>::value) bad = bad || !M::trigArgsBounded(hall);
+		if constexpr (trig_carry<M>::value) bad = bad || !M::trigCarryBounded(o, hall);
+		else if constexpr (trig_by_margin<M>::value) bad = bad || !M::trigArgsBounded(hall);
 		redo = __any(bad); // never on sane trajectories
 	}
 	if (redo) pass1(std::false_type());
@@ -173,13 +185,14 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 		const double *c = ck + (int64_t)(have ? sl : 0) * NZ * ld;
 #pragma unroll
 		for (int k = 0; k < NZ; k++) z[k] = c[k * ld];
+		if (fast2) resync(); // the block's first sample: as pass 1 did at this boundary
 #pragma unroll 1
 		for (int tt = 0; tt < MB; tt++) {
 			const int s = blk * MB + tt;
 			if (tt > 0) {
 				// pass 1 has range-checked these very states (unless it had to be redone): the fast step is valid again
 				typename BackupLoop<M>::Hold none2 = {0.0, 0.0};
-				if (fast2) BackupLoop<M>::template eulerStepT<false, kFastTrig>(o, z, none2, 0.0);
+				if (fast2) BackupLoop<M>::template eulerStepT<false, kFastTrig>(o, z, none2, 0.0, &carry, false);
 				else BackupLoop<M>::eulerStep(o, z);
 			}
 			double xs[NX];

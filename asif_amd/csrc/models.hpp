@@ -106,7 +106,7 @@ constexpr double kTrigFastRange = 1e5;
 //   kTrigCarried    (models that declare kTrigCarry) sin / cos of the state's angle are CARRIED along the Euler steps:
 //                   evaluated by the fast path at the first sample of a block, then rotated by the angle's increment,
 //                   sin(a + d) = sin a + (sin a (cos d - 1) + cos a sin d) and its twin, with short polynomials for
-//                   sin d and cos d - 1 (|d| <= kTrigCarryMaxStep: truncation below 1e-19).  The correction is O(d), so
+//                   sin d and cos d - 1 (|d| <= kTrigCarryMaxStep: truncation below 1e-17).  The correction is O(d), so
 //                   each step adds half an ulp of the result from the final addition only: <= 1.5 + n / 2 ulp after n
 //                   steps of a block (16: <= 9.5, typically 2-3) -- against 1.5 ulp for an evaluation per step, at
 //                   17 instead of 35 vector instructions.  Policed per block like kTrigUnchecked, with the bound on the
@@ -115,12 +115,12 @@ constexpr double kTrigFastRange = 1e5;
 struct TrigCarry {
 	double x, s, c; // angle at which s = sin, c = cos hold
 };
-constexpr double kTrigCarryMaxStep = 0.03;
+constexpr double kTrigCarryMaxStep = 0.05; // truncation of the two polynomials there: 5e-18 and 3e-20
 __device__ __forceinline__ void sincos_carry(double x, TrigCarry &cy)
 {
 	const double d = x - cy.x;
 	const double d2 = d * d;
-	// sin d to d^7 and cos d - 1 to d^8: truncation d^9 / 9! and d^10 / 10!, 5e-20 and 2e-22 at |d| = 0.03
+	// sin d to d^7 and cos d - 1 to d^8: truncation d^9 / 9! and d^10 / 10!, 5e-18 and 3e-20 at |d| = 0.05
 	const double sd = fma(d * d2, fma(d2, fma(d2, -1.98412698412698412698e-04, 8.33333333333333333333e-03), -1.66666666666666666667e-01), d);
 	const double cm = d2 * fma(d2, fma(d2, fma(d2, 2.48015873015873015873e-05, -1.38888888888888888889e-03), 4.16666666666666666667e-02), -0.5);
 	const double s = cy.s, c = cy.c;
@@ -294,6 +294,7 @@ struct InvertedPendulum {
 	}
 	// the same with the angle's sin / cos carried from the previous step (kTrigCarried); reset: first step of a block
 	static constexpr bool kTrigCarry = true;
+	static constexpr int kTrigAngle = 0; // the state component whose sin / cos are carried
 	__device__ static void dynamicsAndGradientsCarried(const DevOptions &, const double (&x)[NX], double (&f)[NX],
 	                                                   double (&g)[NX * NU], double (&Df)[NX * NX],
 	                                                   double (&Dg)[NX * NU * NX], TrigCarry &cy, bool reset)
@@ -537,6 +538,7 @@ struct InvertedPendulumTB {
 		InvertedPendulum::dynamicsAndGradients<POISON>(o, x, f, g, Df, Dg);
 	}
 	static constexpr bool kTrigCarry = true;
+	static constexpr int kTrigAngle = 0;
 	__device__ static void dynamicsAndGradientsCarried(const DevOptions &o, const double (&x)[NX], double (&f)[NX],
 	                                                   double (&g)[NX * NU], double (&Df)[NX * NX],
 	                                                   double (&Dg)[NX * NU * NX], TrigCarry &cy, bool reset)
@@ -695,10 +697,39 @@ struct Segway {
 	}
 	// :113-212
 	template <int POISON = kTrigChecked>
-	__device__ static void dynamicsAndGradients(const DevOptions &, const double (&x)[NX], double (&f)[NX],
+	__device__ static void dynamicsAndGradients(const DevOptions &o, const double (&x)[NX], double (&f)[NX],
 	                                            double (&g)[NX * NU], double (&Df)[NX * NX], double (&Dg)[NX * NU * NX])
 	{
-		const Trig t = trig<POISON>(x[2]);
+		gradientsWithTrig(o, x, trig<POISON>(x[2]), f, g, Df, Dg);
+	}
+	// the pitch's sin / cos carried along the Euler steps (kTrigCarried; the TB kernel re-synchronises at block starts)
+	static constexpr bool kTrigCarry = true;
+	static constexpr int kTrigAngle = 2;
+	__device__ static void dynamicsAndGradientsCarried(const DevOptions &o, const double (&x)[NX], double (&f)[NX],
+	                                                   double (&g)[NX * NU], double (&Df)[NX * NX],
+	                                                   double (&Dg)[NX * NU * NX], TrigCarry &cy, bool reset)
+	{
+		if (reset) {
+			sincos_fast<kTrigUnchecked>(x[2], cy.s, cy.c);
+			cy.x = x[2];
+		} else {
+			sincos_carry(x[2], cy);
+		}
+		Trig t;
+		t.s1 = cy.s;
+		t.c1 = cy.c;
+		t.s2 = 2.0 * t.s1 * t.c1;
+		t.c2 = (t.c1 - t.s1) * (t.c1 + t.s1);
+		gradientsWithTrig(o, x, t, f, g, Df, Dg);
+	}
+	// |pitch rate| <= sqrt(xb(3)^2 - hmin): the pitch's increment per step is dt times that
+	__device__ static bool trigCarryBounded(const DevOptions &o, double hmin)
+	{
+		return trigArgsBounded(hmin) && (xb(3) * xb(3) - hmin) * (o.trajDt * o.trajDt) <= kTrigCarryMaxStep * kTrigCarryMaxStep;
+	}
+	__device__ static void gradientsWithTrig(const DevOptions &, const double (&x)[NX], const Trig &t, double (&f)[NX],
+	                                         double (&g)[NX * NU], double (&Df)[NX * NX], double (&Dg)[NX * NU * NX])
+	{
 		const Shared h = dynamicsT(x, t, f, g);
 		const double c1 = t.c1, s1 = t.s1, c2 = t.c2, s2 = t.s2;
 		const double w2 = x[3] * x[3];

@@ -91,7 +91,7 @@ def test_carried_sincos_over_one_block(hip):
     practice; increments up to kTrigCarryMaxStep."""
     rng = np.random.default_rng(5)
     x0 = rng.uniform(-4, 4, 400000)
-    d = np.concatenate([rng.uniform(-0.03, 0.03, 200000), rng.normal(0, 2e-3, 200000)])
+    d = np.concatenate([rng.uniform(-0.05, 0.05, 200000), rng.normal(0, 2e-3, 200000)])
     s, c = hip.math_probe(6, x0, d)
     x = x0.copy()
     for _ in range(15):
