@@ -72,6 +72,10 @@ def _with_options(hip, oracle, cfg, **kw):
     (3, 96, dict(satSharpness=1e-31, backTrajHorizon=0.75, backTrajDt=0.005)),
     (3, 96, dict(satSharpness=4.0, backTrajHorizon=0.75, backTrajDt=0.005)),
     (4, 512, dict(satSharpness=1e-31, backTrajHorizon=1.0)),
+    # a coarse trajectory step: the angle moves by up to 0.06 per step for the faster states, beyond what the carried
+    # sin / cos accept (kTrigCarryMaxStep) -- those blocks are repeated on the generic step, the others stay on the fast one
+    (3, 192, dict(backTrajHorizon=2.0, backTrajDt=0.04)),
+    (8, 96, dict(backTrajHorizon=2.0, backTrajDt=0.04)),
 ])
 def test_non_default_options(hip, oracle, cfg, B, kw):
     o, oo = _with_options(hip, oracle, cfg, **kw)
