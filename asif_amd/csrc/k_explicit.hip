@@ -314,7 +314,7 @@ int launch_explicit_di(const DevOptions &o, const asif_hip_solver &S, const Filt
 	if (a.B <= 0) return 0;
 	// default solver mode (dual active-set stage first) or presolve: that stage alone decides every instance of this
 	// class with one input -- the light instantiation, one instance per lane, larger blocks
-	if ((S.presolve || (S.polish == 2 && S.lanes_per_qp <= 1)) && !assemble_only) {
+	if ((S.presolve || (S.polish == 2 && (S.lanes_per_qp == 0 || S.lanes_per_qp == 1))) && !assemble_only) {
 		const int block = 256;
 		if (o.npKeep < DoubleIntegrator::NPSS || a.lfh != nullptr)
 			hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, 1, true, true>), dim3(grid_for(a.B, 1, block)),
