@@ -488,6 +488,7 @@ struct DoubleIntegratorImplicit {
 struct InvertedPendulumTB {
 	static constexpr int NX = 2, NU = 1, NPSS = 4, NPBS = 1, NPBTSS = 4;
 	static constexpr int kTrajBlock = 32; // 11 551-sample trajectory, 4 critical samples (measured: 16 = 32 < 64 < 128)
+	static constexpr bool kTbUnrollSteps = true; // k_tb.hip: full blocks unrolled by four
 	// g = e_last and Dg = 0 for every state: lets the backup loop drop the generic formula's products with
 	// those constants (x*0, x*1, 0+x) -- same values, ~10 fewer FP64 issues per Euler step
 	static constexpr bool kInputOnLastState = true;
@@ -560,6 +561,7 @@ struct InvertedPendulumTB {
 struct Segway {
 	static constexpr int NX = 4, NU = 1, NPSS = 4, NPBS = 1, NPBTSS = 4;
 	static constexpr int kTrajBlock = 4; // 316-sample trajectory, 4 critical samples (measured: 4 < 8 < 2 < 16)
+	static constexpr bool kTbUnrollSteps = false;
 	static constexpr bool kInputOnLastState = false; // g depends on the pitch
 	static constexpr bool kDfFirstRowShift = false;
 
