@@ -148,7 +148,7 @@ def cpu_baseline(cfg, gpu_uact, gpu_rc, x, udes):
     t = time.perf_counter()
     O.filter_batch(model, variant, o, xs, us, O.SOLVER_ADMM, None, cores)
     dt = time.perf_counter() - t
-    m = min(x.shape[1], {2: 65536, 3: 512, 4: 16384, 5: 8192, 8: 512, 9: 16384, 10: 512, 11: 65536}[cfg])
+    m = min(x.shape[1], {2: 65536, 3: 16384, 4: 32768, 5: 8192, 8: 16384, 9: 65536, 10: 16384, 11: 65536}[cfg])  # the full batch
     ua, _, rc = O.filter_batch(model, variant, o, np.ascontiguousarray(x[:, :m].T),
                                np.ascontiguousarray(udes[:, :m].T), O.SOLVER_EXACT, None, cores,
                                uact_init=np.zeros((m, gpu_uact.shape[0])))
