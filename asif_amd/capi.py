@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libasif_hip.so")
+LIB_PATH = os.environ.get("ASIF_HIP_LIB") or os.path.join(_HERE, "libasif_hip.so")  # env: a developer build to try
 
 MODEL_DOUBLE_INTEGRATOR, MODEL_INVERTED_PENDULUM, MODEL_SEGWAY, MODEL_INVERTED_PENDULUM_ROBUST = 0, 1, 2, 3
 EXPLICIT, IMPLICIT, IMPLICIT_TB, ROBUST = 0, 1, 2, 3

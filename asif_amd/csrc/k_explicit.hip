@@ -17,8 +17,8 @@ namespace asif {
 // SEL: the optional paths of src/asif.cpp (npSSmax < npSS row selection, caller-supplied Lie derivatives) are
 // compiled in; the default instantiation (every row, the model's own Lie derivatives) does not carry them.
 template <class M, int G, bool PRE, bool SEL = false>
-__global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_filter_kernel(DevOptions o, asif_hip_solver S, FilterArgs a,
-                                                             bool assemble_only)
+__device__ __forceinline__ void explicit_filter_body(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a,
+                                                     bool assemble_only)
 {
 	constexpr int NX = M::NX, NU = M::NU, NP = M::NPSS, NV = NU + 1, NC = NP;
 	constexpr int RPL = (NC + G - 1) / G;
@@ -172,6 +172,23 @@ __global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_f
 	}
 }
 
+template <class M, int G, bool PRE, bool SEL = false>
+__global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_filter_kernel(DevOptions o, asif_hip_solver S, FilterArgs a,
+                                                             bool assemble_only)
+{
+	explicit_filter_body<M, G, PRE, SEL>(o, S, a, assemble_only);
+}
+
+// The light instantiation with its options by POINTER (the handle's device copy): its step is bound by the host's
+// launch rate, and a launch that carries the 2 KB options structure in its argument block costs the host 3.9 us
+// against 2.8 us for a small block (tools/scratch/launch_cost.hip).  The loads are scalar either way.
+template <class M, bool SEL>
+__global__ __launch_bounds__(256) void explicit_light_kernel(const DevOptions *op, FilterArgs a)
+{
+	const asif_hip_solver none = {};
+	explicit_filter_body<M, 1, true, SEL>(*op, none, a, false);
+}
+
 // Closed loop, T control steps per launch (the caller's side of filter(): examples/DoubleIntegrator.cpp:81-116).
 // Per step:  rc = filter(x, uDes, uAct, relax)  exactly as above (cold start, like every batched call);  then the
 // plant's forward-Euler step  fCl = 0 + f + uAct*g,  x += dt*fCl  (:96-110) with the dynamics at the state the
@@ -278,7 +295,8 @@ __global__ __launch_bounds__(LIGHT ? 256 : 64) void explicit_rollout_kernel(DevO
 	a.nfail[i] = nfail;
 }
 
-int launch_rollout_explicit_di(const DevOptions &o, const asif_hip_solver &S0, const RolloutArgs &a, hipStream_t stream)
+int launch_rollout_explicit_di(const DevOptions &o, const DevOptions *, const asif_hip_solver &S0, const RolloutArgs &a,
+                               hipStream_t stream)
 {
 	if (a.B <= 0 || a.T <= 0) return 0;
 	const asif_hip_solver S = resolve_scaling(S0, 1, 1);
@@ -308,20 +326,29 @@ static int launch_g(const DevOptions &o, const asif_hip_solver &S0, const Filter
 	return (int)hipGetLastError();
 }
 
-int launch_explicit_di(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
-                       hipStream_t stream)
+int launch_explicit_di(const DevOptions &o, const DevOptions *d_o, const asif_hip_solver &S, const FilterArgs &a,
+                       bool assemble_only, hipStream_t stream)
 {
 	if (a.B <= 0) return 0;
 	// default solver mode (dual active-set stage first) or presolve: that stage alone decides every instance of this
 	// class with one input -- the light instantiation, one instance per lane, larger blocks
 	if ((S.presolve || (S.polish == 2 && (S.lanes_per_qp == 0 || S.lanes_per_qp == 1))) && !assemble_only) {
 		const int block = 256;
-		if (o.npKeep < DoubleIntegrator::NPSS || a.lfh != nullptr)
+		const bool sel = o.npKeep < DoubleIntegrator::NPSS || a.lfh != nullptr;
+		if (d_o) { // options from the handle's device copy
+			if (sel)
+				hipLaunchKernelGGL((explicit_light_kernel<DoubleIntegrator, true>), dim3(grid_for(a.B, 1, block)), dim3(block),
+				                   0, stream, d_o, a);
+			else
+				hipLaunchKernelGGL((explicit_light_kernel<DoubleIntegrator, false>), dim3(grid_for(a.B, 1, block)), dim3(block),
+				                   0, stream, d_o, a);
+		} else if (sel) {
 			hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, 1, true, true>), dim3(grid_for(a.B, 1, block)),
 			                   dim3(block), 0, stream, o, S, a, false);
-		else
+		} else {
 			hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, 1, true, false>), dim3(grid_for(a.B, 1, block)),
 			                   dim3(block), 0, stream, o, S, a, false);
+		}
 		return (int)hipGetLastError();
 	}
 	switch (S.lanes_per_qp) {

@@ -297,6 +297,35 @@ def qp_problem(cfg, B, dev, first=0):
                 udes=udes[:, idx[np.arange(B) % len(idx)]], nv=nv, nc=d.nc)
 
 
+def upload_graph(graph, stream):
+    """The instantiated graph is handed to the device before the timed region (hipGraphUpload: preparation, nothing runs),
+    so that the timed replay does not include it.  Returns the raw executable-graph handle, or None."""
+    if graph is None or os.environ.get("BENCH_GRAPH_UPLOAD", "1") == "0":
+        return None
+    import ctypes as C
+    try:
+        ex = graph.raw_cuda_graph_exec()
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipGraphUpload.argtypes = [C.c_void_p, C.c_void_p]
+        if hip.hipGraphUpload(C.c_void_p(ex), C.c_void_p(stream.cuda_stream)) != 0:
+            return None
+        torch.cuda.synchronize()
+        return ex
+    except Exception:
+        return None
+
+
+def launch_graph(graph, graph_exec, stream):
+    import ctypes as C
+    if graph_exec is not None:
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipGraphLaunch.argtypes = [C.c_void_p, C.c_void_p]
+        if hip.hipGraphLaunch(C.c_void_p(graph_exec), C.c_void_p(stream.cuda_stream)) == 0:
+            return
+    with torch.cuda.stream(stream):
+        graph.replay()
+
+
 def bench_qp(args, grp, dev):
     """asif_hip_qp_solve_batch on one shape: the QPWrapperAbstract path (initialize + solve + getSolution, cold start)
     for a batch of pre-assembled problems resident in HBM.  Algorithmic bytes per instance:
@@ -318,7 +347,8 @@ def bench_qp(args, grp, dev):
         arr = (C.c_uint8 * nc)(*[int(v) for v in q["be"]])
         bep = C.cast(arr, C.c_void_p)
     lib = capi.load()
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream(device=dev)  # a side stream: its launches can be captured into a graph
+    stream.wait_stream(torch.cuda.current_stream())
     ptr = lambda t: C.c_void_p(t.data_ptr())
     call = (dev.index, C.byref(solver), C.c_int64(B), C.c_int64(q["c"].stride(0)), nv, nc, ptr(q["Hd"]), ptr(q["c"]),
             ptr(q["A"]), ptr(q["b"]), ptr(q["lb"]), ptr(q["ub"]), bep, ptr(sol), ptr(status), ptr(iters),
@@ -331,6 +361,22 @@ def bench_qp(args, grp, dev):
 
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    # --graph (see --help): the 2 x 4 shape's step is bound by the host's launch rate like the explicit filter's
+    if args.graph < 0:
+        args.graph = 1 if args.shape == "c2" and args.lanes != 64 else 0
+    graph = None
+    if args.graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                for _ in range(args.steps):
+                    step()
+        except Exception as e:
+            print(f"bench.py: graph capture failed ({e}); direct launches", file=sys.stderr)
+            graph = None
+        torch.cuda.synchronize()
+    graph_exec = upload_graph(graph, stream)
     grp.barrier()
     hip = C.CDLL("libamdhip64.so")
     hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
@@ -341,8 +387,11 @@ def bench_qp(args, grp, dev):
     sptr = C.c_void_p(stream.cuda_stream)
     t0 = time.perf_counter()
     hip.hipEventRecord(ev[0], sptr)
-    for _ in range(args.steps):
-        step()
+    if graph is not None:
+        launch_graph(graph, graph_exec, stream)
+    else:
+        for _ in range(args.steps):
+            step()
     hip.hipEventRecord(ev[1], sptr)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -364,6 +413,8 @@ def bench_qp(args, grp, dev):
            "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"pre-assembled QPs of {WORKLOAD[cfg]}: nv={nv} nc={nc}", "batch_per_gpu": B,
+                      "launch": (f"one HIP graph of {args.steps} launches, replayed once" if graph is not None
+                                 else f"{args.steps} direct launches"),
                       "kernel": kernel, "solver": {"polish": solver.polish, "iterations_mean": float(it.mean()),
                                                    "iterations_max": int(it.max())},
                       "status_histogram": {str(int(k)): int(v) for k, v in zip(*np.unique(st, return_counts=True))}},
@@ -422,11 +473,13 @@ def main():
                          "once before the first iteration")
     ap.add_argument("--presolve", type=int, default=0,
                     help="asif_hip_solver.presolve (config 2: closed-form clip instead of the in-kernel ADMM; default 0)")
-    ap.add_argument("--graph", type=int, default=0,
-                    help="0 (default): K direct launches; 1: the K timed launches are captured into one HIP graph and replayed "
-                         "once (a filter call only enqueues kernels, INTEGRATION.md 2).  Measured on MI355X / ROCm 7.2: a "
-                         "graph of kernel nodes runs each 6.7 us C2 step in 7.7 us (node-to-node dependency), direct "
-                         "launches keep the queue full at 6.7 us -- so direct launches are the default")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="1: the K timed launches are captured into one HIP graph (before the timed region) and replayed once "
+                         "inside it -- same K launches, same arguments, same stream order (a filter call only enqueues "
+                         "kernels, INTEGRATION.md 2); 0: K direct launches; -1 (default): 1 for the explicit filter (config 2 "
+                         "and 11), whose step is bound by the HOST's launch rate (a launch costs the host 2.8-3.6 us, the "
+                         "kernel runs in about 2: measured 3.3 us per step direct, 2.2 us replayed), 0 elsewhere (kernels "
+                         "of 10 us and more keep the queue full with direct launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
     args = ap.parse_args()
@@ -501,6 +554,8 @@ def main():
     # --graph 1: the K timed steps as ONE HIP graph of K filter launches.  Same K launches, same arguments, same
     # stream order.  Off by default: measured slower than direct launches for the short kernels (see --help).
     graph = None
+    if args.graph < 0:
+        args.graph = 1 if args.config in ("2", "11") else 0
     if args.graph:
         try:
             graph = torch.cuda.CUDAGraph()
@@ -511,6 +566,7 @@ def main():
             print(f"bench.py: graph capture failed ({e}); direct launches", file=sys.stderr)
             graph = None
         torch.cuda.synchronize()
+    graph_exec = upload_graph(graph, stream)
     grp.barrier()
     # device duration of the K steps from HIP events on the launch stream
     # (raw hipEvent* through ctypes: a torch.cuda.Event.record costs more host time than this kernel runs)
@@ -529,8 +585,7 @@ def main():
     t0 = time.perf_counter()
     hip.hipEventRecord(ev[0], sptr)
     if graph is not None:
-        with torch.cuda.stream(stream):
-            graph.replay()
+        launch_graph(graph, graph_exec, stream)
     else:
         for k in range(args.steps):
             step()
