@@ -18,10 +18,6 @@ struct asif_hip_ctx {
 	asif_hip_solver solver;
 	asif_hip_dims dims;
 	DevOptions dev;
-	// the same options in device memory: short kernels take them by pointer -- a launch whose argument block carries the
-	// 2 KB structure by value costs the host 1.2 us more (tools/scratch/launch_cost.hip), and the explicit filter's
-	// step is bound by the host's launch rate
-	DevOptions *d_dev;
 	// staging for the host-buffer convenience entry
 	double *d_in, *d_out;
 	int32_t *d_rc;
@@ -352,17 +348,6 @@ extern "C" int asif_hip_create(asif_hip_ctx **out, int model, int variant, const
 	if (r != ASIF_HIP_OK) {
 		delete c;
 		return r;
-	}
-	c->d_dev = nullptr;
-	if (variant == ASIF_HIP_EXPLICIT) {
-		hipError_t e = hipSetDevice(device);
-		if (e == hipSuccess) e = hipMalloc((void **)&c->d_dev, sizeof(DevOptions));
-		if (e == hipSuccess) e = hipMemcpy(c->d_dev, &c->dev, sizeof(DevOptions), hipMemcpyHostToDevice);
-		if (e != hipSuccess) {
-			if (c->d_dev) (void)hipFree(c->d_dev);
-			delete c;
-			return (int)e;
-		}
 	}
 	c->d_in = c->d_out = nullptr;
 	c->d_rc = nullptr;
@@ -793,10 +778,6 @@ extern "C" int asif_hip_destroy(asif_hip_ctx *ctx)
 		(void)hipSetDevice(ctx->device);
 		(void)hipFree(ctx->s_ckpt);
 	}
-	if (ctx->d_dev) {
-		(void)hipSetDevice(ctx->device);
-		(void)hipFree(ctx->d_dev);
-	}
 	if (ctx->d_in) {
 		(void)hipSetDevice(ctx->device);
 		(void)hipFree(ctx->d_in);
@@ -821,11 +802,6 @@ extern "C" int asif_hip_update_options(asif_hip_ctx *ctx, const asif_hip_options
 	DevOptions dev;
 	int r = model_dims(ctx->model, ctx->variant, *opts, d, dev, true);
 	if (r) return r;
-	if (ctx->d_dev) { // (calls on one handle are ordered by the caller: no launch of this handle is reading the old copy)
-		hipError_t e = hipSetDevice(ctx->device);
-		if (e == hipSuccess) e = hipMemcpy(ctx->d_dev, &dev, sizeof(DevOptions), hipMemcpyHostToDevice);
-		if (e != hipSuccess) return (int)e;
-	}
 	ctx->opts = *opts;
 	ctx->dims = d;
 	ctx->dev = dev;
@@ -893,7 +869,7 @@ static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipSt
 		return ctx->rz ? launch_realizable(ctx->rz->dev, ctx->solver, a, assemble_only, stream) : ASIF_HIP_EINVAL;
 	if (ctx->rb) return launch_robust_data(ctx->rb->dev, ctx->solver, a, assemble_only, stream);
 	if (ctx->model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR && ctx->variant == ASIF_HIP_EXPLICIT)
-		return launch_explicit_di(ctx->dev, ctx->d_dev, ctx->solver, a, assemble_only, stream);
+		return launch_explicit_di(ctx->dev, ctx->solver, a, assemble_only, stream);
 	if (ctx->model == ASIF_HIP_MODEL_PLANAR_TWO_INPUT && ctx->variant == ASIF_HIP_EXPLICIT)
 		return launch_explicit_p2(ctx->dev, ctx->solver, a, assemble_only, stream);
 	// ASIFimplicitRB, and ASIFimplicit with its learned residual switched on (src/asif_implicit.cpp:585-588):
@@ -993,7 +969,7 @@ extern "C" int asif_hip_rollout_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx,
 	if (e != hipSuccess) return (int)e;
 	if (fused) {
 		const RolloutArgs a = {B, ldx, T, dt, x, udes, uact, relax, nfail, xlog, ulog, rclog};
-		return launch_rollout_explicit_di(ctx->dev, ctx->d_dev, ctx->solver, a, (hipStream_t)stream);
+		return launch_rollout_explicit_di(ctx->dev, ctx->solver, a, (hipStream_t)stream);
 	}
 	// two-stage filters: T x (rows kernel, QP kernel, plant step) in stream order, nothing returns to the host
 	hipStream_t s = (hipStream_t)stream;

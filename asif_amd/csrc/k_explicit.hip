@@ -179,14 +179,29 @@ __global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_f
 	explicit_filter_body<M, G, PRE, SEL>(o, S, a, assemble_only);
 }
 
-// The light instantiation with its options by POINTER (the handle's device copy): its step is bound by the host's
-// launch rate, and a launch that carries the 2 KB options structure in its argument block costs the host 3.9 us
-// against 2.8 us for a small block (tools/scratch/launch_cost.hip).  The loads are scalar either way.
+// The light instantiation takes the handful of options the explicit class reads in a 56-byte block of its own: a
+// launch that carries the 2 KB DevOptions structure in its argument block costs the host 3.9 us against 2.8 us for a
+// small one (tools/scratch/launch_cost.hip) -- more than this kernel runs -- and costs a replayed graph 0.25 us per
+// node; a pointer to a device copy would cost the kernel a dependent load before its first instruction.
+struct ExplicitOpts {
+	double lb[ASIF_HIP_MAX_NU], ub[ASIF_HIP_MAX_NU], relaxCost, relaxLb;
+	int npKeep;
+};
 template <class M, bool SEL>
-__global__ __launch_bounds__(256) void explicit_light_kernel(const DevOptions *op, FilterArgs a)
+__global__ __launch_bounds__(256) void explicit_light_kernel(ExplicitOpts e, FilterArgs a)
 {
+	static_assert(M::kIgnoresOptions, "the model's functors must not read DevOptions: only the class's fields are passed");
+	DevOptions o = {};
+#pragma unroll
+	for (int j = 0; j < ASIF_HIP_MAX_NU; j++) {
+		o.lb[j] = e.lb[j];
+		o.ub[j] = e.ub[j];
+	}
+	o.relaxCost = e.relaxCost;
+	o.relaxLb = e.relaxLb;
+	o.npKeep = e.npKeep;
 	const asif_hip_solver none = {};
-	explicit_filter_body<M, 1, true, SEL>(*op, none, a, false);
+	explicit_filter_body<M, 1, true, SEL>(o, none, a, false);
 }
 
 // Closed loop, T control steps per launch (the caller's side of filter(): examples/DoubleIntegrator.cpp:81-116).
@@ -295,8 +310,7 @@ __global__ __launch_bounds__(LIGHT ? 256 : 64) void explicit_rollout_kernel(DevO
 	a.nfail[i] = nfail;
 }
 
-int launch_rollout_explicit_di(const DevOptions &o, const DevOptions *, const asif_hip_solver &S0, const RolloutArgs &a,
-                               hipStream_t stream)
+int launch_rollout_explicit_di(const DevOptions &o, const asif_hip_solver &S0, const RolloutArgs &a, hipStream_t stream)
 {
 	if (a.B <= 0 || a.T <= 0) return 0;
 	const asif_hip_solver S = resolve_scaling(S0, 1, 1);
@@ -326,8 +340,8 @@ static int launch_g(const DevOptions &o, const asif_hip_solver &S0, const Filter
 	return (int)hipGetLastError();
 }
 
-int launch_explicit_di(const DevOptions &o, const DevOptions *d_o, const asif_hip_solver &S, const FilterArgs &a,
-                       bool assemble_only, hipStream_t stream)
+int launch_explicit_di(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+                       hipStream_t stream)
 {
 	if (a.B <= 0) return 0;
 	// default solver mode (dual active-set stage first) or presolve: that stage alone decides every instance of this
@@ -335,20 +349,20 @@ int launch_explicit_di(const DevOptions &o, const DevOptions *d_o, const asif_hi
 	if ((S.presolve || (S.polish == 2 && (S.lanes_per_qp == 0 || S.lanes_per_qp == 1))) && !assemble_only) {
 		const int block = 256;
 		const bool sel = o.npKeep < DoubleIntegrator::NPSS || a.lfh != nullptr;
-		if (d_o) { // options from the handle's device copy
-			if (sel)
-				hipLaunchKernelGGL((explicit_light_kernel<DoubleIntegrator, true>), dim3(grid_for(a.B, 1, block)), dim3(block),
-				                   0, stream, d_o, a);
-			else
-				hipLaunchKernelGGL((explicit_light_kernel<DoubleIntegrator, false>), dim3(grid_for(a.B, 1, block)), dim3(block),
-				                   0, stream, d_o, a);
-		} else if (sel) {
-			hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, 1, true, true>), dim3(grid_for(a.B, 1, block)),
-			                   dim3(block), 0, stream, o, S, a, false);
-		} else {
-			hipLaunchKernelGGL((explicit_filter_kernel<DoubleIntegrator, 1, true, false>), dim3(grid_for(a.B, 1, block)),
-			                   dim3(block), 0, stream, o, S, a, false);
+		ExplicitOpts e;
+		for (int j = 0; j < ASIF_HIP_MAX_NU; j++) {
+			e.lb[j] = o.lb[j];
+			e.ub[j] = o.ub[j];
 		}
+		e.relaxCost = o.relaxCost;
+		e.relaxLb = o.relaxLb;
+		e.npKeep = o.npKeep;
+		if (sel)
+			hipLaunchKernelGGL((explicit_light_kernel<DoubleIntegrator, true>), dim3(grid_for(a.B, 1, block)), dim3(block), 0,
+			                   stream, e, a);
+		else
+			hipLaunchKernelGGL((explicit_light_kernel<DoubleIntegrator, false>), dim3(grid_for(a.B, 1, block)), dim3(block), 0,
+			                   stream, e, a);
 		return (int)hipGetLastError();
 	}
 	switch (S.lanes_per_qp) {

@@ -24,7 +24,7 @@ struct FilterArgs {
 };
 
 // explicit CBF filter (class ASIF), model = DoubleIntegrator / PlanarTwoInput
-int launch_explicit_di(const DevOptions &o, const DevOptions *d_o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+int launch_explicit_di(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                        hipStream_t stream);
 int launch_explicit_p2(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                        hipStream_t stream);
@@ -43,8 +43,7 @@ struct RolloutArgs {
 	double *ulog;       // [T][nu][ld] input applied after each filter call, or nullptr
 	int32_t *rclog;     // [T][ld], or nullptr
 };
-int launch_rollout_explicit_di(const DevOptions &o, const DevOptions *d_o, const asif_hip_solver &S, const RolloutArgs &a,
-                               hipStream_t stream);
+int launch_rollout_explicit_di(const DevOptions &o, const asif_hip_solver &S, const RolloutArgs &a, hipStream_t stream);
 // plant Euler step x += dt (f(x) + g(x) uact) between two filter calls of the two-stage filters (k_rollout.hip);
 // logs the state / input / rc of the call just made (nullptr to skip) and counts rc < 0 into nfail
 int launch_plant_step(int model, const DevOptions &o, int64_t B, int64_t ld, double dt, double *x, const double *uact,

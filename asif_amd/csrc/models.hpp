@@ -191,6 +191,7 @@ __device__ __forceinline__ void sincos_fast(double x, double &s, double &c)
 // ---------------------------------------------------------------------------------------------
 // Double integrator, examples/DoubleIntegrator.cpp:12-61.  x = (position, velocity).
 struct DoubleIntegrator {
+	static constexpr bool kIgnoresOptions = true; // no functor below reads DevOptions (k_explicit.hip: explicit_light_kernel)
 	static constexpr int NX = 2, NU = 1, NPSS = 4;
 
 	// :24-38  safe box |x|<=1, |v|<=1 with the braking parabola on the side the velocity points to
