@@ -545,22 +545,27 @@ struct AdmmSmall {
 		stat_farkas = 0;
 #pragma unroll
 		for (int j = 0; j < NV; j++) xout[j] = 0.0;
+		// non-finite data (a NaN / inf state): the reference's solver never converges on it and returns max_iter
+		// (qp_lane.hpp: qp_data_nonfinite); latched here for every solver mode, the iterations skip a latched lane
+		const bool nonfinite = qp_data_nonfinite<NV, RPL, G>(in.Hd, in.c, in.lb, in.ub, in.A, in.b);
+		if (nonfinite) status = kStatusMaxIter;
 		if constexpr (NV <= 3) {
 			if (finish_first && S_.polish != 0) {
 				double xg[NV];
 				int gsteps;
-				const int v = GiSmall<NV, RPL, G>::solve(in, (int)(threadIdx.x % G), 8 * NV + 4, xg, gsteps);
+				const int v = GiSmall<NV, RPL, G>::solve_unchecked(in, (int)(threadIdx.x % G), 8 * NV + 4, xg, gsteps);
 				stat_rounds = gsteps;
-				if (v == kGiOptimal) {
+				if (nonfinite) {
+				} else if (v == kGiOptimal) {
 					status = kStatusSolved;
 #pragma unroll
 					for (int j = 0; j < NV; j++) xout[j] = xg[j];
 				} else if (v == kGiInfeasible) {
 					status = kStatusPrimalInf;
 				}
-				if (__all(status != 0)) return; // the usual case: nothing left for the iterations
 			}
 		}
+		if (__all(status != 0)) return; // the usual case: nothing left for the iterations
 		load_and_scale(in, S_.scaling_iters);
 #pragma unroll
 		for (int j = 0; j < NV; j++) { x[j] = 0.0; zb[j] = 0.0; yb[j] = 0.0; dyb[j] = 0.0; dx[j] = 0.0; }

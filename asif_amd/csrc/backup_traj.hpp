@@ -269,12 +269,19 @@ struct Dopri5 {
 	double t, tOld, dt;
 	double z[NZ], zOld[NZ];
 	double k1[NZ], k3[NZ], k4[NZ], k5[NZ], k6[NZ], k7[NZ]; // of the last accepted step; k7 = f(z) (first same as last)
+	// odeint throws after 500 failed attempts of one step, and a NaN error estimate (dropped by the max) never recovers;
+	// the reference has no handler.  Here such a lane stops stepping and every later sample of it is NaN: non-finite
+	// rows, filter() fails like a failed solve (oracle/or_assembly.c: dopri5_t::failed, same rule).
+	bool failed;
+	int rejects;
 
 	__device__ __forceinline__ void init(const DevOptions &o, const double (&z0)[NZ], double dt0)
 	{
 		t = 0.0;
 		tOld = 0.0;
 		dt = dt0;
+		failed = false;
+		rejects = 0;
 #pragma unroll
 		for (int i = 0; i < NZ; i++) {
 			z[i] = z0[i];
@@ -320,6 +327,7 @@ struct Dopri5 {
 			BackupLoop<M>::rhs(o, zn, n7);
 		}
 		double err = 0.0;
+		bool nan = false;
 		{
 #pragma clang fp contract(off)
 #pragma unroll
@@ -327,10 +335,14 @@ struct Dopri5 {
 				const double xe = h * (dc1 * k7[i] + dc3 * n3[i] + dc4 * n4[i] + dc5 * n5[i] + dc6 * n6[i] + dc7 * n7[i]);
 				const double e = fabs(xe) / (o.trajAbsTol + o.trajRelTol * (fabs(z[i]) + fabs(h) * fabs(k7[i])));
 				err = fmax(err, e);
+				nan = nan | (e != e);
 			}
 		}
-		const bool reject = need && err > 1.0;
-		const bool accept = need && !(err > 1.0);
+		need = need & !failed;
+		const bool reject = need && !nan && err > 1.0;
+		const bool accept = need && !nan && !(err > 1.0);
+		rejects = reject ? rejects + 1 : (accept ? 0 : rejects);
+		failed = failed | (need & nan) | (rejects >= 500);
 		const double shrink = fmax(0.9 * pow(err, -1.0 / 3.0), 0.2);
 		const double grow = 0.9 * pow(fmax(err, 1.0 / 3125.0), -1.0 / 5.0);
 		dt = reject ? h * shrink : ((accept && err < 0.5) ? h * grow : dt);
@@ -349,6 +361,8 @@ struct Dopri5 {
 		}
 	}
 
+	// this lane still has to step to reach sample time ts (n_step_iterator's less_with_sign: by more than epsilon)
+	__device__ __forceinline__ bool behind(double ts) const { return !failed & (ts - t > 2.220446049250313e-16); }
 	// continuous extension on the last step [tOld, t] (odeint runge_kutta_dopri5::calc_state)
 	__device__ __forceinline__ void dense(double ts, double (&out)[NZ]) const
 	{
@@ -370,7 +384,7 @@ struct Dopri5 {
 #pragma unroll
 		for (int i = 0; i < NZ; i++) {
 			const double v = zOld[i] + h * (bt1 * k1[i] + bt3 * k3[i] + bt4 * k4[i] + bt5 * k5[i] + bt6 * k6[i] + bt7 * k7[i]);
-			out[i] = moved ? v : z[i];
+			out[i] = failed ? __builtin_nan("") : (moved ? v : z[i]);
 		}
 	}
 };

@@ -3,6 +3,7 @@
 // of the reference classes), kernel dispatch.  There is no CPU compute path behind any entry point.
 #include "asif_hip.h"
 #include "launchers.hpp"
+#include "multi_own.hpp"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1157,44 +1158,34 @@ extern "C" int asif_hip_multi_destroy(asif_hip_multi *m)
 	return ASIF_HIP_OK;
 }
 
-// adopts the handles (one per entry of the device list; a device may appear more than once)
-static int multi_adopt(asif_hip_multi **out, std::vector<asif_hip_ctx *> &hs)
-{
-	asif_hip_multi *m = new (std::nothrow) asif_hip_multi();
-	if (!m) return ASIF_HIP_EINVAL;
-	m->h = hs;
-	m->s.assign(hs.size(), nullptr);
-	for (size_t i = 0; i < hs.size(); i++) {
-		hipError_t e = hipSetDevice(hs[i]->device);
-		if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->s[i], hipStreamNonBlocking);
-		if (e != hipSuccess) {
-			asif_hip_multi_destroy(m);
-			return (int)e;
-		}
-	}
-	*out = m;
-	return ASIF_HIP_OK;
-}
-
 extern "C" int asif_hip_create_multi(asif_hip_multi **out, int model, int variant, const asif_hip_options *opts,
                                      const asif_hip_solver *solver, int32_t ndev, const int32_t *devs)
 {
 	if (!out || ndev < 1 || !devs) return ASIF_HIP_EINVAL;
 	*out = nullptr;
-	std::vector<asif_hip_ctx *> hs;
-	for (int i = 0; i < ndev; i++) {
-		asif_hip_ctx *c = nullptr;
-		const int r = asif_hip_create(&c, model, variant, opts, solver, devs[i]);
-		if (r) {
-			for (asif_hip_ctx *h : hs) asif_hip_destroy(h);
-			return r;
-		}
-		hs.push_back(c);
+	asif_hip_multi *m = new (std::nothrow) asif_hip_multi();
+	if (!m) return ASIF_HIP_EINVAL;
+	// one handle per entry of the device list (a device may appear more than once), then one stream per handle;
+	// ownership on failure: multi_own.hpp (every handle and stream released exactly once, by this function)
+	const int r = create_all(
+	    ndev, m->h, m->s,
+	    [&](int i, asif_hip_ctx **c) { return asif_hip_create(c, model, variant, opts, solver, devs[i]); },
+	    [](asif_hip_ctx *c) { asif_hip_destroy(c); },
+	    [](asif_hip_ctx *c, hipStream_t *s) {
+		    hipError_t e = hipSetDevice(c->device);
+		    if (e == hipSuccess) e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+		    return (int)e;
+	    },
+	    [](asif_hip_ctx *c, hipStream_t s) {
+		    (void)hipSetDevice(c->device);
+		    (void)hipStreamDestroy(s);
+	    });
+	if (r) {
+		delete m;
+		return r;
 	}
-	const int r = multi_adopt(out, hs);
-	if (r)
-		for (asif_hip_ctx *h : hs) asif_hip_destroy(h);
-	return r;
+	*out = m;
+	return ASIF_HIP_OK;
 }
 
 extern "C" int asif_hip_multi_size(const asif_hip_multi *m) { return m ? (int)m->h.size() : 0; }

@@ -34,6 +34,7 @@ namespace asif {
 constexpr int kGiOptimal = 1;
 constexpr int kGiInfeasible = 2;
 constexpr int kGiUndecided = 0;
+constexpr int kGiFailed = 3; // non-finite problem data: the reference's solver runs such a problem to max_iter
 
 template <int NV, int RPL, int G>
 struct GiSmall {
@@ -56,6 +57,13 @@ struct GiSmall {
 	template <int J>
 	ASIF_HD static int solve_with_pinned(const QpLaneData<NV, RPL> &in, int g, int max_steps, double (&x)[NV], int &steps)
 	{
+		const bool nonfinite = qp_data_nonfinite<NV, RPL, G>(in.Hd, in.c, in.lb, in.ub, in.A, in.b);
+		const int verdict = pinned_unchecked<J>(in, g, max_steps, x, steps);
+		return nonfinite ? kGiFailed : verdict;
+	}
+	template <int J>
+	ASIF_HD static int pinned_unchecked(const QpLaneData<NV, RPL> &in, int g, int max_steps, double (&x)[NV], int &steps)
+	{
 		static_assert(NV >= 2 && J >= 0 && J < NV, "a variable to eliminate and one to keep");
 		QpLaneData<NV - 1, RPL> red;
 		const double pin = in.lb[J];
@@ -75,14 +83,22 @@ struct GiSmall {
 			red.ub[j] = in.ub[jj];
 		}
 		double xr[NV - 1];
-		const int verdict = GiSmall<NV - 1, RPL, G>::solve(red, g, max_steps, xr, steps);
+		const int verdict = GiSmall<NV - 1, RPL, G>::solve_unchecked(red, g, max_steps, xr, steps);
 #pragma unroll
 		for (int j = 0; j < NV - 1; j++) x[j < J ? j : j + 1] = xr[j];
 		x[J] = pin;
 		return verdict;
 	}
 
+	// Entry.  Non-finite data is asked for once, on the whole problem, and overrides whatever the comparisons below made
+	// of it (they read a NaN row as met); selects, not an early return: the method holds group and wave reductions.
 	ASIF_HD static int solve(const QpLaneData<NV, RPL> &in, int g, int max_steps, double (&x)[NV], int &steps)
+	{
+		const bool nonfinite = qp_data_nonfinite<NV, RPL, G>(in.Hd, in.c, in.lb, in.ub, in.A, in.b);
+		const int verdict = solve_unchecked(in, g, max_steps, x, steps);
+		return nonfinite ? kGiFailed : verdict;
+	}
+	ASIF_HD static int solve_unchecked(const QpLaneData<NV, RPL> &in, int g, int max_steps, double (&x)[NV], int &steps)
 	{
 		if constexpr (NV >= 2) {
 			bool pinned[NV];
@@ -92,7 +108,7 @@ struct GiSmall {
 			unrolled_until<NV>([&](auto jc) {
 				constexpr int J = NV - 1 - decltype(jc)::value; // last variable first: the relaxation variables sit at the end
 				if (!pinned[J]) return false;
-				verdict = solve_with_pinned<J>(in, g, max_steps, x, steps);
+				verdict = pinned_unchecked<J>(in, g, max_steps, x, steps);
 				return true;
 			});
 			if (verdict >= 0) return verdict;

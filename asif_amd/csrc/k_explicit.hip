@@ -3,7 +3,9 @@
 // One launch does, per instance: safetySet + dynamics (model functors), Lfh = Dh f, Lgh = Dh g
 // (src/asif.cpp:279-284), rows A = [Lgh | h], b = -Lfh (:295-303), the QP
 //   min (u-uDes)'(u-uDes) + relaxCost (delta-relaxLb)^2   s.t. rows, lb<=u<=ub, delta pinned (:84-98)
-// solved by the in-register ADMM, then inputSaturate (:343-352) and the return code (:199-209).
+// solved in registers (dual active-set stage of gi_small.hpp, which decides this class's one-variable problem on its
+// own; admm_small.hpp's iterations for the other solver modes), then inputSaturate (:343-352) and the return code
+// (:199-209).
 // HBM traffic is the algorithmic minimum: 8(nx+nu) bytes in, 8(nu+1)+4 bytes out per instance, SoA,
 // consecutive lanes -> consecutive instances (G = 1) so every load/store is a fully coalesced line.
 #include <type_traits>
@@ -253,6 +255,18 @@ __global__ __launch_bounds__(LIGHT ? 256 : 64) void explicit_rollout_kernel(DevO
 			qp.A[r][NU] = h[r];
 			qp.b[r] = -s;
 			qp.eq[r] = false;
+		}
+		if (o.npKeep < NP) { // wave-uniform; npSSmax < npSS (src/asif.cpp:250-268): rows beyond the npKeep smallest h are inert
+#pragma unroll
+			for (int r = 0; r < NP; r++) {
+				int p = 0;
+#pragma unroll
+				for (int q = 0; q < NP; q++) p += (h[q] < h[r] || (h[q] == h[r] && q < r)) ? 1 : 0;
+				const bool kept = p < o.npKeep;
+#pragma unroll
+				for (int j = 0; j < NV; j++) qp.A[r][j] = kept ? qp.A[r][j] : 0.0;
+				qp.b[r] = kept ? qp.b[r] : -1e20;
+			}
 		}
 #pragma unroll
 		for (int j = 0; j < NU; j++) {

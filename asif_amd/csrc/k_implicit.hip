@@ -110,10 +110,11 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 		for (int s = 0; s < o.npBT; s++) {
 			const double ts = o.trajDt * (double)s; // backTraj_[i].first, :451
 			// n_step_iterator: step while t < ts (less_with_sign: by more than epsilon), then interpolate
-			while (guard > 0 && __any(ts - rk.t > 2.220446049250313e-16)) {
-				rk.tryStep(o, ts - rk.t > 2.220446049250313e-16);
+			while (guard > 0 && __any(rk.behind(ts))) {
+				rk.tryStep(o, rk.behind(ts));
 				guard--;
 			}
+			rk.failed = rk.failed | rk.behind(ts); // the wave's budget ran out with this lane still short of ts
 			double zs[NZ], xs[NX];
 			rk.dense(ts, zs);
 #pragma unroll

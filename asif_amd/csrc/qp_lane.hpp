@@ -107,6 +107,32 @@ ASIF_HD int gmin_int(int p)
 	if (G >= 16) { const int o = dpp_xchg<8>(p); p = o < p ? o : p; }
 	return p;
 }
+// Non-finite problem data, one verdict per lane group.  A NaN or infinite state reaches the rows through h, Lfh, Lgh;
+// OSQP takes such data as it is and never converges on it (every residual comparison is false on NaN): it runs to
+// max_iter and QPWrapperOsqp::solve returns that raw status (src/qpwrapper_osqp.cpp:225-238).  The comparisons of the
+// solvers here would read a NaN row as "not violated", so they ask first.  0 * v is NaN exactly when v is NaN or
+// infinite: one fused multiply-add per entry, one test at the end.  Bounds may be infinite (one-sided), not NaN.
+template <int NV, int RPL, int G>
+ASIF_HD bool qp_data_nonfinite(const double (&Hd)[NV], const double (&c)[NV], const double (&lb)[NV], const double (&ub)[NV],
+                               const double (&A)[RPL][NV], const double (&b)[RPL])
+{
+	double s = 0.0;
+	int bad = 0;
+#pragma unroll
+	for (int j = 0; j < NV; j++) {
+		s = fma(Hd[j], 0.0, s);
+		s = fma(c[j], 0.0, s);
+		bad |= ((lb[j] != lb[j]) | (ub[j] != ub[j])) ? 1 : 0;
+	}
+#pragma unroll
+	for (int k = 0; k < RPL; k++) {
+#pragma unroll
+		for (int j = 0; j < NV; j++) s = fma(A[k][j], 0.0, s);
+		s = fma(b[k], 0.0, s);
+	}
+	bad |= (s != s) ? 1 : 0;
+	return gor<G>(bad) != 0;
+}
 // compile-time loop with early exit: f(integral_constant<int, I>) for I = 0 .. N-1 until one returns true
 template <int N, int I = 0, class F>
 ASIF_HD bool unrolled_until(F &&f)

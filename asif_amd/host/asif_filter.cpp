@@ -15,7 +15,7 @@ ASIF::ASIF(const uint32_t nx, const uint32_t nu, const uint32_t npSS, SafetySetF
     : nx_(nx), nu_(nu), nv_(nu + 1), npSS_(npSS), npSSmax_(std::min(npSSmax, npSS)), nc_(npSSmax_),
       safetySet_(safetySet), dynamics_(dynamics), options_(), QPsolver_(nullptr), H_(nv_ * nv_, 0.0), c_(nv_, 0.0),
       A_(nc_ * nv_, 0.0), b_(nc_, 0.0), lb_(nv_, 0.0), ub_(nv_, 0.0), LfhUser_(nullptr), LghUser_(nullptr),
-      batch_(nullptr)
+      batch_(nullptr), boundModel_(-1)
 {
 	(void)qpSolverType; // one solver in this build: the in-kernel ADMM
 	QPsolver_ = new QPWrapperHip(nv_, nc_, diagonalCost);
@@ -118,18 +118,8 @@ int32_t ASIF::updateOptions(void)
 	QPsolver_->updateCost(H_.data(), c_.data());
 	if (batch_) {
 		asif_hip_options o;
-		asif_hip_default_options(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR, ASIF_HIP_EXPLICIT, &o);
-		o.relaxCost = options_.relaxCost;
-		o.relaxLb = options_.relaxLb;
-		o.inf = options_.inf;
-		o.satSharpness = options_.satSharpness;
-	o.npSSmax = (int32_t)npSSmax_; // the device keeps the same rows per call (src/asif.cpp:250-268)
-		o.npSSmax = (int32_t)npSSmax_;
-		for (uint32_t j = 0; j < nu_ && j < ASIF_HIP_MAX_NU; j++) {
-			o.lb[j] = lb_[j];
-			o.ub[j] = ub_[j];
-		}
-		asif_hip_multi_update_options(batch_, &o);
+		if (int r = deviceOptions(boundModel_, &o)) return r;
+		if (int r = asif_hip_multi_update_options(batch_, &o)) return r;
 	}
 	return 1;
 }
@@ -191,16 +181,8 @@ int32_t ASIF::bindDeviceModel(int model, int32_t ndev, const int32_t devs[])
 		batch_ = nullptr;
 	}
 	asif_hip_options o;
-	int r = asif_hip_default_options(model, ASIF_HIP_EXPLICIT, &o);
+	int r = deviceOptions(model, &o);
 	if (r) return r;
-	o.relaxCost = options_.relaxCost;
-	o.relaxLb = options_.relaxLb;
-	o.inf = options_.inf;
-	o.satSharpness = options_.satSharpness;
-	for (uint32_t j = 0; j < nu_ && j < ASIF_HIP_MAX_NU; j++) {
-		o.lb[j] = lb_[j];
-		o.ub[j] = ub_[j];
-	}
 	r = asif_hip_create_multi(&batch_, model, ASIF_HIP_EXPLICIT, &o, nullptr, ndev, devs);
 	if (r) return r;
 	asif_hip_dims d;
@@ -209,6 +191,26 @@ int32_t ASIF::bindDeviceModel(int model, int32_t ndev, const int32_t devs[])
 		asif_hip_multi_destroy(batch_);
 		batch_ = nullptr;
 		return ASIF_HIP_EINVAL;
+	}
+	boundModel_ = model;
+	return 0;
+}
+
+// the device-side options of THIS object for a compiled model: the class's options, its input bounds and its row
+// budget (npSSmax: the device keeps the same rows per call, src/asif.cpp:250-268); used when binding and whenever
+// updateOptions() runs afterwards, so both describe the same filter
+int32_t ASIF::deviceOptions(int model, asif_hip_options *o) const
+{
+	const int r = asif_hip_default_options(model, ASIF_HIP_EXPLICIT, o);
+	if (r) return r;
+	o->relaxCost = options_.relaxCost;
+	o->relaxLb = options_.relaxLb;
+	o->inf = options_.inf;
+	o->satSharpness = options_.satSharpness;
+	o->npSSmax = (int32_t)npSSmax_;
+	for (uint32_t j = 0; j < nu_ && j < ASIF_HIP_MAX_NU; j++) {
+		o->lb[j] = lb_[j];
+		o->ub[j] = ub_[j];
 	}
 	return 0;
 }

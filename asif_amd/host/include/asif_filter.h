@@ -56,6 +56,7 @@ protected:
 	int32_t updateCost(const double uDes[]);
 	int32_t updateH(const double H[]);
 	void inputSaturate(double u[]);
+	int32_t deviceOptions(int asif_hip_model_id, asif_hip_options *o) const;
 
 	const uint32_t nx_, nu_, nv_, npSS_, npSSmax_, nc_;
 	SafetySetFn safetySet_;
@@ -65,6 +66,7 @@ protected:
 	std::vector<double> H_, c_, A_, b_, lb_, ub_;
 	const double *LfhUser_, *LghUser_; // caller-owned overrides, retained like the reference (src/asif.cpp:137-139)
 	asif_hip_multi *batch_;
+	int boundModel_; // the compiled model filterBatch() runs, -1 before bindDeviceModel
 };
 
 } // namespace ASIF

@@ -351,6 +351,9 @@ typedef struct {
 	double z[OR_MAX_NX + OR_MAX_NX * OR_MAX_NX], z_old[OR_MAX_NX + OR_MAX_NX * OR_MAX_NX];
 	double k[7][OR_MAX_NX + OR_MAX_NX * OR_MAX_NX]; /* stage derivatives of the LAST accepted step; k[6] = f(z) (FSAL) */
 	double dz[OR_MAX_NX + OR_MAX_NX * OR_MAX_NX];   /* derivative at z */
+	int failed; /* odeint throws (500 failed attempts of one step; and a NaN error estimate never recovers): the
+	             * reference has no handler, so the process ends.  Here: every later sample is NaN, the rows are
+	             * non-finite and filter() fails like a failed solve (rc -1, backup controller). */
 } dopri5_t;
 
 static void dopri5_init(dopri5_t *d, const or_model *m, const or_options *o, const double *z0, int nz, double dt)
@@ -364,7 +367,7 @@ static void dopri5_init(dopri5_t *d, const or_model *m, const or_options *o, con
 	ode_rhs(m, o, d->z, d->dz, 0, 0.0);
 }
 
-/* one accepted step (retries inside) */
+/* one accepted step (retries inside); sets d->failed instead when odeint would have thrown */
 static void dopri5_step(dopri5_t *d, const or_model *m, const or_options *o)
 {
 	static const double a21 = 1.0 / 5, a31 = 3.0 / 40, a32 = 9.0 / 40, a41 = 44.0 / 45, a42 = -56.0 / 15, a43 = 32.0 / 9,
@@ -399,7 +402,9 @@ static void dopri5_step(dopri5_t *d, const or_model *m, const or_options *o)
 			const double xe = h * (dc1 * k[0][i] + dc3 * k[2][i] + dc4 * k[3][i] + dc5 * k[4][i] + dc6 * k[5][i] + dc7 * k[6][i]);
 			const double e = fabs(xe) / (o->backTrajAbsTol + o->backTrajRelTol * (fabs(d->z[i]) + fabs(h) * fabs(d->dz[i])));
 			if (e > err) err = e;
+			if (e != e) d->failed = 1; /* a NaN error estimate: max() drops it and the step would be accepted */
 		}
+		if (d->failed) return;
 		if (err > 1.0) {
 			double fac = 0.9 * pow(err, -1.0 / 3.0);
 			if (fac < 0.2) fac = 0.2;
@@ -419,13 +424,18 @@ static void dopri5_step(dopri5_t *d, const or_model *m, const or_options *o)
 		}
 		return;
 	}
+	d->failed = 1; /* odeint's failed_step_checker: 500 consecutive rejections */
 }
 
 /* state at time ts >= the last sample: step while t < ts - eps, then the continuous extension on [t_old, t] */
 static void dopri5_sample(dopri5_t *d, const or_model *m, const or_options *o, double ts, double *out)
 {
-	while (ts - d->t > 2.220446049250313e-16) dopri5_step(d, m, o);
+	while (!d->failed && ts - d->t > 2.220446049250313e-16) dopri5_step(d, m, o);
 	const int n = d->nz;
+	if (d->failed) {
+		for (int i = 0; i < n; i++) out[i] = NAN;
+		return;
+	}
 	const double b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784, b6 = 11.0 / 84;
 	const double h = d->t - d->t_old;
 	if (!(h > 0.0)) { /* before any step: ts == 0 */

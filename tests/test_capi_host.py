@@ -102,3 +102,30 @@ def test_multi_create_without_gpu_fails_loudly(capi):
         pytest.skip("GPU present")
     with pytest.raises(capi.AsifHipError):
         capi.MultiFilter(capi.MODEL_DOUBLE_INTEGRATOR, capi.EXPLICIT, [0, 1])
+
+
+def test_create_multi_releases_everything_exactly_once(tmp_path):
+    """asif_hip_create_multi's ownership rules (asif_amd/csrc/multi_own.hpp) on counting stand-ins: whichever step
+    fails -- the k-th handle, or the k-th stream after every handle exists -- each handle and stream made so far is
+    released once and only once (round 2 destroyed the handles twice when a stream could not be created)."""
+    import subprocess
+    so = str(tmp_path / "libmulti_own.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "asif_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host_multi_own_driver.cpp"), "-o", so])
+    lib = C.CDLL(so)
+    n = 4
+    for fail_create, fail_stream in [(-1, -1)] + [(k, -1) for k in range(n)] + [(-1, k) for k in range(n)]:
+        destroyed = (C.c_int32 * n)()
+        unmade = (C.c_int32 * n)()
+        lh, ls = C.c_int32(), C.c_int32()
+        r = lib.multi_own_scenario(n, fail_create, fail_stream, destroyed, unmade, C.byref(lh), C.byref(ls))
+        if fail_create < 0 and fail_stream < 0:
+            assert r == 0 and lh.value == n and ls.value == n
+            assert list(destroyed) == [0] * n and list(unmade) == [0] * n
+            continue
+        assert r == (77 if fail_create >= 0 else 88)
+        assert lh.value == 0 and ls.value == 0
+        made_h = fail_create if fail_create >= 0 else n
+        made_s = fail_stream if fail_stream >= 0 else 0
+        assert list(destroyed) == [1] * made_h + [0] * (n - made_h)
+        assert list(unmade) == [1] * made_s + [0] * (n - made_s)

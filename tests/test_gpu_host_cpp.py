@@ -242,3 +242,33 @@ def test_qpwrapper_hip_contract(hip, tmp_path):
     # synchronisation -- no staging copies (the value itself is printed for the record, not asserted tightly)
     assert r["latency_us"][0] == 1 and r["latency_us"][1] < 500.0
     print("QPWrapperHip latency per solve [us]:", r["latency_us"][1])
+
+
+def test_explicit_class_two_input_model_and_reduced_row_budget(hip, oracle):
+    """ASIF::ASIF bound to a model other than the double integrator (two inputs) and with npSSmax = 2 of 4 rows:
+    filterBatch() (fused kernel of the bound model) equals filter() (host rows + QPWrapperHip) before and after
+    updateOptions() -- round 2 rebuilt the device options from the double integrator's defaults whatever was bound
+    and never passed npSSmax at bind time (EINVAL).  Both against the oracle's exact optimum as well."""
+    exe = os.path.join(HOST, "explicit_variants")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HOST, "-s"])
+    n = 96
+    out = subprocess.run([exe, str(n)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l.split(",") for l in out.stdout.strip().split("\n")[1:]]
+    seen = set()
+    for name, nu in (("planar2", 2), ("di_keep2", 1)):
+        for phase in (0, 1):
+            rows = np.array([[float(v) for v in l[2:]] for l in lines if l[0] == name and int(l[1]) == phase])
+            assert rows.shape == (n, 3 + 2 * nu + 2), (name, phase, rows.shape)
+            rc1, rcb = rows[:, 1].astype(int), rows[:, 2].astype(int)
+            u1, ub = rows[:, 3:3 + nu], rows[:, 3 + nu:3 + 2 * nu]
+            assert np.array_equal(rc1, rcb), (name, phase)
+            assert set(rc1.tolist()) <= {1, -1} and (rc1 == 1).sum() >= n // 4
+            ok = rc1 == 1
+            assert np.abs(u1[ok] - ub[ok]).max() <= 1e-6, (name, phase)
+            assert np.all(ub[~ok] == 7.0) and np.all(u1[~ok] == 7.0)  # untouched on failure, both paths
+            assert np.abs(rows[ok, -2] - rows[ok, -1]).max() <= 1e-9  # pinned relaxation variable, same value
+            assert np.abs(rows[ok, -1] - (5.0 if phase == 0 else 2.0)).max() <= 1e-9
+            seen.add((name, phase))
+    assert len(seen) == 4

@@ -72,3 +72,20 @@ def test_only_the_plain_implicit_class_has_it(hip):
     o.integrator = 1
     with pytest.raises(hip.AsifHipError):
         hip.Filter(hip.MODEL_SEGWAY, hip.IMPLICIT_TB, options=o)
+
+
+def test_failed_integration_fails_the_filter(hip, oracle):
+    """NaN / overflowing states under the adaptive integrator: the lane stops stepping (no hang), its rows are
+    non-finite and the filter returns what the oracle returns (rc -1); the neighbouring lanes are unaffected."""
+    B = 128
+    od, oo = _opts(hip, oracle, 3)
+    x, udes = gpu_util.workloads.make_batch(3, B)
+    clean = gpu_util.run_filter(3, B, options=od, x=x.copy(), udes=udes)
+    x[0, 5], x[1, 17], x[:, 40] = np.nan, np.nan, 1.7e308
+    out = gpu_util.run_filter(3, B, options=od, x=x, udes=udes, uact_init=7.0)
+    model, variant = oracle.CONFIGS[3]
+    ua, rl, rc = oracle.filter_batch(model, variant, oo, np.ascontiguousarray(x.T), np.ascontiguousarray(udes.T),
+                                     uact_init=np.full((B, 1), 7.0))
+    assert np.array_equal(out["rc"], rc) and list(rc[[5, 17, 40]]) == [-1, -1, -1]
+    keep = np.ones(B, bool); keep[[5, 17, 40]] = False
+    assert np.array_equal(out["uact"][:, keep], clean["uact"][:, keep])

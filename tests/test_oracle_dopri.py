@@ -67,3 +67,18 @@ def test_dopri5_rows_converge_with_the_tolerance(oracle):
     d1 = max(np.abs(rows[1e-5][k] - rows[1e-10][k]).max() for k in (0, 1))
     d2 = max(np.abs(rows[1e-7][k] - rows[1e-10][k]).max() for k in (0, 1))
     assert d2 < d1 and d2 <= 1e-5 and d1 <= 1e-3, (d1, d2)
+
+
+def test_dopri5_failure_ends_and_fails_the_filter(oracle):
+    """odeint throws when a step cannot be made (the reference has no handler); a NaN error estimate is dropped by the
+    controller's max() and would be ACCEPTED.  The restatement marks the trajectory failed instead: later samples are
+    NaN, the rows non-finite, and filter() fails like a failed solve (rc -1, backup controller) -- and the call ends."""
+    model, variant = oracle.MODEL_IP, oracle.VAR_IMPLICIT
+    o = oracle.default_options(model, variant)
+    o.integrator = 1
+    x = np.array([[np.nan, 0.0], [0.2, np.nan], [1.7e308, 1.7e308], [0.1, 0.0]])
+    u = np.zeros((4, 1))
+    A, b, code, _ = oracle.assemble_batch(model, variant, o, x)
+    assert not np.isfinite(b[:3]).all(axis=1).any() and np.isfinite(b[3]).all() and np.isfinite(A[3]).all()
+    ua, rl, rc = oracle.filter_batch(model, variant, o, x, u, uact_init=np.full((4, 1), 7.0))
+    assert list(rc) == [-1, -1, -1, 1]
