@@ -556,6 +556,8 @@ struct AdmmSmall {
 				const int v = GiSmall<NV, RPL, G>::solve_unchecked(in, (int)(threadIdx.x % G), 8 * NV + 4, xg, gsteps);
 				stat_rounds = gsteps;
 				if (nonfinite) {
+				} else if (v == kGiFailed) { // overflow inside the stage: nothing the iterations could do better
+					status = kStatusMaxIter;
 				} else if (v == kGiOptimal) {
 					status = kStatusSolved;
 #pragma unroll

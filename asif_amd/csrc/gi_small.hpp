@@ -82,12 +82,18 @@ struct GiSmall {
 			red.lb[j] = in.lb[jj];
 			red.ub[j] = in.ub[jj];
 		}
+		// a column entry of 1e308 times the pin overflows: the reduced right-hand side is no longer data the comparisons
+		// below can judge (inf > inf is false) -- failed, like non-finite data handed in
+		double ovf = 0.0;
+#pragma unroll
+		for (int k = 0; k < RPL; k++) ovf = fma(red.b[k], 1e160, ovf);
+		const bool overflow = gor<G>(!(fabs(ovf) < __builtin_huge_val()) ? 1 : 0) != 0;
 		double xr[NV - 1];
 		const int verdict = GiSmall<NV - 1, RPL, G>::solve_unchecked(red, g, max_steps, xr, steps);
 #pragma unroll
 		for (int j = 0; j < NV - 1; j++) x[j < J ? j : j + 1] = xr[j];
 		x[J] = pin;
-		return verdict;
+		return overflow ? kGiFailed : verdict;
 	}
 
 	// Entry.  Non-finite data is asked for once, on the whole problem, and overrides whatever the comparisons below made

@@ -107,30 +107,33 @@ ASIF_HD int gmin_int(int p)
 	if (G >= 16) { const int o = dpp_xchg<8>(p); p = o < p ? o : p; }
 	return p;
 }
-// Non-finite problem data, one verdict per lane group.  A NaN or infinite state reaches the rows through h, Lfh, Lgh;
-// OSQP takes such data as it is and never converges on it (every residual comparison is false on NaN): it runs to
-// max_iter and QPWrapperOsqp::solve returns that raw status (src/qpwrapper_osqp.cpp:225-238).  The comparisons of the
-// solvers here would read a NaN row as "not violated", so they ask first.  0 * v is NaN exactly when v is NaN or
-// infinite: one fused multiply-add per entry, one test at the end.  Bounds may be infinite (one-sided), not NaN.
+// Problem data outside the solvers' domain, one verdict per lane group: NaN, infinite, or so large (beyond ~1e148)
+// that a product of two entries overflows.  A NaN or infinite state reaches the rows through h, Lfh, Lgh; OSQP takes
+// such data as it is and never converges on it (every residual comparison is false on NaN): it runs to max_iter and
+// QPWrapperOsqp::solve returns that raw status (src/qpwrapper_osqp.cpp:225-238).  The comparisons of the solvers here
+// would read a NaN row as "not violated" (and inf > inf as false), so they ask first.  One fused multiply-add per
+// entry: v * 1e160 overflows for |v| > 1.8e148 and the running sum is then inf or NaN; one test at the end.
+// Bounds may be infinite (one-sided), not NaN.
 template <int NV, int RPL, int G>
 ASIF_HD bool qp_data_nonfinite(const double (&Hd)[NV], const double (&c)[NV], const double (&lb)[NV], const double (&ub)[NV],
                                const double (&A)[RPL][NV], const double (&b)[RPL])
 {
+	constexpr double kBig = 1e160;
 	double s = 0.0;
 	int bad = 0;
 #pragma unroll
 	for (int j = 0; j < NV; j++) {
-		s = fma(Hd[j], 0.0, s);
-		s = fma(c[j], 0.0, s);
+		s = fma(Hd[j], kBig, s);
+		s = fma(c[j], kBig, s);
 		bad |= ((lb[j] != lb[j]) | (ub[j] != ub[j])) ? 1 : 0;
 	}
 #pragma unroll
 	for (int k = 0; k < RPL; k++) {
 #pragma unroll
-		for (int j = 0; j < NV; j++) s = fma(A[k][j], 0.0, s);
-		s = fma(b[k], 0.0, s);
+		for (int j = 0; j < NV; j++) s = fma(A[k][j], kBig, s);
+		s = fma(b[k], kBig, s);
 	}
-	bad |= (s != s) ? 1 : 0;
+	bad |= !(fabs(s) < __builtin_huge_val()) ? 1 : 0;
 	return gor<G>(bad) != 0;
 }
 // compile-time loop with early exit: f(integral_constant<int, I>) for I = 0 .. N-1 until one returns true

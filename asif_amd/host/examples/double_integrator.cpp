@@ -5,8 +5,11 @@
 // for the first `steps` steps (default 2500 = up to the updateOptions call at t > 2.5 s, after which
 // the reference's behaviour depends on OSQP internals: lb_relax = 6 > ub_relax = 5).
 // With --batch B it also runs B copies of the current state through filterBatch() at every 100th step
-// and checks they agree with the single-agent answer.
+// and checks they agree with the single-agent answer.  With --time every filter() call is clocked on the host and a
+// one-line JSON summary (median / mean / p99 microseconds per call) goes to stderr -- bench.py's `c1` entry.
 #include <asif++.h>
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -42,8 +45,10 @@ int main(int argc, char **argv)
 {
 	int steps = 2500;
 	long batch = 0;
+	bool timing = false;
 	for (int i = 1; i < argc; i++) {
 		if (!std::strcmp(argv[i], "--steps") && i + 1 < argc) steps = std::atoi(argv[++i]);
+		else if (!std::strcmp(argv[i], "--time")) timing = true;
 		else if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) batch = std::atol(argv[++i]);
 	}
 	ASIF::ASIF *asif = new ASIF::ASIF(nx, nu, npSS, safetySet, dynamics);
@@ -59,9 +64,13 @@ int main(int argc, char **argv)
 	const double dt = 0.001;
 	double xNow[2] = {0.0, 0.0}, uDesNow[1] = {1.0}, uActNow[1] = {0.0}, tNow = 0.0, relax = 0.0;
 	int bad = 0;
+	std::vector<double> us;
+	us.reserve(steps);
 	std::printf("t,x,v,uDes,uAct,relax,rc\n");
 	for (int k = 0; k < steps; k++) {
+		const auto c0 = std::chrono::steady_clock::now();
 		const int32_t rc = asif->filter(xNow, uDesNow, uActNow, relax);
+		us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count());
 		if (batch > 0 && k % 100 == 0) {
 			std::vector<double> bx(2 * batch), bu(batch, uDesNow[0]), ba(batch, 0.0), br(batch, 0.0);
 			std::vector<int32_t> brc(batch, 0);
@@ -80,6 +89,13 @@ int main(int argc, char **argv)
 		std::printf("%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%d\n", tNow, xNow[0], xNow[1], uDesNow[0], uActNow[0], relax, rc);
 	}
 	delete asif;
+	if (timing && !us.empty()) {
+		double sum = 0.0;
+		for (double v : us) sum += v;
+		std::sort(us.begin(), us.end());
+		std::fprintf(stderr, "{\"median_us\": %.3f, \"mean_us\": %.3f, \"p99_us\": %.3f, \"min_us\": %.3f, \"calls\": %zu}\n",
+		             us[us.size() / 2], sum / us.size(), us[(us.size() * 99) / 100], us[0], us.size());
+	}
 	if (bad) {
 		std::fprintf(stderr, "filterBatch disagreed with filter() %d times\n", bad);
 		return 1;

@@ -129,7 +129,8 @@ typedef struct asif_hip_options {
 
 /* LearningData (include/asif_learning_utils.h:8-32): two small ReLU networks whose outputs are added to the
  * first row's Lfh / Lgh (update_weights, :123-155).  HOST pointers, dense column-major [rows x cols] as
- * matrixVectorMultiply reads them; asif_hip_set_learning copies.  Hidden widths <= 64, inputs >= 2 nx. */
+ * matrixVectorMultiply reads them; asif_hip_set_learning copies.  Inputs >= 2 nx; hidden widths <= 32, input and
+ * output widths <= 64 (larger networks: ASIF_HIP_EUNSUPPORTED). */
 typedef struct asif_hip_learning_data {
 	uint32_t d_drift_in, d_act_in, d_drift_hidden, d_act_hidden, d_drift_hidden_2, d_act_hidden_2, d_drift_out,
 	    d_act_out;

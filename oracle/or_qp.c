@@ -101,19 +101,21 @@ int or_qp_exact_small(const or_qp *qp, double *xout)
 {
 	const int nv = qp->nv, nc = qp->nc;
 	if (nv < 1 || nv > 3 || nc > 250) return -100;
-	/* Non-finite data (a NaN / inf state reaches the rows through h, Lfh, Lgh): OSQP 0.6 validates only l <= u at
-	 * set-up, osqp_update_A / _lin_cost take the values as they are, and every residual comparison of its termination
-	 * test is false on NaN -- it runs to max_iter and QPWrapperOsqp::solve hands back the raw status
-	 * (src/qpwrapper_osqp.cpp:225-238).  The exact solver stands in for it with that verdict; filter() then returns
-	 * -1 with uAct untouched (src/asif.cpp:199-209). */
+	/* Data outside the domain: NaN, infinite, or beyond 1e148 in magnitude (a NaN / inf / overflowing state reaches the
+	 * rows through h, Lfh, Lgh).  OSQP 0.6 validates only l <= u at set-up, osqp_update_A / _lin_cost take the values
+	 * as they are, and every residual comparison of its termination test is false on NaN -- it runs to max_iter and
+	 * QPWrapperOsqp::solve hands back the raw status (src/qpwrapper_osqp.cpp:225-238); on 1e150-sized entries its
+	 * double-precision iterates overflow into the same state.  The exact solver stands in for it with that verdict;
+	 * filter() then returns -1 with uAct untouched (src/asif.cpp:199-209).  Same rule on the device (qp_lane.hpp). */
+#define OR_OUT_OF_DOMAIN(v) (!(fabs(v) <= 1e148))
 	for (int j = 0; j < nv; j++) {
-		if (!isfinite(qp->Hd[j]) || !isfinite(qp->c[j]) || isnan(qp->lb[j]) || isnan(qp->ub[j]))
+		if (OR_OUT_OF_DOMAIN(qp->Hd[j]) || OR_OUT_OF_DOMAIN(qp->c[j]) || isnan(qp->lb[j]) || isnan(qp->ub[j]))
 			return OR_OSQP_MAX_ITER_REACHED;
 		for (int i = 0; i < nc; i++)
-			if (!isfinite(qp->A[i + j * nc])) return OR_OSQP_MAX_ITER_REACHED;
+			if (OR_OUT_OF_DOMAIN(qp->A[i + j * nc])) return OR_OSQP_MAX_ITER_REACHED;
 	}
 	for (int i = 0; i < nc; i++)
-		if (!isfinite(qp->b[i])) return OR_OSQP_MAX_ITER_REACHED;
+		if (OR_OUT_OF_DOMAIN(qp->b[i])) return OR_OSQP_MAX_ITER_REACHED;
 	cand_t cand[256 + 8];
 	int ncand = 0;
 	long double Dinv[3], c[3], x[3];
