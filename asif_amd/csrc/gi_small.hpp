@@ -162,6 +162,73 @@ struct GiSmall {
 		return bad ? kGiInfeasible : kGiOptimal;
 	}
 
+	// r with sum_s r_s n_s = c for NV normals n_s (rows of sn): Cramer's rule.  A determinant is a sum of products; its
+	// rounding is kNoise times the sum of their magnitudes.  False ("ambiguous") when the main determinant, or a
+	// numerator that is not plainly zero, is known to fewer than three digits.
+	ASIF_HD static bool solve_square(const double (&sn)[NV][NV], const double (&c)[NV], double (&r)[NV])
+	{
+		bool ok = true;
+		if constexpr (NV == 1) {
+			r[0] = c[0] / (sn[0][0] != 0.0 ? sn[0][0] : 1.0);
+			ok = sn[0][0] != 0.0;
+		} else if constexpr (NV == 2) {
+			// columns of the system are the normals: [n_0 n_1] r = c
+			auto det2 = [](double a, double b, double cc, double d, double &mag) {
+				const double p = a * d, q = b * cc;
+				mag = fabs(p) + fabs(q);
+				return p - q;
+			};
+			double m, m0, m1;
+			const double det = det2(sn[0][0], sn[1][0], sn[0][1], sn[1][1], m);
+			const double d0 = det2(c[0], sn[1][0], c[1], sn[1][1], m0);
+			const double d1 = det2(sn[0][0], c[0], sn[0][1], c[1], m1);
+			ok = fabs(det) > 1e4 * kNoise * m;
+			const double inv = 1.0 / (ok ? det : 1.0);
+			const double num[2] = {d0, d1}, mg[2] = {m0, m1};
+#pragma unroll
+			for (int s = 0; s < 2; s++) {
+				const bool zero = !(fabs(num[s]) > 16.0 * kNoise * mg[s]);
+				ok = ok & (zero | (fabs(num[s]) > 1e4 * kNoise * mg[s]));
+				r[s] = zero ? 0.0 : num[s] * inv;
+			}
+		} else {
+			// 3 x 3 by cofactors along the replaced column; a[i][s] = component i of normal s
+			auto det3 = [](const double (&a)[3][3], double &mag) {
+				double d = 0.0;
+				mag = 0.0;
+#pragma unroll
+				for (int k = 0; k < 3; k++) {
+					const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+					const double p = a[0][k] * a[1][k1] * a[2][k2], q = a[0][k] * a[1][k2] * a[2][k1];
+					d += p - q;
+					mag += fabs(p) + fabs(q);
+				}
+				return d;
+			};
+			double a[3][3], m;
+#pragma unroll
+			for (int i = 0; i < 3; i++)
+#pragma unroll
+				for (int t = 0; t < 3; t++) a[i][t] = sn[t][i];
+			const double det = det3(a, m);
+			ok = fabs(det) > 1e4 * kNoise * m;
+			const double inv = 1.0 / (ok ? det : 1.0);
+#pragma unroll
+			for (int s = 0; s < 3; s++) {
+				double b[3][3], ms;
+#pragma unroll
+				for (int i = 0; i < 3; i++)
+#pragma unroll
+					for (int t = 0; t < 3; t++) b[i][t] = t == s ? c[i] : a[i][t];
+				const double ds = det3(b, ms);
+				const bool zero = !(fabs(ds) > 16.0 * kNoise * ms);
+				ok = ok & (zero | (fabs(ds) > 1e4 * kNoise * ms));
+				r[s] = zero ? 0.0 : ds * inv;
+			}
+		}
+		return ok;
+	}
+
 	ASIF_HD static int solve_general(const QpLaneData<NV, RPL> &in, int g, int max_steps, double (&x)[NV], int &steps)
 	{
 		if constexpr (NV == 1) return solve_1d(in, g, x, steps);
@@ -350,15 +417,77 @@ struct GiSmall {
 				}
 				Mdiag[s] = M[s][s];
 			}
-			const bool spd = ldl_factor<NV>(M, Mi);
+			bool spd = ldl_factor<NV>(M, Mi);
 			ldl_solve<NV>(M, Mi, r);
 			double zn = 0.0, nn = 0.0, cond = 1.0;
 #pragma unroll
 			for (int s = 0; s < NV; s++) cond = fmax(cond, Mdiag[s] * Mi[s]); // 1 / sin^2 of the sharpest angle inside W
+			// W full (nv normals): n_p = N r is a square system, and going through N'G^-1 N squares its condition number --
+			// two rows [eps, h], [0, 1] with eps / h = 1e-12 (affine-arithmetic noise in Lgh, the shipped half-planes of
+			// DoubleIntegrator_Robust) leave a 2 x 2 matrix M whose second pivot is pure rounding, where N itself still
+			// gives r to four digits.  Cramer's rule on N, every determinant judged against the rounding of its own terms.
+			bool direct_amb = false;
+			if constexpr (NV >= 2) {
+				double rd[NV];
+				direct_amb = !solve_square(sn, cn, rd);
+#pragma unroll
+				for (int s = 0; s < NV; s++) r[s] = full ? rd[s] : r[s];
+				spd = full ? true : spd;
+				cond = full ? 1.0 : cond; // z is zero by construction below; nothing is scaled by cond on this path
+			}
 			// z component by component, each judged against the rounding of its own cancellation: a component at that
 			// level is zero (n_p lies in the span of W there), one clearly above it is data -- however small: a row
 			// [Lgh, h] with h = 1e-9 is NOT parallel to a bound on u, the relaxation variable just has to travel far
-			bool dependent = true, ambiguous = !spd;
+			bool dependent = true, ambiguous = !spd | (full & direct_amb);
+			// W one normal short of full: the part of n_p outside span(W) lies along G w, w the normal of that span (2-D: the
+			// perpendicular of the one normal; 3-D: the cross product of the two), t = G w (n_p.w) / (w.G w).  One
+			// determinant n_p.w carries the whole cancellation, judged against its own terms -- instead of 1 - 0.99999...
+			// per component when n_p is nearly parallel to a working row (rows [1e-9, h] against the bound on delta).
+			bool codim1 = false, cw_zero = false;
+			double tcf[NV];
+#pragma unroll
+			for (int j = 0; j < NV; j++) tcf[j] = 0.0;
+			if constexpr (NV >= 2) {
+				int nW = 0;
+#pragma unroll
+				for (int s = 0; s < NV; s++) nW += sid[s] >= 0 ? 1 : 0;
+				codim1 = nW == NV - 1;
+				double w[NV], wmag[NV];
+				if constexpr (NV == 2) { // empty slots hold zero normals: the sum IS the one normal in W
+					w[0] = sn[0][1] + sn[1][1];
+					w[1] = -(sn[0][0] + sn[1][0]);
+					wmag[0] = wmag[1] = 0.0;
+				} else {
+#pragma unroll
+					for (int k = 0; k < 3; k++) {
+						const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+						double v = 0.0, m = 0.0;
+#pragma unroll
+						for (int a = 0; a < 3; a++)
+#pragma unroll
+							for (int b = a + 1; b < 3; b++) { // the pair without the empty slot is the only non-zero term
+								const double p = sn[a][k1] * sn[b][k2], q = sn[a][k2] * sn[b][k1];
+								v += p - q;
+								m += fabs(p) + fabs(q);
+							}
+						w[k] = v;
+						wmag[k] = m;
+					}
+				}
+				double cw = 0.0, cwmag = 0.0, den = 0.0;
+#pragma unroll
+				for (int k = 0; k < NV; k++) {
+					cw += cn[k] * w[k];
+					cwmag += fabs(cn[k] * w[k]) + fabs(cn[k]) * wmag[k];
+					den += 2.0 * in.Hd[k] * w[k] * w[k];
+				}
+				cw_zero = !(fabs(cw) > 16.0 * kNoise * cwmag);
+				const bool cw_amb = (!cw_zero & !(fabs(cw) > 1e4 * kNoise * cwmag)) | !(den > 0.0);
+				ambiguous = ambiguous | (codim1 & cw_amb);
+				const double f = cw / (den > 0.0 ? den : 1.0);
+#pragma unroll
+				for (int k = 0; k < NV; k++) tcf[k] = 2.0 * in.Hd[k] * w[k] * f;
+			}
 #pragma unroll
 			for (int j = 0; j < NV; j++) {
 				double t = cn[j], mag = 0.0;
@@ -368,8 +497,11 @@ struct GiSmall {
 					mag += fabs(sn[s][j] * r[s]);
 				}
 				const double noise = kNoise * (fabs(cn[j]) + cond * mag);
-				const bool zero = full | !(fabs(t) > 16.0 * noise); // nv normals in W span everything
-				ambiguous = ambiguous | (!zero & !(fabs(t) > 1e4 * noise)); // known to < 3 digits: give up
+				bool zero = full | !(fabs(t) > 16.0 * noise); // nv normals in W span everything
+				const bool amb_j = !zero & !(fabs(t) > 1e4 * noise); // known to < 3 digits: give up
+				zero = codim1 ? (cw_zero | (tcf[j] == 0.0)) : zero;
+				ambiguous = ambiguous | (!codim1 & amb_j);
+				t = codim1 ? tcf[j] : t;
 				t = zero ? 0.0 : t;
 				dependent = dependent & zero;
 				z[j] = t * Pinv[j];

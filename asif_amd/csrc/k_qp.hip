@@ -130,9 +130,20 @@ int launch_qp_wave(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream
 	if (a.B <= 0) return 0;
 	if (a.B > 0x7fffffffLL) return ASIF_HIP_EUNSUPPORTED;
 	if (S.polish == 0 && !a.H && a.nv >= 1 && a.nv <= 32 && a.nc + a.nv <= 64) {
-		if (a.nv <= 8) return launch_wave<8>(S, a, stream);
-		if (a.nv <= 16) return launch_wave<16>(S, a, stream);
-		return launch_wave<32>(S, a, stream);
+		int r;
+		if (a.nv <= 8) r = launch_wave<8>(S, a, stream);
+		else if (a.nv <= 16) r = launch_wave<16>(S, a, stream);
+		else r = launch_wave<32>(S, a, stream);
+		if (r) return r;
+		// What the iterations leave at max_iter is not a verdict.  The problems the robust / realizable classes lift
+		// (multipliers without cost: LP-like, degenerate) keep ~0.5 % of their instances there at any practical budget,
+		// with iterates 1e-2 away from the optimum, where OSQP at its 1e-3 tolerances would have reported "solved".
+		// Second launch, same stream: exactly those instances go through the exact method of qp_lds.hpp; every other
+		// workgroup leaves at once.  Status and solution then equal the oracle's (tests/test_gpu_qp_generic.py).
+		QpArgs b = a;
+		b.only_status = kStatusMaxIter;
+		b.iters = nullptr; // keep the iteration counts of the first pass
+		return launch_qp_lds(S, b, stream);
 	}
 	return launch_qp_lds(S, a, stream);
 }

@@ -433,6 +433,7 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 	const int lane = threadIdx.x;
 	const int64_t qi = xcd_contiguous_index(blockIdx.x, a.B);
 	if (qi >= a.B) return; // wave-uniform (one wave per workgroup)
+	if (a.only_status != 0 && a.status[qi] != a.only_status) return; // second pass: this instance is already decided
 	const int nv = a.nv, nc = a.nc;
 	const int64_t ld = a.ld;
 	s.lane = lane;

@@ -154,3 +154,40 @@ def test_all_nan_rows_of_the_explicit_filter(gi):
     A = np.zeros((1, 8)); A[0, 2] = np.nan  # a single NaN entry
     sol, st, _ = gi(2, 4, Hd, c, A, np.full((1, 4), -1.0), np.array([[-1.0, 5.0]]), np.array([[1.0, 5.0]]), None)
     assert st[0] == 3
+
+
+def test_shipped_half_plane_problems_are_all_decided(oracle, gi):
+    """ASIFrobust on the shipped 100 half-planes (examples/DoubleIntegrator_Robust.cpp, 5 kept per call): after the
+    exact elimination of the multipliers the QP has rows [lo/hi(Lgh), h] (u, delta) >= -lo(Lfh) whose Lgh entries
+    are affine-arithmetic noise of 1e-9 ... 1e-14 next to h ~ -0.09 -- pairs of rows, and rows against the bound on
+    delta, meet at angles of 1e-8 ... 1e-12.  Round 2's stage declined 76 of 8 192 such instances (the normal-equations
+    matrix of two such normals is singular to rounding) and their waves fell through to ADMM + finish; with the square
+    system solved on the normals themselves and the codimension-one direction in closed form it decides every one,
+    verdict equal to the exact enumeration's."""
+    hp = oracle.load_halfplanes()
+    z = oracle.RobustData(hp)
+    B = 8192
+    x, u = oracle.make_batch_robust_data(hp, B)
+    A, b, code, sel = z.assemble(x)
+    M, nc, nv = z.nc // 3, z.nc, z.nv
+    A3 = A.reshape(B, nv, nc)
+    nr = 2 * M
+    A2, b2 = np.zeros((B, 2, nr)), np.zeros((B, nr))
+    for s in range(M):  # the two plain rows per safety function (oracle/or_filter.c: robust_exact)
+        iRow, iCol = 3 * s, 2 + 4 * s
+        for p, col, sign in ((0, iCol, 1.0), (1, iCol + 2, -1.0)):
+            A2[:, 0, 2 * s + p] = sign * A3[:, col, iRow]
+            A2[:, 1, 2 * s + p] = A3[:, 1, iRow]
+            b2[:, 2 * s + p] = -A3[:, iCol + 1, iRow]
+    Hd, c, lb, ub = (np.zeros((B, 2)) for _ in range(4))
+    for i in range(B):
+        H_, c_, lb_, ub_, _ = z.qp_static(u[i])
+        Hd[i], c[i], lb[i], ub[i] = H_[:2], c_[:2], lb_[:2], ub_[:2]
+    Af = np.ascontiguousarray(A2.reshape(B, 2 * nr))
+    ex, stex, _ = oracle.qp_solve_batch(2, nr, Hd, c, Af, b2, lb, ub, None, oracle.SOLVER_EXACT)
+    sol, st, steps = gi(2, nr, Hd, c, Af, b2, lb, ub, None)
+    assert (st == 0).sum() == 0
+    assert np.array_equal(st == 1, stex == 1) and np.array_equal(st == 2, stex != 1)
+    assert (stex != 1).sum() > 1000
+    ok = st == 1
+    assert np.abs(sol[ok] - ex[ok]).max() <= 1e-11

@@ -163,3 +163,41 @@ def test_shape_limits(hip):
     hip.qp_solve_batch(z(nv) + 1, c, z(nc * nv), z(nc) - 1e20, z(nv) - 1, z(nv) + 1, sol, st)
     torch.cuda.synchronize()
     assert np.all(st.cpu().numpy() == 1) and np.abs(sol.cpu().numpy() - 1.0).max() <= 1e-9
+
+
+def test_plain_admm_wave_kernel_on_the_lifted_robust_problem(hip, oracle):
+    """polish = 0, lanes_per_qp = 64: the north star's literal layout (OSQP-style ADMM, one wavefront per QP, iterates
+    and factor in LDS) on the shape it exists for, the lifted 18 x 12 robust QP.  Round 2 left ~0.5 % of the instances
+    at max_iter with a solution 6e-3 off and status -2 where the oracle says 1; what the iterations leave undecided now
+    goes through the exact LDS method in a second launch.  Status equal on every instance; |u - u_ref| <= 1e-5 with the
+    iterations' tolerances at 1e-9 (without a finish step their accuracy is what eps buys: 1.2e-5 at the default 1e-8)."""
+    B = 2048
+    d, Hd, c, A, b, lb, ub, be = _config_qps(oracle, 5, B)
+    model, variant = oracle.CONFIGS[5]
+    o = oracle.default_options(model, variant)
+    x, u = oracle.make_batch(5, B)
+    ua, rl, rc = oracle.filter_batch(model, variant, o, x, u, oracle.SOLVER_EXACT)
+    sol, st, it = _solve(hip, Hd, c, A, b, lb, ub, be, lanes_per_qp=64, polish=0, eps_abs=1e-9, eps_rel=1e-9)
+    assert np.array_equal(st, rc), f"{(st != rc).sum()} status mismatches"
+    assert np.abs(sol[:, 0].clip(o.lb[0], o.ub[0]) - ua[:, 0]).max() <= 1e-5
+    assert np.abs(sol[:, 1] - rl[:, 0]).max() <= 1e-5
+    assert it.max() >= 1000 and np.median(it) <= 400  # the iterations did run; a few instances used the whole budget
+
+
+def test_plain_admm_wave_kernel_on_shipped_half_planes_22x15(hip, oracle):
+    """Same mode on the 22 x 15 problems of DoubleIntegrator_Robust (a quarter infeasible): feasible <-> 1 on every
+    instance; an infeasible one ends with the certificate (-3) from either pass, never 'solved'."""
+    hp = oracle.load_halfplanes()
+    z = oracle.RobustData(hp)
+    B = 2048
+    x, u = oracle.make_batch_robust_data(hp, B)
+    ua, rl, rc = z.filter(x, u)
+    A, b, code, sel = z.assemble(x)
+    Hd, c, lb, ub = (np.zeros((B, z.nv)) for _ in range(4))
+    for i in range(B):
+        Hd[i], c[i], lb[i], ub[i], be = z.qp_static(u[i])
+    sol, st, it = _solve(hip, Hd, c, A, b, lb, ub, be, lanes_per_qp=64, polish=0, eps_abs=1e-9, eps_rel=1e-9)
+    assert np.array_equal(st == 1, rc == 1), f"{((st == 1) != (rc == 1)).sum()} status mismatches"
+    assert np.all(st[rc != 1] == -3)
+    ok = rc == 1
+    assert (np.abs(sol[ok, 0] - ua[ok, 0]) / np.maximum(1.0, np.abs(ua[ok, 0]))).max() <= 1e-5  # |u| up to 20 here
