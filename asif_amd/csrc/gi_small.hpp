@@ -417,77 +417,15 @@ struct GiSmall {
 				}
 				Mdiag[s] = M[s][s];
 			}
-			bool spd = ldl_factor<NV>(M, Mi);
+			const bool spd = ldl_factor<NV>(M, Mi);
 			ldl_solve<NV>(M, Mi, r);
 			double zn = 0.0, nn = 0.0, cond = 1.0;
 #pragma unroll
 			for (int s = 0; s < NV; s++) cond = fmax(cond, Mdiag[s] * Mi[s]); // 1 / sin^2 of the sharpest angle inside W
-			// W full (nv normals): n_p = N r is a square system, and going through N'G^-1 N squares its condition number --
-			// two rows [eps, h], [0, 1] with eps / h = 1e-12 (affine-arithmetic noise in Lgh, the shipped half-planes of
-			// DoubleIntegrator_Robust) leave a 2 x 2 matrix M whose second pivot is pure rounding, where N itself still
-			// gives r to four digits.  Cramer's rule on N, every determinant judged against the rounding of its own terms.
-			bool direct_amb = false;
-			if constexpr (NV >= 2) {
-				double rd[NV];
-				direct_amb = !solve_square(sn, cn, rd);
-#pragma unroll
-				for (int s = 0; s < NV; s++) r[s] = full ? rd[s] : r[s];
-				spd = full ? true : spd;
-				cond = full ? 1.0 : cond; // z is zero by construction below; nothing is scaled by cond on this path
-			}
 			// z component by component, each judged against the rounding of its own cancellation: a component at that
 			// level is zero (n_p lies in the span of W there), one clearly above it is data -- however small: a row
 			// [Lgh, h] with h = 1e-9 is NOT parallel to a bound on u, the relaxation variable just has to travel far
-			bool dependent = true, ambiguous = !spd | (full & direct_amb);
-			// W one normal short of full: the part of n_p outside span(W) lies along G w, w the normal of that span (2-D: the
-			// perpendicular of the one normal; 3-D: the cross product of the two), t = G w (n_p.w) / (w.G w).  One
-			// determinant n_p.w carries the whole cancellation, judged against its own terms -- instead of 1 - 0.99999...
-			// per component when n_p is nearly parallel to a working row (rows [1e-9, h] against the bound on delta).
-			bool codim1 = false, cw_zero = false;
-			double tcf[NV];
-#pragma unroll
-			for (int j = 0; j < NV; j++) tcf[j] = 0.0;
-			if constexpr (NV >= 2) {
-				int nW = 0;
-#pragma unroll
-				for (int s = 0; s < NV; s++) nW += sid[s] >= 0 ? 1 : 0;
-				codim1 = nW == NV - 1;
-				double w[NV], wmag[NV];
-				if constexpr (NV == 2) { // empty slots hold zero normals: the sum IS the one normal in W
-					w[0] = sn[0][1] + sn[1][1];
-					w[1] = -(sn[0][0] + sn[1][0]);
-					wmag[0] = wmag[1] = 0.0;
-				} else {
-#pragma unroll
-					for (int k = 0; k < 3; k++) {
-						const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
-						double v = 0.0, m = 0.0;
-#pragma unroll
-						for (int a = 0; a < 3; a++)
-#pragma unroll
-							for (int b = a + 1; b < 3; b++) { // the pair without the empty slot is the only non-zero term
-								const double p = sn[a][k1] * sn[b][k2], q = sn[a][k2] * sn[b][k1];
-								v += p - q;
-								m += fabs(p) + fabs(q);
-							}
-						w[k] = v;
-						wmag[k] = m;
-					}
-				}
-				double cw = 0.0, cwmag = 0.0, den = 0.0;
-#pragma unroll
-				for (int k = 0; k < NV; k++) {
-					cw += cn[k] * w[k];
-					cwmag += fabs(cn[k] * w[k]) + fabs(cn[k]) * wmag[k];
-					den += 2.0 * in.Hd[k] * w[k] * w[k];
-				}
-				cw_zero = !(fabs(cw) > 16.0 * kNoise * cwmag);
-				const bool cw_amb = (!cw_zero & !(fabs(cw) > 1e4 * kNoise * cwmag)) | !(den > 0.0);
-				ambiguous = ambiguous | (codim1 & cw_amb);
-				const double f = cw / (den > 0.0 ? den : 1.0);
-#pragma unroll
-				for (int k = 0; k < NV; k++) tcf[k] = 2.0 * in.Hd[k] * w[k] * f;
-			}
+			bool dependent = true, ambiguous = !spd;
 #pragma unroll
 			for (int j = 0; j < NV; j++) {
 				double t = cn[j], mag = 0.0;
@@ -497,16 +435,85 @@ struct GiSmall {
 					mag += fabs(sn[s][j] * r[s]);
 				}
 				const double noise = kNoise * (fabs(cn[j]) + cond * mag);
-				bool zero = full | !(fabs(t) > 16.0 * noise); // nv normals in W span everything
-				const bool amb_j = !zero & !(fabs(t) > 1e4 * noise); // known to < 3 digits: give up
-				zero = codim1 ? (cw_zero | (tcf[j] == 0.0)) : zero;
-				ambiguous = ambiguous | (!codim1 & amb_j);
-				t = codim1 ? tcf[j] : t;
+				const bool zero = full | !(fabs(t) > 16.0 * noise); // nv normals in W span everything
+				ambiguous = ambiguous | (!zero & !(fabs(t) > 1e4 * noise)); // known to < 3 digits: give up
 				t = zero ? 0.0 : t;
 				dependent = dependent & zero;
 				z[j] = t * Pinv[j];
 				zn += t * z[j];
 				nn += cn[j] * cn[j] * Pinv[j];
+			}
+			// A lane the general form leaves ambiguous gets a second opinion -- computed only by a wave that holds such a
+			// lane -- from the two forms that do not square the condition number of W:
+			//  * W full (nv normals): n_p = N r is a square system; Cramer's rule on N itself, every determinant judged
+			//    against the rounding of its own terms.  Two rows [eps, h], [0, 1] with eps / h = 1e-12 (affine-arithmetic
+			//    noise in Lgh: the shipped half-planes of DoubleIntegrator_Robust) leave a 2 x 2 matrix M = N'G^-1 N whose
+			//    second pivot is pure rounding, where N still gives r to four digits.
+			//  * W one normal short of full: the part of n_p outside span(W) lies along G w, w the normal of that span
+			//    (2-D: the perpendicular of the one normal; 3-D: the cross product of the two),
+			//    t = G w (n_p.w) / (w.G w): ONE determinant n_p.w carries the whole cancellation instead of 1 - 0.99999...
+			//    per component when n_p is nearly parallel to a working row (a row [1e-9, h] against the bound on delta).
+			if constexpr (NV >= 2) {
+				const bool robust = ambiguous & have & !done;
+				if (wave_any(robust)) {
+					int nW = 0;
+#pragma unroll
+					for (int s = 0; s < NV; s++) nW += sid[s] >= 0 ? 1 : 0;
+					double rd[NV];
+					const bool sq_ok = solve_square(sn, cn, rd);
+					const bool sq = robust & full, codim1 = robust & (nW == NV - 1);
+					double w[NV], wmag[NV];
+					if constexpr (NV == 2) { // empty slots hold zero normals: the sum IS the one normal in W
+						w[0] = sn[0][1] + sn[1][1];
+						w[1] = -(sn[0][0] + sn[1][0]);
+						wmag[0] = wmag[1] = 0.0;
+					} else {
+#pragma unroll
+						for (int k = 0; k < 3; k++) {
+							const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+							double v = 0.0, m = 0.0;
+#pragma unroll
+							for (int a = 0; a < 3; a++)
+#pragma unroll
+								for (int b = a + 1; b < 3; b++) { // the pair without the empty slot is the only non-zero term
+									const double p = sn[a][k1] * sn[b][k2], q = sn[a][k2] * sn[b][k1];
+									v += p - q;
+									m += fabs(p) + fabs(q);
+								}
+							w[k] = v;
+							wmag[k] = m;
+						}
+					}
+					double cw = 0.0, cwmag = 0.0, den = 0.0;
+#pragma unroll
+					for (int k = 0; k < NV; k++) {
+						cw += cn[k] * w[k];
+						cwmag += fabs(cn[k] * w[k]) + fabs(cn[k]) * wmag[k];
+						den += 2.0 * in.Hd[k] * w[k] * w[k];
+					}
+					const bool cw_zero = !(fabs(cw) > 16.0 * kNoise * cwmag);
+					const bool cw_amb = (!cw_zero & !(fabs(cw) > 1e4 * kNoise * cwmag)) | !(den > 0.0);
+					const double f = cw / (den > 0.0 ? den : 1.0);
+					// full: r from the square system, z = 0 by construction (spd and cond play no part on this path)
+#pragma unroll
+					for (int s = 0; s < NV; s++) r[s] = sq ? rd[s] : r[s];
+					ambiguous = sq ? !sq_ok : (codim1 ? (!spd | cw_amb) : ambiguous);
+					bool dep1 = true;
+					double zn1 = 0.0;
+					double z1[NV];
+#pragma unroll
+					for (int k = 0; k < NV; k++) {
+						const double t = (cw_zero | sq) ? 0.0 : 2.0 * in.Hd[k] * w[k] * f;
+						dep1 = dep1 & (t == 0.0);
+						z1[k] = t * Pinv[k];
+						zn1 += t * z1[k];
+					}
+					const bool over = sq | codim1;
+					dependent = over ? dep1 : dependent;
+					zn = over ? zn1 : zn;
+#pragma unroll
+					for (int k = 0; k < NV; k++) z[k] = over ? z1[k] : z[k];
+				}
 			}
 			// ---- 3. dual blocking: smallest su / r over the droppable slots with r > 0
 			double t1 = 1e300;

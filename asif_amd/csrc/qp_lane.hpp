@@ -155,6 +155,14 @@ ASIF_HD bool wave_all(bool p)
 	return p;
 #endif
 }
+ASIF_HD bool wave_any(bool p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __any(p);
+#else
+	return p;
+#endif
+}
 // ranking-grade 1/sqrt (hardware seed on the device; only ever used to order candidates)
 ASIF_HD double rank_rsqrt(double v)
 {
