@@ -8,6 +8,8 @@
 // (:199-209).
 // HBM traffic is the algorithmic minimum: 8(nx+nu) bytes in, 8(nu+1)+4 bytes out per instance, SoA,
 // consecutive lanes -> consecutive instances (G = 1) so every load/store is a fully coalesced line.
+#include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 #include "admm_small.hpp"
 #include "launchers.hpp"
@@ -18,7 +20,7 @@ namespace asif {
 // solver mode or asif_hip_solver::presolve): no ADMM / finish code, hence none of their register footprint.
 // SEL: the optional paths of src/asif.cpp (npSSmax < npSS row selection, caller-supplied Lie derivatives) are
 // compiled in; the default instantiation (every row, the model's own Lie derivatives) does not carry them.
-template <class M, int G, bool PRE, bool SEL = false>
+template <class M, int G, bool PRE, bool SEL = false, bool WHOLE = false>
 __device__ __forceinline__ void explicit_filter_body(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a,
                                                      bool assemble_only)
 {
@@ -135,7 +137,22 @@ __device__ __forceinline__ void explicit_filter_body(const DevOptions &o, const 
 		double sol[NV];
 		int steps;
 		const int verdict = GiSmall<NV, RPL, G>::template solve_with_pinned<NU>(qp, g, 8 * NV + 4, sol, steps);
-		if (live) {
+		if constexpr (WHOLE) {
+			// whole-line stores (see launch_explicit_di): a failed lane stores back what it finds in its slot
+			const bool ok = verdict == kGiOptimal;
+			double u = fmin(fmax(sol[0], o.lb[0]), o.ub[0]), rl = sol[NU];
+			if (__any(live & !ok)) {
+				if (live & !ok) {
+					u = a.uact[i];
+					rl = a.relax[i];
+				}
+			}
+			if (live) {
+				a.uact[i] = u;
+				a.relax[i] = rl;
+				a.rc[i] = ok ? ASIF_HIP_RC_OK : ASIF_HIP_RC_QP_FAILED;
+			}
+		} else if (live) {
 			if (verdict == kGiOptimal) {
 				a.uact[i] = fmin(fmax(sol[0], o.lb[0]), o.ub[0]);
 				a.relax[i] = sol[NU];
@@ -143,6 +160,8 @@ __device__ __forceinline__ void explicit_filter_body(const DevOptions &o, const 
 			} else {
 				a.rc[i] = ASIF_HIP_RC_QP_FAILED; // uAct and relax stay untouched, src/asif.cpp:208-209
 			}
+		}
+		if (live) {
 			if (a.diag) {
 				a.diag[0 * a.ld + i] = 0.0;
 				a.diag[1 * a.ld + i] = 0.0;
@@ -185,11 +204,14 @@ __global__ __launch_bounds__((PRE ? 256 : 64), (G >= 2 ? 2 : 1)) void explicit_f
 // launch that carries the 2 KB DevOptions structure in its argument block costs the host 3.9 us against 2.8 us for a
 // small one (tools/scratch/launch_cost.hip) -- more than this kernel runs -- and costs a replayed graph 0.25 us per
 // node; a pointer to a device copy would cost the kernel a dependent load before its first instruction.
+// batch size from which the whole-line stores take over: where the 44 B per instance of one launch no longer fit the
+// 256 MiB Infinity Cache (below it the partially written lines are merged in cache; measured)
+constexpr long long kWholeLinesFrom = 6291456;
 struct ExplicitOpts {
 	double lb[ASIF_HIP_MAX_NU], ub[ASIF_HIP_MAX_NU], relaxCost, relaxLb;
 	int npKeep;
 };
-template <class M, bool SEL>
+template <class M, bool SEL, bool WHOLE = false>
 __global__ __launch_bounds__(256) void explicit_light_kernel(ExplicitOpts e, FilterArgs a)
 {
 	static_assert(M::kIgnoresOptions, "the model's functors must not read DevOptions: only the class's fields are passed");
@@ -203,7 +225,7 @@ __global__ __launch_bounds__(256) void explicit_light_kernel(ExplicitOpts e, Fil
 	o.relaxLb = e.relaxLb;
 	o.npKeep = e.npKeep;
 	const asif_hip_solver none = {};
-	explicit_filter_body<M, 1, true, SEL>(o, none, a, false);
+	explicit_filter_body<M, 1, true, SEL, WHOLE>(o, none, a, false);
 }
 
 // Closed loop, T control steps per launch (the caller's side of filter(): examples/DoubleIntegrator.cpp:81-116).
@@ -371,6 +393,22 @@ int launch_explicit_di(const DevOptions &o, const asif_hip_solver &S, const Filt
 		e.relaxCost = o.relaxCost;
 		e.relaxLb = o.relaxLb;
 		e.npKeep = o.npKeep;
+		// From ~1 M instances the kernel is bound by memory, and what binds it is the STORES: uAct / relax are written
+		// only where the solve succeeded (src/asif.cpp:208-209 leaves them untouched otherwise), and lines written under a
+		// partial lane mask cost the memory system a read-modify-write -- 3.9 TB/s against 6.0 TB/s for the same columns
+		// stored whole (tools/scratch/stream_pattern.hip, profiles/r03/stream_pattern_microbench.txt; 16-byte accesses
+		// change neither figure).  The whole-line instantiation reads the old values of the failed lanes itself (only in
+		// waves that hold one) and stores every lane: 16 M instances 195 -> 175 us.  Below the switch-over the batch lives
+		// in the caches, the partial lines are merged there, and the extra dependent load only costs (1 M: 10.4 -> 12.0 us).
+		static const int64_t whole_from = []() {
+			const char *v = getenv("ASIF_HIP_WHOLE_LINES_FROM"); // developer override of the switch-over batch size
+			return v ? (int64_t)atoll(v) : (int64_t)kWholeLinesFrom;
+		}();
+		if (!sel && a.B >= whole_from) {
+			hipLaunchKernelGGL((explicit_light_kernel<DoubleIntegrator, false, true>), dim3(grid_for(a.B, 1, block)), dim3(block), 0,
+			                   stream, e, a);
+			return (int)hipGetLastError();
+		}
 		if (sel)
 			hipLaunchKernelGGL((explicit_light_kernel<DoubleIntegrator, true>), dim3(grid_for(a.B, 1, block)), dim3(block), 0,
 			                   stream, e, a);

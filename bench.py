@@ -523,6 +523,8 @@ def bench_filter(args, grp, dev, cfg, headline):
         x, udes = workloads.make_batch_robust_data(halfplanes, count, first=first)
     else:
         x, udes = workloads.make_batch(cfg, count, first=first)
+    if args.state_scale != 1.0:
+        x = x * args.state_scale  # NOT the SURVEY 8(d) workload any more; recorded in config.state_scale
     tx = torch.from_numpy(x).to(dev)
     tu = torch.from_numpy(udes).to(dev)
     uact = torch.zeros((d.nu, B), dtype=torch.float64, device=dev)
@@ -669,6 +671,7 @@ def bench_filter(args, grp, dev, cfg, headline):
         "config": {"workload": WORKLOAD[cfg], "batch_per_gpu": B, "sharding": "instances, no collective",
                    "lanes_per_qp": args.lanes or "default",
                    "presolve": args.presolve,
+                   "state_scale": args.state_scale,
                    "launch": how,
                    # how the QPs were decided: polish 2 runs the in-register dual active-set stage first, then OSQP-style
                    # ADMM iterations (with an active-set finish at every check) for what it leaves undecided
@@ -789,6 +792,9 @@ def main():
                          "K steps is timed too and reported beside it as value_graph_replay")
     ap.add_argument("--cpu-seconds", type=float, default=5.0,
                     help="CPU work spent on the cpu_baseline sample of each config in `configs` (the headline's is 15 s)")
+    ap.add_argument("--state-scale", type=float, default=1.0,
+                    help="multiplies the seeded states (1.0 = the SURVEY 8(d) workload; e.g. 0.5 puts every C2 state inside the "
+                         "safe set: no failed instance, the kernel's memory behaviour without the untouched-slot reads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
     ap.add_argument("--no-c1", action="store_true", help="skip the single-agent C1 leg of --config all")

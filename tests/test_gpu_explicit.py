@@ -93,3 +93,42 @@ def test_presolve_closed_form_equals_admm_path(hip, oracle):
     ok = rc == 1
     assert np.all(pre["relax"][0, ok] == 5.0) and np.all(pre["relax"][0, ~ok] == -7.0)
     assert np.all(pre["uact"][0, ~ok] == 7.0)
+
+
+def test_whole_line_store_kernel_is_bitwise_the_masked_store_kernel(hip, oracle):
+    """From 6 M instances the explicit filter stores every lane of uAct / relax (a failed lane writes back the value it
+    read from its slot) instead of storing under the mask of the successful lanes: partial-line stores cost HBM a
+    read-modify-write (profiles/r03/stream_pattern_microbench.txt).  An odd batch just above the switch-over against the
+    same instances in two launches below it (masked stores): uAct, relax, rc bitwise equal, untouched slots untouched,
+    and equal to the oracle on a sample."""
+    import torch
+    from asif_amd import workloads
+    B = 6291456 + 1
+    x, udes = workloads.make_batch(2, B)
+    dev = torch.device("cuda:0")
+    flt = hip.Filter(*hip.CONFIGS[2][:2])
+
+    def run(lo, hi):
+        n = hi - lo
+        tx = torch.from_numpy(np.ascontiguousarray(x[:, lo:hi])).to(dev)
+        tu = torch.from_numpy(np.ascontiguousarray(udes[:, lo:hi])).to(dev)
+        uact = torch.full((1, n), 7.0, dtype=torch.float64, device=dev)
+        relax = torch.full((1, n), -7.0, dtype=torch.float64, device=dev)
+        rc = torch.zeros(n, dtype=torch.int32, device=dev)
+        flt.filter(tx, tu, uact, relax, rc)
+        torch.cuda.synchronize()
+        return uact.cpu().numpy(), relax.cpu().numpy(), rc.cpu().numpy()
+
+    whole = run(0, B)
+    h1, h2 = run(0, B // 2), run(B // 2, B)
+    flt.close()
+    for k in range(3):
+        assert np.array_equal(whole[k], np.concatenate([h1[k], h2[k]], axis=-1))
+    ua, rl, rc = whole
+    fail = rc == -1
+    assert fail.sum() > B // 10
+    assert np.all(ua[0, fail] == 7.0) and np.all(rl[0, fail] == -7.0)
+    for sl in (slice(0, 8192), slice(B - 4097, B)):
+        uo, ro, rco = gpu_util.oracle_filter(oracle, 2, x[:, sl], udes[:, sl], uact_init=7.0, relax_init=-7.0)
+        assert np.array_equal(rc[sl], rco)
+        assert np.abs(ua[:, sl] - uo).max() <= U_TOL
