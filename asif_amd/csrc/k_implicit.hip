@@ -62,7 +62,24 @@ __device__ inline double learn_net(const DevOptions::Learn &L, int net, const do
 // there is no per-block restart point: one pass, the exact per-sample selection with the states parked in LDS
 // (the handful of Runge-Kutta steps per trajectory is cheap next to 5000 Euler steps; the samples are interpolations).
 
-template <class M, bool RB, bool DOPRI = false>
+// CKPT: where the block-start states of pass 1's running selection live (K slots of NZ + 2 doubles per lane), as in
+// k_tb.hip: kCkptLds2 -- in LDS next to pass 2's payload, nothing of the search touches HBM (70 KB per wave for the
+// pendulum: two waves per CU, taken when the batch needs no more: C3 is 256 waves); kCkptSpill -- in LDS during pass 1,
+// in the region pass 2 reuses, the K survivors written to HBM once between the passes.  (Round 2 wrote a checkpoint
+// whenever a block entered the selection.)
+constexpr int kImCkptLds2 = 1, kImCkptSpill = 2;
+template <class M>
+struct ImplicitLds {
+	static constexpr int NZ = M::NX + M::NX * M::NX, K = M::NPBTSS, CK = NZ + 2;
+	static constexpr int kPay = K * NZ * 64, kCk = K * CK * 64;
+	static constexpr size_t bytes(int ckpt, bool rb)
+	{
+		const size_t head = ckpt == kImCkptLds2 ? (size_t)kPay + kCk : (size_t)(kPay > kCk ? kPay : kCk);
+		return sizeof(double) * (head + (rb ? 2 * kLearnMaxHidden * 64 : 0));
+	}
+};
+
+template <class M, bool RB, bool DOPRI = false, int CKPT = kImCkptSpill>
 __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, FilterArgs a)
 {
 	// the soft saturation selects between these two and the input: as kernel arguments (SGPRs) they are copied into
@@ -74,8 +91,13 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 	constexpr int NC = K * NP + NB;
 	static_assert(NB == 1, "one backup-set function");
 	static_assert(!RB || NP >= NX, "Dh_index_ takes the first nx entries of a column of the npSS x nx product");
-	__shared__ double pay[K * NZ * 64];
-	__shared__ double act[RB ? 2 * kLearnMaxHidden * 64 : 1];
+	extern __shared__ double im_lds[];
+	using L = ImplicitLds<M>;
+	double *const pay = im_lds;                                                 // pass 2: states of the K most critical samples
+	double *const ckl = CKPT == kImCkptLds2 ? im_lds + L::kPay : im_lds;        // pass 1: checkpoints of the K selected blocks
+	double *const act = im_lds + (CKPT == kImCkptLds2 ? L::kPay + L::kCk : (L::kPay > L::kCk ? L::kPay : L::kCk));
+	(void)act;
+	(void)ckl;
 	const int lane = threadIdx.x;
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const bool live = i < a.B;
@@ -155,11 +177,11 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 		if (__any(bmin < topB.key[K - 1])) {
 			const int slot = topB.insert(bmin, blk);
 			if (slot >= 0) {
-				double *c = ck + (int64_t)slot * CK * ldc;
+				double *c = ckl + slot * CK * 64 + lane;
 #pragma unroll
-				for (int k = 0; k < NZ; k++) c[k * ldc] = zs[k];
-				c[NZ * ldc] = hs.u;
-				c[(NZ + 1) * ldc] = hs.tLast;
+				for (int k = 0; k < NZ; k++) c[k * 64] = zs[k];
+				c[NZ * 64] = hs.u;
+				c[(NZ + 1) * 64] = hs.tLast;
 			}
 		}
 	};
@@ -250,6 +272,24 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 #pragma unroll
 	for (int k = 0; k < NZ; k++) zEnd[k] = z[k];
 
+	if constexpr (CKPT == kImCkptSpill) {
+		// the survivors of the selection leave LDS before pass 2 starts to overwrite the region with its payload
+#pragma unroll 1
+		for (int p = 0; p < K; p++) {
+			int slot = 0, idx = -1;
+#pragma unroll
+			for (int q = 0; q < K; q++) {
+				slot = q == p ? topB.slot[q] : slot;
+				idx = q == p ? topB.idx[q] : idx;
+			}
+			if (idx >= 0) {
+				double *c = ck + (int64_t)slot * CK * ldc;
+				const double *l = ckl + slot * CK * 64 + lane;
+#pragma unroll
+				for (int k = 0; k < CK; k++) c[k * ldc] = l[k * 64];
+			}
+		}
+	}
 	// ---- pass 2: re-integrate the selected blocks from their checkpoints, in increasing block order so that
 	// samples arrive in increasing index (the selection's tie rule: earlier sample first), and run the exact
 	// per-sample selection with the states parked in LDS -- at most K*MB of the npBT steps.
@@ -269,11 +309,19 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 		if (!__any(have)) break;
 		cur = have ? nb : cur;
 		const int blk = have ? nb : 0;
-		const double *c = ck + (int64_t)(have ? sl : 0) * CK * ldc;
+		if constexpr (CKPT == kImCkptSpill) {
+			const double *c = ck + (int64_t)(have ? sl : 0) * CK * ldc;
 #pragma unroll
-		for (int k = 0; k < NZ; k++) z[k] = c[k * ldc];
-		hold.u = c[NZ * ldc];
-		hold.tLast = c[(NZ + 1) * ldc];
+			for (int k = 0; k < NZ; k++) z[k] = c[k * ldc];
+			hold.u = c[NZ * ldc];
+			hold.tLast = c[(NZ + 1) * ldc];
+		} else {
+			const double *c = ckl + (have ? sl : 0) * CK * 64 + lane;
+#pragma unroll
+			for (int k = 0; k < NZ; k++) z[k] = c[k * 64];
+			hold.u = c[NZ * 64];
+			hold.tLast = c[(NZ + 1) * 64];
+		}
 #pragma unroll 1
 		for (int t = 0; t < MB; t++) {
 			const int s = blk * MB + t;
@@ -457,17 +505,48 @@ struct ImplicitPolicy {
 	}
 };
 
+template <class K>
+static int launch_with_lds(K kern, size_t bytes, int grid, const DevOptions &o, const FilterArgs &a, hipStream_t stream)
+{
+	if (bytes > 48 * 1024) {
+		const hipError_t he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+		if (he != hipSuccess) return (int)he;
+	}
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(64), bytes, stream, o, a);
+	return (int)hipGetLastError();
+}
+
+// rows kernel of model M: checkpoints in an LDS region of their own when the batch fits the occupancy that leaves
+template <class M>
+static int launch_rows(const DevOptions &o, const FilterArgs &a, hipStream_t stream, bool rb)
+{
+	using L = ImplicitLds<M>;
+	const int grid = grid_for(a.B, 1, 64);
+	if (o.integrator == 1) // one pass, no checkpoints: payload region only
+		return launch_with_lds(implicit_rows_kernel<M, false, true>, L::bytes(kImCkptSpill, false), grid, o, a, stream);
+	static const int cus = []() {
+		int dev = 0, n = 256;
+		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+		return n > 0 ? n : 256;
+	}();
+	const size_t both = L::bytes(kImCkptLds2, rb);
+	const int per_cu = (int)((160 * 1024) / both);
+	const bool lds2 = per_cu >= 1 && (int64_t)grid <= (int64_t)(per_cu < 4 ? per_cu : 4) * cus;
+	if (rb) {
+		if (lds2) return launch_with_lds(implicit_rows_kernel<M, true, false, kImCkptLds2>, both, grid, o, a, stream);
+		return launch_with_lds(implicit_rows_kernel<M, true, false, kImCkptSpill>, L::bytes(kImCkptSpill, true), grid, o, a, stream);
+	}
+	if (lds2) return launch_with_lds(implicit_rows_kernel<M, false, false, kImCkptLds2>, both, grid, o, a, stream);
+	return launch_with_lds(implicit_rows_kernel<M, false, false, kImCkptSpill>, L::bytes(kImCkptSpill, false), grid, o, a, stream);
+}
+
 int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                        hipStream_t stream, bool rb)
 {
 	using M = InvertedPendulum;
 	if (a.B <= 0) return 0;
 	if (o.integrator == 1 && rb) return ASIF_HIP_EUNSUPPORTED; // held input: time-dependent rhs, Euler only
-	if (rb) hipLaunchKernelGGL((implicit_rows_kernel<M, true>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
-	else if (o.integrator == 1)
-		hipLaunchKernelGGL((implicit_rows_kernel<M, false, true>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
-	else hipLaunchKernelGGL((implicit_rows_kernel<M, false>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
-	int e = (int)hipGetLastError();
+	int e = launch_rows<M>(o, a, stream, rb);
 	if (e || assemble_only) return e;
 	const ImplicitPolicy<M> p = {a.B, o, a};
 	switch (S.lanes_per_qp) {
@@ -487,11 +566,7 @@ int launch_implicit_di(const DevOptions &o, const asif_hip_solver &S, const Filt
 	static_assert(M::NPBTSS * M::NPSS + M::NPBS == 17, "QP shape 3 x 17");
 	if (a.B <= 0) return 0;
 	if (o.integrator == 1 && rb) return ASIF_HIP_EUNSUPPORTED;
-	if (rb) hipLaunchKernelGGL((implicit_rows_kernel<M, true>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
-	else if (o.integrator == 1)
-		hipLaunchKernelGGL((implicit_rows_kernel<M, false, true>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
-	else hipLaunchKernelGGL((implicit_rows_kernel<M, false>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
-	int e = (int)hipGetLastError();
+	int e = launch_rows<M>(o, a, stream, rb);
 	if (e || assemble_only) return e;
 	const ImplicitPolicy<M> p = {a.B, o, a};
 	switch (S.lanes_per_qp) {

@@ -19,7 +19,17 @@
 namespace asif {
 
 
-template <class M>
+// CKPT: where the block-start states of pass 1's running selection live (K slots of NZ doubles per lane).
+//   kCkptLds2  in LDS, in a region of their own next to pass 2's payload (2 x K NZ 64 doubles = 80 KB for the segway:
+//              two waves per CU) -- nothing of the search ever touches HBM; taken when the batch needs no more than
+//              two waves per CU anyway (C4: 32 768 instances per GPU = 512 waves on 256 CUs);
+//   kCkptSpill in LDS during pass 1, in the region pass 2 will use for its payload; the K survivors are written to
+//              HBM once, between the passes (640 B per instance), and pass 2 reads them back.
+// Round 2 wrote a checkpoint to HBM whenever a block ENTERED the selection: on the segway, whose margins shrink along
+// the trajectory, nearly every 4-sample block does -- 171 MB of writes per 32 768 instances (PMC), 5.2 KB per instance.
+constexpr int kCkptLds2 = 1, kCkptSpill = 2;
+
+template <class M, int CKPT>
 __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArgs a)
 {
 	// the soft saturation selects between these two and the input: as kernel arguments (SGPRs) they are copied into
@@ -28,7 +38,9 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 	asm("" : "+v"(o.lb[0]), "+v"(o.ub[0]));
 	constexpr int NX = M::NX, NP = M::NPSS, K = M::NPBTSS, NZ = NX + NX * NX;
 	constexpr int NC = K * NP + 2, NV = 2;
-	__shared__ double pay[K * NZ * 64];
+	extern __shared__ double tb_lds[];
+	double *const pay = tb_lds;                                            // pass 2: states of the K most critical samples
+	double *const ckl = CKPT == kCkptLds2 ? tb_lds + K * NZ * 64 : tb_lds; // pass 1: states at the start of the K selected blocks
 	const int lane = threadIdx.x;
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const bool live = i < a.B;
@@ -66,9 +78,8 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 		if (__any(bmin < topB.key[K - 1])) {
 			const int slot = topB.insert(bmin, blk);
 			if (slot >= 0) {
-				double *c = ck + (int64_t)slot * NZ * ld;
 #pragma unroll
-				for (int k = 0; k < NZ; k++) c[k * ld] = zs[k];
+				for (int k = 0; k < NZ; k++) ckl[(slot * NZ + k) * 64 + lane] = zs[k];
 			}
 		}
 	};
@@ -185,6 +196,23 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 	double zHit[NZ]; // the rows below are written for the state at idxHit
 #pragma unroll
 	for (int k = 0; k < NZ; k++) zHit[k] = z[k];
+	if constexpr (CKPT == kCkptSpill) {
+		// the survivors of the selection leave LDS before pass 2 starts to overwrite the region with its payload
+#pragma unroll 1
+		for (int p = 0; p < K; p++) {
+			int slot = 0, idx = -1;
+#pragma unroll
+			for (int q = 0; q < K; q++) {
+				slot = q == p ? topB.slot[q] : slot;
+				idx = q == p ? topB.idx[q] : idx;
+			}
+			if (idx >= 0) {
+				double *c = ck + (int64_t)slot * NZ * ld;
+#pragma unroll
+				for (int k = 0; k < NZ; k++) c[k * ld] = ckl[(slot * NZ + k) * 64 + lane];
+			}
+		}
+	}
 
 	// ---- pass 2: re-integrate the selected blocks in increasing order, exact per-sample selection with the states
 	// parked in LDS; samples beyond the lane's last one (its hit) do not take part
@@ -206,9 +234,15 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 		if (!__any(have)) break;
 		cur = have ? nb : cur;
 		const int blk = have ? nb : 0;
-		const double *c = ck + (int64_t)(have ? sl : 0) * NZ * ld;
+		if constexpr (CKPT == kCkptSpill) {
+			const double *c = ck + (int64_t)(have ? sl : 0) * NZ * ld;
 #pragma unroll
-		for (int k = 0; k < NZ; k++) z[k] = c[k * ld];
+			for (int k = 0; k < NZ; k++) z[k] = c[k * ld];
+		} else {
+			const int sl2 = have ? sl : 0;
+#pragma unroll
+			for (int k = 0; k < NZ; k++) z[k] = ckl[(sl2 * NZ + k) * 64 + lane];
+		}
 		if (fast2) resync(); // the block's first sample: as pass 1 did at this boundary
 #pragma unroll 1
 		for (int tt = 0; tt < MB; tt++) {
@@ -419,7 +453,33 @@ static int launch_tb(const DevOptions &o, const asif_hip_solver &S, const Filter
 {
 	static_assert(M::NPBTSS * M::NPSS + 2 == 18 && M::NU == 1, "QP shape 2 x 18");
 	if (a.B <= 0) return 0;
-	hipLaunchKernelGGL((tb_rows_kernel<M>), dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
+	{
+		constexpr size_t region = sizeof(double) * M::NPBTSS * (M::NX + M::NX * M::NX) * 64;
+		const int grid = grid_for(a.B, 1, 64);
+		// a region of their own for the checkpoints costs LDS-limited occupancy (two waves per CU for the segway): taken
+		// when the batch does not need more than that
+		static const int cus = []() {
+			int dev = 0, n = 256;
+			if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+			return n > 0 ? n : 256;
+		}();
+		const int per_cu = (int)((160 * 1024) / (2 * region));
+		const bool both = per_cu >= 1 && (int64_t)grid <= (int64_t)per_cu * cus;
+		hipError_t he = hipSuccess;
+		if (both) {
+			auto kern = tb_rows_kernel<M, kCkptLds2>;
+			if (2 * region > 48 * 1024)
+				he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * region));
+			if (he != hipSuccess) return (int)he;
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 2 * region, stream, o, a);
+		} else {
+			auto kern = tb_rows_kernel<M, kCkptSpill>;
+			if (region > 48 * 1024)
+				he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)region);
+			if (he != hipSuccess) return (int)he;
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(64), region, stream, o, a);
+		}
+	}
 	int e = (int)hipGetLastError();
 	if (e || assemble_only) return e;
 	const TbPolicy<M> p = {a.B, o, a};
