@@ -5,6 +5,8 @@
 #include "qp_kernel.hpp"
 #include "admm_wave.hpp"
 #include "qp_lds.hpp"
+#include "qp_inv.hpp"
+#include <cstdlib>
 
 namespace asif {
 
@@ -165,11 +167,40 @@ static int launch_lds(const asif_hip_solver &S0, const QpArgs &a, hipStream_t st
 	return (int)hipGetLastError();
 }
 
+// nv <= 32, nc <= 32, diagonal cost: two QPs per wave, the inverse of K_J kept by rank-one steps (qp_inv.hpp).
+// Shapes are padded to the next compiled size <NVMAX, NCMAX>.
+template <int NVMAX, int NCMAX>
+static int launch_inv(const asif_hip_solver &S0, const QpArgs &a, hipStream_t stream)
+{
+	asif_hip_solver S = S0;
+	if (S.scaling_iters == 0) S.scaling_iters = 4;
+	else if (S.scaling_iters < 0) S.scaling_iters = 0;
+	const size_t bytes = 2 * inv_half_doubles(NVMAX, NCMAX) * sizeof(double);
+	auto kern = qp_inv_kernel<NVMAX, NCMAX>;
+	hipLaunchKernelGGL(kern, dim3(xcd_grid((a.B + 1) / 2)), dim3(64), bytes, stream, S, a);
+	return (int)hipGetLastError();
+}
+template <int NVMAX>
+static int launch_inv_nc(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
+{
+	return a.nc <= 16 ? launch_inv<NVMAX, 16>(S, a, stream) : launch_inv<NVMAX, 32>(S, a, stream);
+}
+
 // any shape with nv <= 128 and nc <= 128 whose LDS footprint fits 160 KB (86 x 65 with a full cost matrix: 148 KB)
 int launch_qp_lds(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
 {
 	if (a.B <= 0) return 0;
 	if (a.nv < 1 || a.nv > 128 || a.nc < 0 || a.nc > 128 || a.B > 0x7fffffffLL) return ASIF_HIP_EUNSUPPORTED;
+	static const bool inv_off = []() { // developer switch: ASIF_HIP_QP_INV=0 sends the small shapes to the wave-per-QP kernel
+		const char *v = getenv("ASIF_HIP_QP_INV");
+		return v && v[0] == '0';
+	}();
+	if (!a.H && a.nv <= 32 && a.nc <= 32 && !inv_off) {
+		if (a.nv <= 8) return launch_inv_nc<8>(S, a, stream);
+		if (a.nv <= 20) return launch_inv_nc<20>(S, a, stream); // ASIFrobust with four safety functions: 18 x 12
+		if (a.nv <= 24) return launch_inv_nc<24>(S, a, stream); // five: 22 x 15
+		return launch_inv_nc<32>(S, a, stream);
+	}
 	const bool small = a.nv <= 64 && a.nc <= 64;
 	if (a.H) return small ? launch_lds<1, 1, true>(S, a, stream) : launch_lds<2, 2, true>(S, a, stream);
 	return small ? launch_lds<1, 1, false>(S, a, stream) : launch_lds<2, 2, false>(S, a, stream);
