@@ -119,6 +119,7 @@ struct InvQp {
 		for (int j = 0; j < NVMAX; j += 2) {
 			s0 += (ABS ? fabs(col[j * RS]) : col[j * RS]) * va[j];
 			s1 += (ABS ? fabs(col[(j + 1) * RS]) : col[(j + 1) * RS]) * va[j + 1];
+			if (j % 8 == 6) __builtin_amdgcn_sched_barrier(0); // eight terms' loads in flight, not all of them: registers
 		}
 		sync();
 		return isr ? s0 + s1 : 0.0;
@@ -135,9 +136,67 @@ struct InvQp {
 		for (int i = 0; i < NCMAX; i += 2) {
 			s0 += (ABS ? fabs(row[i]) : row[i]) * vr[i];
 			s1 += (ABS ? fabs(row[i + 1]) : row[i + 1]) * vr[i + 1];
+			if (i % 8 == 6) __builtin_amdgcn_sched_barrier(0);
 		}
 		sync();
 		return isv ? s0 + s1 : 0.0;
+	}
+	// one pass over this row's coefficients for a_t . v and |a_t| . |v|
+	__device__ __forceinline__ void row_dot_pair(double v, double &plain, double &absd)
+	{
+		va[t] = isv ? v : 0.0;
+		sync();
+		double s0 = 0.0, s1 = 0.0;
+		const double *col = At + (t < NCMAX ? t : 0);
+#pragma unroll
+		for (int j = 0; j < NVMAX; j++) {
+			const double a = col[j * RS], b = va[j];
+			s0 += a * b;
+			s1 += fabs(a) * fabs(b);
+			if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+		}
+		sync();
+		plain = isr ? s0 : 0.0;
+		absd = isr ? s1 : 0.0;
+	}
+	// one pass over this variable's column for sum_i a_it w_i and sum_i |a_it| |w_i|
+	__device__ __forceinline__ void col_dot_pair(double w, double &plain, double &absd)
+	{
+		vr[t] = isr ? w : 0.0;
+		sync();
+		double s0 = 0.0, s1 = 0.0;
+		const double *row = At + (t < NVMAX ? t : 0) * RS;
+#pragma unroll
+		for (int i = 0; i < NCMAX; i++) {
+			const double a = row[i], b = vr[i];
+			s0 += a * b;
+			s1 += fabs(a) * fabs(b);
+			if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+		}
+		sync();
+		plain = isv ? s0 : 0.0;
+		absd = isv ? s1 : 0.0;
+	}
+	// the outer update's three products in one pass: A'y, |A|'|y| and A'v
+	__device__ __forceinline__ void col_dot_triple(double y_, double v_, double &aty, double &atya, double &atv)
+	{
+		vr[t] = isr ? y_ : 0.0;
+		rb[t] = isr ? v_ : 0.0;
+		sync();
+		double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+		const double *row = At + (t < NVMAX ? t : 0) * RS;
+#pragma unroll
+		for (int i = 0; i < NCMAX; i++) {
+			const double a = row[i], b = vr[i];
+			s0 += a * b;
+			s1 += fabs(a) * fabs(b);
+			s2 += a * rb[i];
+			if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+		}
+		sync();
+		aty = isv ? s0 : 0.0;
+		atya = isv ? s1 : 0.0;
+		atv = isv ? s2 : 0.0;
 	}
 	// K^-1 v for a per-variable vector (entries beyond nv are zero on both sides)
 	__device__ __forceinline__ double kinv_mul(double v)
@@ -149,6 +208,7 @@ struct InvQp {
 		for (int j = 0; j < NVMAX; j += 2) {
 			s0 += Kr[j] * va[j];
 			s1 += Kr[j + 1] * va[j + 1];
+			if (j % 8 == 6) __builtin_amdgcn_sched_barrier(0);
 		}
 		sync();
 		return s0 + s1;
@@ -161,7 +221,10 @@ struct InvQp {
 		sync();
 		const double coef = on ? c * fast_rcp(1.0 + c * vu) * ut : 0.0; // denominator >= 1
 #pragma unroll
-		for (int j = 0; j < NVMAX; j++) Kr[j] -= coef * rb[j];
+		for (int j = 0; j < NVMAX; j++) {
+			Kr[j] -= coef * rb[j];
+			if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+		}
 		sync();
 	}
 
@@ -213,8 +276,11 @@ struct InvQp {
 };
 
 // status / iters follow asif_hip_qp_solve_batch's contract (QPWrapperOsqp::solve, src/qpwrapper_osqp.cpp:225-238)
+#ifndef ASIF_INV_MIN_WAVES
+#define ASIF_INV_MIN_WAVES 1 // waves per SIMD the register allocation is held to (scratch builds try 2)
+#endif
 template <int NVMAX, int NCMAX>
-__global__ __launch_bounds__(64) void qp_inv_kernel(asif_hip_solver S_, QpArgs a)
+__global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip_solver S_, QpArgs a)
 {
 	static_assert(NVMAX % 2 == 0 && NCMAX % 2 == 0 && NVMAX <= 32 && NCMAX <= 32, "padded sizes");
 	extern __shared__ double lds[];
@@ -328,11 +394,14 @@ __global__ __launch_bounds__(64) void qp_inv_kernel(asif_hip_solver S_, QpArgs a
 		for (int inner = 0; inner < kLdsMaxInner; inner++) {
 			if (!__any(inn)) break;
 			// ---- gradient of the inner objective
-			const double ax = s.row_dot(s.x);
+			double ax, axa = 0.0, atr, atra = 0.0; // the |.| products feed the scale and floor of the first step only
+			if (inner == 0) s.row_dot_pair(s.x, ax, axa);
+			else ax = s.row_dot(s.x);
 			const double sr = ax + s.y * s.imu;
 			const double rr = s.isr ? s.mu * (sr - fmin(fmax(sr, s.l), s.u)) : 0.0;
 			const bool actr = s.isr && (sr < s.l || sr > s.u);
-			const double atr = s.col_dot(rr);
+			if (inner == 0) s.col_dot_pair(rr, atr, atra);
+			else atr = s.col_dot(rr);
 			const double px = s.Pd * s.x;
 			const double sb = s.ab * s.x + s.yb * s.imub;
 			const double rbv = s.isv ? s.mub * (sb - fmin(fmax(sb, s.lbs), s.ubs)) : 0.0;
@@ -341,10 +410,8 @@ __global__ __launch_bounds__(64) void qp_inv_kernel(asif_hip_solver S_, QpArgs a
 			const double gn = hmax(fabs(g));
 			if (inner == 0) {
 				// scale of the gradient's own terms and its rounding floor, once per inner solve (qp_lds.hpp)
-				const double atra = s.template col_dot<true>(rr);
 				const double gs = s.isv ? fmax(fabs(px), fmax(fabs(s.q), atra + fabs(s.ab * rbv))) : 0.0;
 				const double gsc = 1.0 + hmax(gs);
-				const double axa = s.template row_dot<true>(s.x);
 				const double bd = sr < s.l ? fabs(s.l) : (sr > s.u ? fabs(s.u) : 0.0);
 				const double er = s.isr ? 2.2e-16 * s.mu * (axa + fabs(s.y) * s.imu + bd) : 0.0;
 				const double fl = s.template col_dot<true>(er);
@@ -538,9 +605,8 @@ __global__ __launch_bounds__(64) void qp_inv_kernel(asif_hip_solver S_, QpArgs a
 			ndy = fabs(vcert);
 			lhs = vcert > 0.0 ? s.u * vcert : (vcert < 0.0 ? s.l * vcert : 0.0);
 		}
-		const double aty = s.col_dot(ynew);
-		const double atv = s.col_dot(vcert);
-		const double atya = s.template col_dot<true>(ynew);
+		double aty, atv, atya;
+		s.col_dot_triple(ynew, vcert, aty, atya, atv);
 		const double px = s.Pd * s.x, pxa = fabs(px);
 		double dua = 0.0, nd = 0.0, natv = 0.0, ybn;
 		{
