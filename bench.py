@@ -437,7 +437,8 @@ def bench_qp(args, grp, dev):
     it = iters.cpu().numpy()
     kernel = ("wave-per-QP, plain ADMM (admm_wave.hpp), then qp_inv.hpp / qp_lds.hpp for what it leaves at max_iter"
               if (args.lanes == 64 and solver.polish == 0)
-              else "two QPs per wave, K_J^-1 by rank-one steps in registers (qp_inv.hpp)" if ((args.lanes == 64 or nv > 3) and nv <= 32 and nc <= 32)
+              else "two QPs per wave, K_J^-1 by rank-one steps in registers (qp_inv.hpp)"
+              if ((args.lanes == 64 or nv > 3) and nv <= 32 and nc <= 32 and os.environ.get("ASIF_HIP_QP_INV") != "0")
               else "wave-per-QP, factor in LDS (qp_lds.hpp)" if (args.lanes == 64 or nv > 3)
               else "in-register (gi_small.hpp + admm_small.hpp)")
     tag = f"qp_{args.shape}" + ("_wave" if args.lanes == 64 else "") + (f"_polish{solver.polish}" if args.polish >= 0 else "")
