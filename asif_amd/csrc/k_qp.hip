@@ -169,15 +169,20 @@ static int launch_lds(const asif_hip_solver &S0, const QpArgs &a, hipStream_t st
 
 // nv <= 32, nc <= 32, diagonal cost: two QPs per wave, the inverse of K_J kept by rank-one steps (qp_inv.hpp).
 // Shapes are padded to the next compiled size <NVMAX, NCMAX>.
-template <int NVMAX, int NCMAX>
+template <int NVMAX, int NCMAX, int HW = 32>
 static int launch_inv(const asif_hip_solver &S0, const QpArgs &a, hipStream_t stream)
 {
 	asif_hip_solver S = S0;
 	if (S.scaling_iters == 0) S.scaling_iters = 4;
 	else if (S.scaling_iters < 0) S.scaling_iters = 0;
-	const size_t bytes = 2 * inv_half_doubles(NVMAX, NCMAX) * sizeof(double);
-	auto kern = qp_inv_kernel<NVMAX, NCMAX>;
-	hipLaunchKernelGGL(kern, dim3(xcd_grid((a.B + 1) / 2)), dim3(64), bytes, stream, S, a);
+	constexpr int QPW = 64 / HW;
+	const size_t bytes = QPW * inv_half_doubles(NVMAX, NCMAX, HW) * sizeof(double);
+	auto kern = qp_inv_kernel<NVMAX, NCMAX, HW>;
+	if (bytes > 48 * 1024) {
+		hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+		if (e != hipSuccess) return (int)e;
+	}
+	hipLaunchKernelGGL(kern, dim3(xcd_grid((a.B + QPW - 1) / QPW)), dim3(64), bytes, stream, S, a);
 	return (int)hipGetLastError();
 }
 template <int NVMAX>
@@ -200,6 +205,12 @@ int launch_qp_lds(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
 		if (a.nv <= 20) return launch_inv_nc<20>(S, a, stream); // ASIFrobust with four safety functions: 18 x 12
 		if (a.nv <= 24) return launch_inv_nc<24>(S, a, stream); // five: 22 x 15
 		return launch_inv_nc<32>(S, a, stream);
+	}
+	// 32 < nv or nc <= 64, diagonal cost: the same kernel with the whole wave on one problem (ASIFrealizable's lifted
+	// problems: 38 x 29 on the 100 Hz kernel, 62 x 47 on the 50-point one)
+	if (!a.H && a.nv <= 64 && a.nc <= 64 && !inv_off) {
+		if (a.nv <= 40) return a.nc <= 32 ? launch_inv<40, 32, 64>(S, a, stream) : launch_inv<40, 64, 64>(S, a, stream);
+		return a.nc <= 48 ? launch_inv<64, 48, 64>(S, a, stream) : launch_inv<64, 64, 64>(S, a, stream);
 	}
 	const bool small = a.nv <= 64 && a.nc <= 64;
 	if (a.H) return small ? launch_lds<1, 1, true>(S, a, stream) : launch_lds<2, 2, true>(S, a, stream);

@@ -38,9 +38,10 @@
 
 namespace asif {
 
-__host__ __device__ inline size_t inv_half_doubles(int nvmax, int ncmax)
+// LDS doubles of one problem: hw = lanes that own it (32: two problems per wave; 64: one, for 32 < nv, nc <= 64)
+__host__ __device__ inline size_t inv_half_doubles(int nvmax, int ncmax, int hw = 32)
 {
-	return (size_t)nvmax * (ncmax + 1) + 3 * 32 + 5 * 64 + (2 + 2 * 64);
+	return (size_t)nvmax * (ncmax + 1) + 3 * hw + 5 * 2 * hw + (2 + 4 * hw);
 }
 // 1 / d by the hardware seed and two Newton steps: full precision for a normal operand away from the ends of the range
 // (0, denormals and infinities come back as NaN / inf -- every caller's comparisons treat that as "no value")
@@ -58,38 +59,51 @@ __device__ __forceinline__ double swap16(double v) // lane i <-> lane i ^ 16 (in
 	const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
 	return __hiloint2double(hi, lo);
 }
+// reductions over the HW lanes that own a problem: four DPP steps inside the rows of 16, one ds_swizzle across the two
+// rows of a 32-lane group, and for HW = 64 the two groups through v_readlane (the group results are wave-uniform)
+template <int HW>
 __device__ __forceinline__ double hsum(double v)
 {
 	v += dpp_xchg<1>(v);
 	v += dpp_xchg<2>(v);
 	v += dpp_xchg<4>(v);
 	v += dpp_xchg<8>(v);
-	return v + swap16(v);
+	v += swap16(v);
+	if constexpr (HW == 64) v = lane_get(v, 0) + lane_get(v, 32);
+	return v;
 }
+template <int HW>
 __device__ __forceinline__ double hmax(double v)
 {
 	v = fmax(v, dpp_xchg<1>(v));
 	v = fmax(v, dpp_xchg<2>(v));
 	v = fmax(v, dpp_xchg<4>(v));
 	v = fmax(v, dpp_xchg<8>(v));
-	return fmax(v, swap16(v));
+	v = fmax(v, swap16(v));
+	if constexpr (HW == 64) v = fmax(lane_get(v, 0), lane_get(v, 32));
+	return v;
 }
+template <int HW>
 __device__ __forceinline__ double hmin(double v)
 {
 	v = fmin(v, dpp_xchg<1>(v));
 	v = fmin(v, dpp_xchg<2>(v));
 	v = fmin(v, dpp_xchg<4>(v));
 	v = fmin(v, dpp_xchg<8>(v));
-	return fmin(v, swap16(v));
+	v = fmin(v, swap16(v));
+	if constexpr (HW == 64) v = fmin(lane_get(v, 0), lane_get(v, 32));
+	return v;
 }
-// the 32 ballot bits of this lane's half
-__device__ __forceinline__ unsigned hballot(bool p, int h)
+// the ballot bits of this lane's group (HW = 32: its half of the wave's 64)
+template <int HW>
+__device__ __forceinline__ unsigned long long hballot(bool p, int h)
 {
 	const unsigned long long b = __ballot(p);
-	return h ? (unsigned)(b >> 32) : (unsigned)b;
+	if constexpr (HW == 64) return b;
+	return h ? (b >> 32) : (b & 0xffffffffull);
 }
 
-template <int NVMAX, int NCMAX>
+template <int NVMAX, int NCMAX, int HW>
 struct InvQp {
 	static constexpr int RS = NCMAX + 1; // odd: the column walk of a variable lane and the row walk of a row lane are conflict-free
 	// this half's LDS
@@ -265,8 +279,8 @@ struct InvQp {
 			Pd *= Dt * Dt;
 			q *= Dt;
 			D *= Dt;
-			const double cm = hsum(isv ? fabs(Pd) : 0.0) / (double)nv;
-			const double qn = limit_scaling(hmax(isv ? fabs(q) : 0.0));
+			const double cm = hsum<HW>(isv ? fabs(Pd) : 0.0) / (double)nv;
+			const double qn = limit_scaling(hmax<HW>(isv ? fabs(q) : 0.0));
 			const double ct = pow2_floor_inv(limit_scaling(fmax(cm, qn)));
 			Pd *= ct;
 			q *= ct;
@@ -279,19 +293,19 @@ struct InvQp {
 #ifndef ASIF_INV_MIN_WAVES
 #define ASIF_INV_MIN_WAVES 1 // waves per SIMD the register allocation is held to (scratch builds try 2)
 #endif
-template <int NVMAX, int NCMAX>
+template <int NVMAX, int NCMAX, int HW = 32>
 __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip_solver S_, QpArgs a)
 {
-	static_assert(NVMAX % 2 == 0 && NCMAX % 2 == 0 && NVMAX <= 32 && NCMAX <= 32, "padded sizes");
+	static_assert((HW == 32 || HW == 64) && NVMAX % 2 == 0 && NCMAX % 2 == 0 && NVMAX <= HW && NCMAX <= HW, "padded sizes");
 	extern __shared__ double lds[];
-	InvQp<NVMAX, NCMAX> s;
-	constexpr int RS = NCMAX + 1;
-	const int lane = threadIdx.x, h = lane >> 5, t = lane & 31;
+	InvQp<NVMAX, NCMAX, HW> s;
+	constexpr int RS = NCMAX + 1, QPW = 64 / HW; // problems per wave
+	const int lane = threadIdx.x, h = lane / HW, t = lane % HW;
 	const int nv = a.nv, nc = a.nc;
-	const int64_t npair = (a.B + 1) / 2;
+	const int64_t npair = (a.B + QPW - 1) / QPW;
 	const int64_t pi = xcd_contiguous_index(blockIdx.x, npair);
 	if (pi >= npair) return; // wave-uniform (one wave per workgroup)
-	int64_t qi = 2 * pi + h;
+	int64_t qi = QPW * pi + h;
 	bool keep = qi < a.B; // an odd batch leaves the second half of its last wave without a problem
 	if (!keep) qi = a.B - 1;
 	if (a.only_status != 0 && a.status[qi] != a.only_status) keep = false; // second pass: already decided
@@ -302,16 +316,16 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 	s.nv = nv;
 	s.nc = nc;
 	{
-		double *p = lds + (size_t)h * inv_half_doubles(NVMAX, NCMAX);
+		double *p = lds + (size_t)h * inv_half_doubles(NVMAX, NCMAX, HW);
 		s.At = p; p += (size_t)NVMAX * RS;
-		s.va = p; p += 32;
-		s.vr = p; p += 32;
-		s.rb = p; p += 32;
-		s.ls_s = p; p += 64;
-		s.ls_d = p; p += 64;
-		s.ls_l = p; p += 64;
-		s.ls_u = p; p += 64;
-		s.ls_m = p; p += 64;
+		s.va = p; p += HW;
+		s.vr = p; p += HW;
+		s.rb = p; p += HW;
+		s.ls_s = p; p += 2 * HW;
+		s.ls_d = p; p += 2 * HW;
+		s.ls_l = p; p += 2 * HW;
+		s.ls_u = p; p += 2 * HW;
+		s.ls_m = p; p += 2 * HW;
 		s.ls_t = p;
 	}
 	// ---- form translation (src/qpwrapper_osqp.cpp:263-376): P = 2H, q = c, rows [A; I], l = [b; lb], u = [inf | b; ub]
@@ -322,7 +336,7 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 	{
 		double lo = -kInfty, hi = kInfty;
 		// padding rows and columns are zero
-		for (int e = t; e < NVMAX * RS; e += 32) s.At[e] = 0.0;
+		for (int e = t; e < NVMAX * RS; e += HW) s.At[e] = 0.0;
 		s.sync();
 		if (s.isr) {
 			for (int j = 0; j < nv; j++) {
@@ -332,7 +346,7 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 			}
 			lo = a.b[(int64_t)t * ld + qi];
 			dom = fma(lo, 1e160, dom);
-			hi = ((a.be_mask >> t) & 1ull) ? lo : kInfty;
+			hi = ((a.be_mask >> t) & 1ull) ? lo : kInfty; // t < nc <= 64: the first mask word
 		}
 		s.l = lo;
 		s.u = hi;
@@ -349,7 +363,7 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 		dom = fma(s.q, 1e160, fma(s.Pd, 1e160, dom));
 		nanb = (s.lbs != s.lbs) | (s.ubs != s.ubs);
 	}
-	const bool outside = hballot(nanb | !(fabs(dom) < __builtin_huge_val()), h) != 0;
+	const bool outside = hballot<HW>(nanb | !(fabs(dom) < __builtin_huge_val()), h) != 0;
 	s.va[t] = 0.0;
 	s.vr[t] = 0.0;
 	s.rb[t] = 0.0;
@@ -407,11 +421,11 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 			const double rbv = s.isv ? s.mub * (sb - fmin(fmax(sb, s.lbs), s.ubs)) : 0.0;
 			const bool actb = s.isv && (sb < s.lbs || sb > s.ubs);
 			const double g = s.isv ? px + s.q + (s.x - s.xh) * ig + atr + s.ab * rbv : 0.0;
-			const double gn = hmax(fabs(g));
+			const double gn = hmax<HW>(fabs(g));
 			if (inner == 0) {
 				// scale of the gradient's own terms and its rounding floor, once per inner solve (qp_lds.hpp)
 				const double gs = s.isv ? fmax(fabs(px), fmax(fabs(s.q), atra + fabs(s.ab * rbv))) : 0.0;
-				const double gsc = 1.0 + hmax(gs);
+				const double gsc = 1.0 + hmax<HW>(gs);
 				const double bd = sr < s.l ? fabs(s.l) : (sr > s.u ? fabs(s.u) : 0.0);
 				const double er = s.isr ? 2.2e-16 * s.mu * (axa + fabs(s.y) * s.imu + bd) : 0.0;
 				const double fl = s.template col_dot<true>(er);
@@ -419,7 +433,7 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 				const double eb = 2.2e-16 * s.mub * (fabs(s.ab * s.x) + fabs(s.yb) * s.imub + bdb);
 				const double f = s.isv ? fl + fabs(s.ab) * eb : 0.0;
 				gscale = gsc;
-				gfloor = hmax(f) + 2.2e-16 * gsc;
+				gfloor = hmax<HW>(f) + 2.2e-16 * gsc;
 			}
 			inn = inn && !(gn <= 0.1 * tol * gscale || gn <= 8.0 * gfloor) && newton < max_newton;
 			INV_T(0)
@@ -427,7 +441,7 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 			// ---- K_J^-1 for the current active set
 			{
 				const bool gone = (pactr && !actr) || (pactb && !actb);
-				const bool rebuild = inn && (!kvalid || hballot(gone, h) != 0);
+				const bool rebuild = inn && (!kvalid || hballot<HW>(gone, h) != 0);
 				if (__any(rebuild)) {
 					const double dg = s.isv ? fast_rcp(s.Pd + ig) : 0.0;
 #pragma unroll
@@ -441,9 +455,9 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 				s.vr[t] = s.mub * s.ab * s.ab;
 				s.sync();
 				while (__any(pendb)) {
-					const unsigned m = hballot(pendb, h);
+					const unsigned long long m = hballot<HW>(pendb, h);
 					const bool on = m != 0;
-					const int j = on ? __ffs(m) - 1 : 0;
+					const int j = on ? __ffsll((long long)m) - 1 : 0;
 					if (on && t == j) {
 #pragma unroll
 						for (int k = 0; k < NVMAX; k++) s.va[k] = s.Kr[k];
@@ -458,13 +472,13 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 				s.vr[t] = s.mu;
 				s.sync();
 				while (__any(pendr)) {
-					const unsigned m = hballot(pendr, h);
+					const unsigned long long m = hballot<HW>(pendr, h);
 					const bool on = m != 0;
-					const int i = on ? __ffs(m) - 1 : 0;
+					const int i = on ? __ffsll((long long)m) - 1 : 0;
 					const double at = s.isv ? s.At[t * RS + i] : 0.0;
 					const double c = s.vr[i];
 					const double ut = s.kinv_mul(at);
-					const double vu = hsum(at * ut);
+					const double vu = hsum<HW>(at * ut);
 					s.rank_one(ut, vu, c, on);
 					pendr = pendr && t != i;
 				}
@@ -492,22 +506,22 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 				const double s1 = sr + dl, s1b = sb + dlb;
 				const double fr = s.isr ? s.mu * dl * (s1 - fmin(fmax(s1, s.l), s.u)) : 0.0;
 				const double fb = s.isv ? s.mub * dlb * (s1b - fmin(fmax(s1b, s.lbs), s.ubs)) : 0.0;
-				const double f1 = hsum(qat + a1t + fr + fb);
+				const double f1 = hsum<HW>(qat + a1t + fr + fb);
 				const bool cut = inn && !(f1 < 0.0);
 				INV_T(3)
 				if (__any(cut)) {
-					const double qa = hsum(qat), a1 = hsum(a1t);
+					const double qa = hsum<HW>(qat), a1 = hsum<HW>(a1t);
 					// all rows (general, then bounds) side by side in LDS; this lane's breakpoints in (0, 1]
 					s.ls_s[t] = sr;
 					s.ls_d[t] = s.isr ? dl : 0.0;
 					s.ls_l[t] = s.l;
 					s.ls_u[t] = s.u;
 					s.ls_m[t] = s.isr ? s.mu * dl : 0.0; // mu_i dl_i
-					s.ls_s[32 + t] = sb;
-					s.ls_d[32 + t] = s.isv ? dlb : 0.0;
-					s.ls_l[32 + t] = s.lbs;
-					s.ls_u[32 + t] = s.ubs;
-					s.ls_m[32 + t] = s.isv ? s.mub * dlb : 0.0;
+					s.ls_s[HW + t] = sb;
+					s.ls_d[HW + t] = s.isv ? dlb : 0.0;
+					s.ls_l[HW + t] = s.lbs;
+					s.ls_u[HW + t] = s.ubs;
+					s.ls_m[HW + t] = s.isv ? s.mub * dlb : 0.0;
 					double bp[4];
 					{
 						const double idl = fast_rcp(dl), idlb = fast_rcp(dlb); // a zero or denormal dl gives NaN: no breakpoint
@@ -524,9 +538,9 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 #pragma unroll
 					for (int e = 0; e < 4; e++) {
 						const bool v = bp[e] <= 1.0;
-						const unsigned m = hballot(v, h);
-						if (v) s.ls_t[npt + __popc(m & ((1u << t) - 1u))] = bp[e];
-						npt += __popc(m);
+						const unsigned long long m = hballot<HW>(v, h);
+						if (v) s.ls_t[npt + __popcll(m & ((1ull << t) - 1ull))] = bp[e];
+						npt += __popcll(m);
 					}
 					s.sync();
 					auto dphi = [&](double tt) {
@@ -539,7 +553,7 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 							f1c += s.ls_m[i + 1] * (su - fmin(fmax(su, s.ls_l[i + 1]), s.ls_u[i + 1]));
 						}
 #pragma unroll 2
-						for (int i = 32; i < 32 + NVMAX; i += 2) { // bounds
+						for (int i = HW; i < HW + NVMAX; i += 2) { // bounds
 							const double st = s.ls_s[i] + tt * s.ls_d[i];
 							f0 += s.ls_m[i] * (st - fmin(fmax(st, s.ls_l[i]), s.ls_u[i]));
 							const double su = s.ls_s[i + 1] + tt * s.ls_d[i + 1];
@@ -549,7 +563,7 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 					};
 					// bracket of the zero of phi' among {0} u breakpoints u {1}: every lane evaluates phi' at its own point
 					double tlo = 0.0, flo = 0.0, thi = 2.0, fhi = 0.0;
-					for (int base = 0; __any(base < npt); base += 32) {
+					for (int base = 0; __any(base < npt); base += HW) {
 						const bool mine = base + t < npt;
 						const double tb = mine ? s.ls_t[base + t] : 1.0;
 						const double fbv = dphi(tb);
@@ -566,9 +580,9 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 						// best lower bracket: largest t with f < 0; best upper: smallest t with f >= 0
 						const double cl = (isbp && fbv < 0.0) ? tb : -1.0;
 						const double ch = (isbp && fbv >= 0.0) ? tb : 3.0;
-						const double gl = hmax(cl), gh = hmin(ch);
-						const double flc = hmax(cl == gl ? fbv : -1e300); // f at that breakpoint (negative: max picks it among ties)
-						const double fhc = hmin(ch == gh ? fbv : 1e300);
+						const double gl = hmax<HW>(cl), gh = hmin<HW>(ch);
+						const double flc = hmax<HW>(cl == gl ? fbv : -1e300); // f at that breakpoint (negative: max picks it among ties)
+						const double fhc = hmin<HW>(ch == gh ? fbv : 1e300);
 						if (gl > tlo) { tlo = gl; flo = flc; }
 						if (gh < thi) { thi = gh; fhi = fhc; }
 					}
@@ -634,8 +648,8 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 			s.yb = ybn;
 			s.xh = s.x;
 		}
-		pri = hmax(pri); nax = hmax(nax); dua = hmax(dua); nd = hmax(nd);
-		ndy = hmax(ndy); lhs = hsum(lhs); natv = hmax(natv);
+		pri = hmax<HW>(pri); nax = hmax<HW>(nax); dua = hmax<HW>(dua); nd = hmax<HW>(nd);
+		ndy = hmax<HW>(ndy); lhs = hsum<HW>(lhs); natv = hmax<HW>(natv);
 		const double rp = pri / (1.0 + nax), rd = dua / (1.0 + nd);
 		int st = 0;
 		if (rp <= tol && rd <= tol) st = kStatusSolved;
@@ -645,8 +659,8 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 			best_res = fmin(best_res, fmax(rp, rd));
 			status = st;
 		}
-		const double mumin = hmin(fmin(s.isr ? s.mu : 1e300, s.isv ? s.mub : 1e300));
-		const double mumax = hmax(fmax(s.isr ? s.mu : 0.0, s.isv ? s.mub : 0.0));
+		const double mumin = hmin<HW>(fmin(s.isr ? s.mu : 1e300, s.isv ? s.mub : 1e300));
+		const double mumax = hmax<HW>(fmax(s.isr ? s.mu : 0.0, s.isv ? s.mub : 0.0));
 		if (run && st == 0) {
 			double f = 1.0, cap = kLdsMuMax;
 			if (rp <= tol) {
