@@ -227,6 +227,109 @@ struct BackupLoop {
 		eulerStepT<false>(o, z, none, 0.0);
 	}
 
+	// ---- the Euler step in two roles (k_tb.hip: tb_rows_split_kernel).  x does not depend on Q, so the step of
+	// [x; vec Q] splits into the step of x -- controller, soft saturation, f, g -- and the step of Q, which needs
+	// the gradients at the same x, the same saturation values and the same sin / cos.  Expressions as in closedLoopT /
+	// eulerStepT above, term for term, so that the two roles together give what the one step gives.
+	struct StepRecord { // what the x role hands the Q role for one step: what the gradients at the step's state need
+		double xg[2];      // the two states they depend on directly (M::kGradStates)
+		double uSat, DuSat; // the saturated input and its slope there
+		double s, c;        // sin / cos of the model's angle there
+		double iden, rg;    // the two reciprocals of the model's shared terms there
+	};
+	static constexpr int kRecordDoubles = 8;
+	// fast step of x alone (trig carried along the steps, soft saturation's short forms); returns the record of this step
+	__device__ __forceinline__ static StepRecord stepX(const DevOptions &o, double (&x)[NX], TrigCarry &cy)
+	{
+#pragma clang fp contract(on)
+		static_assert(!M::kInputOnLastState, "role split is written for the general closed loop (the segway)");
+		StepRecord r;
+		double f[NX], g[NX], u[1], Du[NX];
+		r.xg[0] = x[M::kGradStates[0]];
+		r.xg[1] = x[M::kGradStates[1]];
+		M::backupController(o, x, u, Du);
+		saturateSoft<true>(o, u[0], r.uSat, r.DuSat);
+		sincos_carry(x[M::kTrigAngle], cy);
+		r.s = cy.s;
+		r.c = cy.c;
+		typename M::Trig t;
+		t.s1 = cy.s;
+		t.c1 = cy.c;
+		t.s2 = 2.0 * t.s1 * t.c1;
+		t.c2 = (t.c1 - t.s1) * (t.c1 + t.s1);
+		const typename M::Shared h = M::dynamicsT(x, t, f, g);
+		r.iden = h.iden;
+		r.rg = h.rg;
+#pragma unroll
+		for (int i = 0; i < NX; i++) {
+			const double fcl = unitRow(i) ? f[i] : g[i] * r.uSat + f[i];
+			x[i] = fcl * o.trajDt + x[i];
+		}
+		return r;
+	}
+	// the same step's update of Q (vec Q in q, column-major) from the record
+	__device__ __forceinline__ static void stepQ(const DevOptions &o, const StepRecord &r, double (&q)[NX * NX])
+	{
+#pragma clang fp contract(on)
+		double xr[NX], g[NX], Df[NX * NX], Dg[NX * NX], u[1], Du[NX], DfCL[NX * NX], zd[NX * NX];
+#pragma unroll
+		for (int i = 0; i < NX; i++) xr[i] = 0.0;
+		xr[M::kGradStates[0]] = r.xg[0];
+		xr[M::kGradStates[1]] = r.xg[1];
+		M::backupController(o, xr, u, Du); // Du is the constant gain; u is not used here
+		typename M::Trig t;
+		t.s1 = r.s;
+		t.c1 = r.c;
+		t.s2 = 2.0 * t.s1 * t.c1;
+		t.c2 = (t.c1 - t.s1) * (t.c1 + t.s1);
+		typename M::Shared h;
+		h.iden = r.iden;
+		h.rg = r.rg;
+		M::gainT(t, h, g);
+		M::gradientsGiven(xr, t, h, Df, Dg);
+#pragma unroll
+		for (int i = 0; i < NX; i++) {
+			if (unitRow(i)) continue; // row i of DfCL Q is row i+1 of Q
+#pragma unroll
+			for (int j = 0; j < NX; j++) {
+				const double gd = g[i] * r.DuSat * Du[j];
+				DfCL[i + j * NX] = Df[i + j * NX] + (dgEntry(i + j * NX) ? Dg[i + j * NX] * r.uSat + gd : gd);
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < NX; i++)
+#pragma unroll
+			for (int j = 0; j < NX; j++) {
+				if (unitRow(i)) {
+					zd[i + j * NX] = q[i + 1 + j * NX];
+					continue;
+				}
+				double sacc = 0.0;
+#pragma unroll
+				for (int k = 0; k < NX; k++) sacc += DfCL[i + k * NX] * q[k + j * NX];
+				zd[i + j * NX] = sacc;
+			}
+#pragma unroll
+		for (int k = 0; k < NX * NX; k++) q[k] = zd[k] * o.trajDt + q[k];
+	}
+
+	// the fused fast step of a model that has the two roles: the roles themselves, back to back in one wave (the
+	// compiler merges what they compute twice), so that a trajectory is the same bits whichever kernel integrates it
+	__device__ __forceinline__ static void eulerStepRoles(const DevOptions &o, double (&z)[NZ], TrigCarry &cy)
+	{
+		double x[NX], q[NX * NX];
+#pragma unroll
+		for (int i = 0; i < NX; i++) x[i] = z[i];
+#pragma unroll
+		for (int i = 0; i < NX * NX; i++) q[i] = z[NX + i];
+		const StepRecord r = stepX(o, x, cy);
+		stepQ(o, r, q);
+#pragma unroll
+		for (int i = 0; i < NX; i++) z[i] = x[i];
+#pragma unroll
+		for (int i = 0; i < NX * NX; i++) z[NX + i] = q[i];
+	}
+
 	// one forward-Euler step of [x; vec Q] (src/asif_implicit.cpp:470-477: rhs*dt + previous); t is the time
 	// the reference stamps on this rhs (src/asif_implicit_robust.cpp:567: i*backTrajDt for the step INTO sample i)
 	// POISON: the model's sin / cos never branch; out-of-range arguments turn the state into NaN (see sincos_fast)

@@ -12,12 +12,108 @@
 //   Lanes of a wave stop at different samples; the loop runs to the wave's slowest lane.
 // Stage 2  qp_policy_kernel<2,18,G> with the TB epilogue: rc 2 / 1 / -1 / raw solver status / -3 and the
 //   saturated backup controller on every failure (:290-361).
+#include <cstdlib>
 #include <type_traits>
 #include "backup_traj.hpp"
 #include "qp_kernel.hpp"
 
 namespace asif {
 
+
+// ---- pass 1 in two roles (models that declare kTbSplitRoles: the segway) ------------------------------------------
+// One wave per 64 instances runs at the issue rate of ONE instruction stream, and at the BASELINE batch (32 768
+// instances per GPU = 512 waves) half of the chip's 1 024 SIMDs hold no wave at all.  The state x of the backup
+// trajectory does not depend on its sensitivity Q; measured on C4, integrating x alone takes 0.19 ms of the fused pass's
+// 0.335.  So the pass is dealt to TWO waves of one workgroup, on two SIMDs: wave 0 integrates x (controller, saturation,
+// f, g, margins, hit test, the running selection of critical blocks) and leaves a record of every step in an LDS ring;
+// wave 1, one block of MB steps behind, evaluates the gradients at the recorded states and integrates Q.  A workgroup
+// barrier per block hands a ring buffer over (two buffers: the x wave fills one while the Q wave reads the other).
+// Block checkpoints: the x wave decides which block enters the selection and stores the x part; the slot travels with
+// the record and the Q wave stores its part.  After the pass the Q wave publishes its final Q and retires; the x wave
+// goes on alone with pass 2 and the rows exactly as the fused kernel (same code below).  A range / NaN alarm from either
+// role sends the x wave through the fused, checking pass instead.  Taken only when the grid is small enough that the
+// second wave has a SIMD to itself (two workgroups of 77 KB per CU); larger batches run the fused kernel.
+template <class M, class = void>
+struct tb_split_roles : std::false_type {};
+template <class M>
+struct tb_split_roles<M, std::enable_if_t<M::kTbSplitRoles>> : std::true_type {};
+
+template <class M>
+struct TbSplitLds {
+	static constexpr int NX = M::NX, NZ = NX + NX * NX, K = M::NPBTSS, MB = M::kTrajBlock, NF = BackupLoop<M>::kRecordDoubles;
+	static constexpr int kSlots = K * NZ * 64;          // checkpoints (pass 1), payload (pass 2): doubles
+	static constexpr int kRing = 2 * MB * NF * 64;      // records of two blocks of steps: doubles
+	static constexpr int kCtl = 2 * MB * 64 + 64 + 4;   // per-step control words, last-block slots, stop / alarm flags: ints
+	static constexpr size_t bytes() { return sizeof(double) * (kSlots + kRing) + sizeof(int) * kCtl; }
+};
+
+// The Q wave of the two-role pass (see TbSplitLds above): one block of steps behind the x wave, it evaluates the
+// gradients at the recorded states and integrates the sensitivity.  Barriers: one per block (A_b), one after the x
+// wave has published every lane's last-block slot (B1), one after this wave has published its final Q (B2) -- the x
+// wave executes exactly the same sequence.
+template <class M>
+__device__ __forceinline__ void tb_q_role(const DevOptions &o, const double *ring, const int *ctl, const int *lastSlot,
+                                          int *flags, double *ckl, double *qout, int lane, int npBT)
+{
+	using BL = BackupLoop<M>;
+	constexpr int NX = M::NX, NZ = NX + NX * NX, MB = M::kTrajBlock, NF = BL::kRecordDoubles;
+	double q[NX * NX], qs[NX * NX]; // Q now, and at the first sample of the current block
+#pragma unroll
+	for (int e = 0; e < NX * NX; e++) q[e] = qs[e] = (e % (NX + 1) == 0) ? 1.0 : 0.0;
+	const int nblk = (npBT + MB - 1) / MB;
+	auto keep = [&](int slot) { // Q part of the checkpoint of the block that just closed
+#pragma unroll
+		for (int e = 0; e < NX * NX; e++) ckl[(slot * NZ + NX + e) * 64 + lane] = qs[e];
+	};
+#pragma unroll 1
+	for (int b = 0; b < nblk; b++) {
+		__syncthreads(); // A_b: buffer b & 1 holds block b (or the stop flag)
+		const int buf = b & 1;
+		if (flags[buf]) break; // wave-uniform
+#pragma unroll 1
+		for (int k = 0; k < MB; k++) {
+			const int s = b * MB + k;
+			if (s == 0 || s >= npBT) continue; // wave-uniform
+			const int c = ctl[(buf * MB + k) * 64 + lane];
+			const bool act = (c & 1) != 0;
+			typename BL::StepRecord r;
+			const double *rec = ring + (size_t)((buf * MB + k) * NF) * 64 + lane;
+			r.xg[0] = rec[0 * 64];
+			r.xg[1] = rec[1 * 64];
+			r.uSat = rec[2 * 64];
+			r.DuSat = rec[3 * 64];
+			r.s = rec[4 * 64];
+			r.c = rec[5 * 64];
+			r.iden = rec[6 * 64];
+			r.rg = rec[7 * 64];
+			double qn[NX * NX];
+#pragma unroll
+			for (int e = 0; e < NX * NX; e++) qn[e] = q[e];
+			BL::stepQ(o, r, qn); // a lane that did not step holds a stale record: computed and dropped
+#pragma unroll
+			for (int e = 0; e < NX * NX; e++) q[e] = act ? qn[e] : q[e];
+			if (k == 0 && b > 0) { // the step into the first sample of block b closed block b - 1
+				const int slot = (c >> 8) - 1;
+				if (act && slot >= 0) keep(slot);
+#pragma unroll
+				for (int e = 0; e < NX * NX; e++) qs[e] = act ? q[e] : qs[e];
+			}
+		}
+	}
+	__syncthreads(); // B1: every lane's last-block slot is published
+	{
+		const int slot = lastSlot[lane];
+		if (slot >= 0) keep(slot);
+	}
+	bool bad = false;
+#pragma unroll
+	for (int e = 0; e < NX * NX; e++) {
+		qout[e * 64 + lane] = q[e];
+		bad = bad || (q[e] != q[e]);
+	}
+	if (__any(bad) && lane == 0) flags[2] = 1;
+	__syncthreads(); // B2: final Q and the alarm flag are published
+}
 
 // CKPT: where the block-start states of pass 1's running selection live (K slots of NZ doubles per lane).
 //   kCkptLds2  in LDS, in a region of their own next to pass 2's payload (2 x K NZ 64 doubles = 80 KB for the segway:
@@ -29,9 +125,10 @@ namespace asif {
 // the trajectory, nearly every 4-sample block does -- 171 MB of writes per 32 768 instances (PMC), 5.2 KB per instance.
 constexpr int kCkptLds2 = 1, kCkptSpill = 2;
 
-template <class M, int CKPT>
-__global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArgs a)
+template <class M, int CKPT, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 128 : 64) void tb_rows_kernel(DevOptions o_arg, FilterArgs a)
 {
+	static_assert(!SPLIT || CKPT == kCkptSpill, "the two-role pass keeps its step records where the own-region checkpoints would be");
 	// the soft saturation selects between these two and the input: as kernel arguments (SGPRs) they are copied into
 	// VGPRs at every Euler step; an opaque copy made once, here, stays in two VGPR pairs for the whole kernel
 	DevOptions o = o_arg;
@@ -41,11 +138,26 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 	extern __shared__ double tb_lds[];
 	double *const pay = tb_lds;                                            // pass 2: states of the K most critical samples
 	double *const ckl = CKPT == kCkptLds2 ? tb_lds + K * NZ * 64 : tb_lds; // pass 1: states at the start of the K selected blocks
-	const int lane = threadIdx.x;
-	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int lane = SPLIT ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+	int64_t i = (int64_t)blockIdx.x * 64 + lane;
 	const bool live = i < a.B;
 	if (!live) i = a.B - 1;
 	const int64_t ld = a.ld;
+	// two-role pass: step records, per-step control words, last-block slots, flags -- behind the checkpoint region
+	using SL = TbSplitLds<M>;
+	double *const ring = tb_lds + SL::kSlots;
+	int *const ctl = (int *)(ring + SL::kRing);
+	int *const lastSlot = ctl + 2 * M::kTrajBlock * 64;
+	int *const flags = lastSlot + 64; // [0], [1]: "every lane was done before the block in this buffer"; [2]: alarm from the Q wave
+	if constexpr (SPLIT) {
+		if (threadIdx.x == 0) flags[2] = 0;
+		if (threadIdx.x >= 64) { // wave 1: the sensitivity
+			// (options outside the fast step's preconditions: the x wave runs the fused, checking pass on its own and
+			// never reaches a barrier -- the launcher does not pick this kernel then, and this keeps the two in step anyway)
+			if (o.satFastOk) tb_q_role<M>(o, ring, ctl, lastSlot, flags, ckl, ring, lane, o.npBT);
+			return;
+		}
+	}
 
 	double x0[NX], f0[NX], g0[NX];
 #pragma unroll
@@ -130,7 +242,8 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 		// (lanes that reached the backup set sit out)
 		auto sample = [&](int s, bool opens) {
 			if (!done) {
-				BackupLoop<M>::template eulerStepT<false, P>(o, z, none, 0.0, &carry, false);
+				if constexpr (tb_split_roles<M>::value && P == kTrigCarried) BackupLoop<M>::eulerStepRoles(o, z, carry);
+				else BackupLoop<M>::template eulerStepT<false, P>(o, z, none, 0.0, &carry, false);
 				t = t + o.trajDt; // backTraj_[i].first accumulates, :475
 				sLast = s;
 				if (opens) { // wave-uniform: close the previous block, open the next
@@ -180,12 +293,112 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 		}
 		commit(sLast / MB); // every lane's last (possibly partial) block
 	};
+	// the x wave of the two-role pass: pass1(fast) without the sensitivity, a record per step for the Q wave
+	bool alarm = false;
+	auto pass1x = [&]() {
+	  if constexpr (SPLIT) {
+		using BL = BackupLoop<M>;
+		constexpr int NF = BL::kRecordDoubles;
+#pragma unroll
+		for (int k = 0; k < NZ; k++) z[k] = 0.0;
+#pragma unroll
+		for (int k = 0; k < NX; k++) {
+			z[k] = x0[k];
+			z[NX + k * (NX + 1)] = 1.0;
+		}
+		topB.init();
+#pragma unroll
+		for (int k = 0; k < NZ; k++) zs[k] = z[k];
+		resync();
+		bmin = M::safetyMin(o, x0);
+		hall = bmin;
+		done = inside || !live;
+		hit = false;
+		idxHit = 0;
+		sLast = 0;
+		t = 0.0;
+		tHit = 0.0;
+		auto commitX = [&](int blk) { // as commit(), the x part of the checkpoint; the slot goes to the Q wave
+			int slot = -1;
+			if (__any(bmin < topB.key[K - 1])) {
+				slot = topB.insert(bmin, blk);
+				if (slot >= 0) {
+#pragma unroll
+					for (int k = 0; k < NX; k++) ckl[(slot * NZ + k) * 64 + lane] = zs[k];
+				}
+			}
+			return slot;
+		};
+		const int nblk = (o.npBT + MB - 1) / MB;
+#pragma unroll 1
+		for (int b = 0; b < nblk; b++) {
+			const int buf = b & 1;
+			const bool stop = __all(done);
+			if (lane == 0) flags[buf] = stop ? 1 : 0;
+			if (!stop) {
+#pragma unroll 1
+				for (int k = 0; k < MB; k++) {
+					const int s = b * MB + k;
+					if (s == 0 || s >= o.npBT) continue; // wave-uniform
+					int c = 0;
+					if (!done) {
+						double xs[NX];
+#pragma unroll
+						for (int e = 0; e < NX; e++) xs[e] = z[e];
+						const typename BL::StepRecord r = BL::stepX(o, xs, carry);
+#pragma unroll
+						for (int e = 0; e < NX; e++) z[e] = xs[e];
+						t = t + o.trajDt;
+						sLast = s;
+						int slot = -1;
+						if (k == 0 && b > 0) { // wave-uniform: close the previous block, open this one
+							slot = commitX(b - 1);
+							bmin = __builtin_huge_val();
+#pragma unroll
+							for (int e = 0; e < NX; e++) zs[e] = z[e];
+							resync();
+						}
+						const double hm = M::safetyMin(o, xs);
+						bmin = fmin(bmin, hm);
+						hall = fmin(hall, hm);
+						if (M::backupSetInside(o, xs)) {
+							hit = true;
+							done = true;
+							idxHit = s;
+							tHit = t;
+						}
+						double *rec = ring + (size_t)((buf * MB + k) * NF) * 64 + lane;
+						rec[0 * 64] = r.xg[0];
+						rec[1 * 64] = r.xg[1];
+						rec[2 * 64] = r.uSat;
+						rec[3 * 64] = r.DuSat;
+						rec[4 * 64] = r.s;
+						rec[5 * 64] = r.c;
+						rec[6 * 64] = r.iden;
+						rec[7 * 64] = r.rg;
+						c = 1 | ((slot + 1) << 8);
+					}
+					ctl[(buf * MB + k) * 64 + lane] = c;
+				}
+			}
+			__syncthreads(); // A_b
+			if (stop) break;
+		}
+		lastSlot[lane] = commitX(sLast / MB); // every lane's last (possibly partial) block
+		__syncthreads(); // B1
+		__syncthreads(); // B2: the Q wave's final Q sits where the records were
+#pragma unroll
+		for (int e = 0; e < NX * NX; e++) z[NX + e] = ring[e * 64 + lane];
+		alarm = flags[2] != 0;
+	  }
+	};
 	// (the fast pass also takes the soft saturation's short forms, valid for ordinary saturation constants --
 	// DevOptions::satFastOk, checked on the host; other options run the generic pass)
 	bool redo = !o.satFastOk;
 	if (!redo) {
-		pass1(std::true_type());
-		bool bad = false;
+		if constexpr (SPLIT) pass1x();
+		else pass1(std::true_type());
+		bool bad = alarm;
 #pragma unroll
 		for (int k = 0; k < NZ; k++) bad = bad || (z[k] != z[k]);
 		if constexpr (trig_carry<M>::value) bad = bad || !M::trigCarryBounded(o, hall);
@@ -250,8 +463,13 @@ __global__ __launch_bounds__(64) void tb_rows_kernel(DevOptions o_arg, FilterArg
 			if (tt > 0) {
 				// pass 1 has range-checked these very states (unless it had to be redone): the fast step is valid again
 				typename BackupLoop<M>::Hold none2 = {0.0, 0.0};
-				if (fast2) BackupLoop<M>::template eulerStepT<false, kFastTrig>(o, z, none2, 0.0, &carry, false);
-				else BackupLoop<M>::eulerStep(o, z);
+				if constexpr (tb_split_roles<M>::value && kFastTrig == kTrigCarried) {
+					if (fast2) BackupLoop<M>::eulerStepRoles(o, z, carry);
+					else BackupLoop<M>::eulerStep(o, z);
+				} else {
+					if (fast2) BackupLoop<M>::template eulerStepT<false, kFastTrig>(o, z, none2, 0.0, &carry, false);
+					else BackupLoop<M>::eulerStep(o, z);
+				}
 			}
 			double xs[NX];
 #pragma unroll
@@ -466,7 +684,25 @@ static int launch_tb(const DevOptions &o, const asif_hip_solver &S, const Filter
 		const int per_cu = (int)((160 * 1024) / (2 * region));
 		const bool both = per_cu >= 1 && (int64_t)grid <= (int64_t)per_cu * cus;
 		hipError_t he = hipSuccess;
-		if (both) {
+		bool split = false;
+		if constexpr (tb_split_roles<M>::value) {
+			// two waves per 64 instances: only while the second wave has a SIMD to itself (two workgroups per CU)
+			static const bool off = []() {
+				const char *v = getenv("ASIF_HIP_TB_SPLIT"); // developer switch: 0 keeps the fused pass
+				return v && v[0] == '0';
+			}();
+			split = !off && o.satFastOk && (int64_t)grid <= 2LL * cus && 2 * TbSplitLds<M>::bytes() <= 160 * 1024;
+			if (split) {
+				auto kern = tb_rows_kernel<M, kCkptSpill, true>;
+				const size_t bytes = TbSplitLds<M>::bytes();
+				if (bytes > 48 * 1024)
+					he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+				if (he != hipSuccess) return (int)he;
+				hipLaunchKernelGGL(kern, dim3(grid), dim3(128), bytes, stream, o, a);
+			}
+		}
+		if (split) {
+		} else if (both) {
 			auto kern = tb_rows_kernel<M, kCkptLds2>;
 			if (2 * region > 48 * 1024)
 				he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * region));

@@ -563,6 +563,9 @@ struct Segway {
 	static constexpr int NX = 4, NU = 1, NPSS = 4, NPBS = 1, NPBTSS = 4;
 	static constexpr int kTrajBlock = 4; // 316-sample trajectory, 4 critical samples (measured: 4 < 8 < 2 < 16)
 	static constexpr bool kTbUnrollSteps = false;
+	// the gradients (tanh, Df, Dg) and the 4 x 4 sensitivity are the larger half of the Euler step and x does not
+	// depend on them: pass 1 of the TB kernel may deal x and Q to two waves (k_tb.hip: tb_rows_split_kernel)
+	static constexpr bool kTbSplitRoles = true;
 	static constexpr bool kInputOnLastState = false; // g depends on the pitch
 	static constexpr bool kDfFirstRowShift = false;
 
@@ -647,6 +650,7 @@ struct Segway {
 	// :56-68  u = K (x + x_eq)
 	__device__ static void backupController(const DevOptions &, const double (&x)[NX], double (&u)[NU], double (&Du)[NU * NX])
 	{
+#pragma clang fp contract(on)
 		const double K0 = 44.7214, K1 = 44.6528, K2 = 150.1612, K3 = 37.6492;
 		u[0] = K0 * (0. + x[0]) + K1 * (0. + x[1]) + K2 * (-0.1383244254 + x[2]) + K3 * (0. + x[3]);
 		Du[0] = K0; Du[1] = K1; Du[2] = K2; Du[3] = K3;
@@ -673,8 +677,12 @@ struct Segway {
 	// collected coefficients are the example's own numbers multiplied out in double precision; values agree with the
 	// spelled-out form to 1e-15 relative (checked on 2e5 random states), the oracle keeps the spelled-out form.
 	struct Shared { double iden, rg, gc, gs; };
+	// (fp contract(on) in the segway's functions: a multiply-add is fused where the SOURCE expression has one, never
+	// across statements -- hipcc's default also fuses across statements, by use counts that differ between the kernels
+	// these functions are inlined into; the two-role pass of k_tb.hip and the fused pass must give the same bits)
 	__device__ static Shared dynamicsT(const double (&X)[NX], const Trig &t, double (&f)[NX], double (&g)[NX * NU])
 	{
+#pragma clang fp contract(on)
 		const double w2 = X[3] * X[3];
 		Shared h;
 		h.iden = rcp_newton((14.553176960783997 + -2.0831375273848773 * t.c2) + -0.59146430898882 * t.s2);
@@ -684,15 +692,22 @@ struct Segway {
 		f[2] = X[3];
 		f[3] = h.iden * ((-40.918271887954823 * t.c1 + 293.92471275850022 * t.s1) +
 		                 w2 * (0.59146430898882 * t.c2 + -2.0831375273848769 * t.s2));
+		h.rg = rcp_newton(((8.3593271361634187 + -2.1243074194638587 * (t.c1 * t.c1)) +
+		                   -0.04116989207898096 * (t.s1 * t.s1)) + -0.29573215449441 * t.s2);
+		gainT(t, h, g);
+		return h;
+	}
+	// the input gain from sin / cos and the two reciprocals (h.iden, h.rg in; h.gc, h.gs out): dynamicsT's own lines, on
+	// their own so that the Q role of the two-role pass (k_tb.hip) evaluates exactly them from the x role's record
+	__device__ static void gainT(const Trig &t, Shared &h, double (&g)[NX * NU])
+	{
+#pragma clang fp contract(on)
 		g[0] = 0.0;
 		h.gc = 1.4575004011882324 * t.c1;
 		h.gs = 0.20290365220710288 * t.s1;
-		h.rg = rcp_newton(((8.3593271361634187 + -2.1243074194638587 * (t.c1 * t.c1)) +
-		                   -0.04116989207898096 * (t.s1 * t.s1)) + -0.29573215449441 * t.s2);
 		g[1] = 0.551244194154502 * ((4.1706936767483551 + h.gc) + h.gs) * h.rg;
 		g[2] = 0.0;
 		g[3] = -5.65378660671284 * ((2.0043013906215941 + h.gc) + h.gs) * h.iden;
-		return h;
 	}
 	__device__ static void dynamics(const DevOptions &, const double (&x)[NX], double (&f)[NX], double (&g)[NX * NU])
 	{
@@ -734,6 +749,14 @@ struct Segway {
 	                                         double (&g)[NX * NU], double (&Df)[NX * NX], double (&Dg)[NX * NU * NX])
 	{
 		const Shared h = dynamicsT(x, t, f, g);
+		gradientsGiven(x, t, h, Df, Dg);
+	}
+	// the gradients from sin / cos, dynamicsT's shared terms and the two states they depend on (x[1], x[3])
+	static constexpr int kGradStates[2] = {1, 3};
+	__device__ static void gradientsGiven(const double (&x)[NX], const Trig &t, const Shared &h, double (&Df)[NX * NX],
+	                                      double (&Dg)[NX * NU * NX])
+	{
+#pragma clang fp contract(on)
 		const double c1 = t.c1, s1 = t.s1, c2 = t.c2, s2 = t.s2;
 		const double w2 = x[3] * x[3];
 		const double th = tanh_abs_accurate(x[1] * 1000.0);
