@@ -70,7 +70,7 @@ __device__ __forceinline__ void tb_q_role(const DevOptions &o, const double *rin
 		__syncthreads(); // A_b: buffer b & 1 holds block b (or the stop flag)
 		const int buf = b & 1;
 		if (flags[buf]) break; // wave-uniform
-#pragma unroll 1
+#pragma unroll
 		for (int k = 0; k < MB; k++) {
 			const int s = b * MB + k;
 			if (s == 0 || s >= npBT) continue; // wave-uniform
@@ -336,8 +336,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void tb_rows_kernel(DevOptions o_
 			const bool stop = __all(done);
 			if (lane == 0) flags[buf] = stop ? 1 : 0;
 			if (!stop) {
-#pragma unroll 1
-				for (int k = 0; k < MB; k++) {
+#pragma unroll
+				for (int k = 0; k < MB; k++) { // unrolled: the record's LDS addresses are a base per buffer plus immediates
 					const int s = b * MB + k;
 					if (s == 0 || s >= o.npBT) continue; // wave-uniform
 					int c = 0;
