@@ -321,9 +321,11 @@ def native_loop():
     import subprocess
     so = os.path.join(ROOT, "asif_amd", "host", "libbench_loop.so")
     try:
-        if not os.path.exists(so):
+        if not os.path.exists(so):  # normally built by __graft_entry__.build(); ranks may race here: build aside, rename
+            tmp = f"{so}.{os.getpid()}.tmp"
             subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", os.path.join(ROOT, "asif_amd", "host", "bench_loop.c"),
-                                   "-o", so])
+                                   "-o", tmp])
+            os.replace(tmp, so)
         _native[1] = C.CDLL(so)
     except Exception as e:
         print(f"bench.py: native step loop unavailable ({e}); stepping from Python", file=sys.stderr)

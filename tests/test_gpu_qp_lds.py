@@ -201,3 +201,19 @@ def test_plain_admm_wave_kernel_on_shipped_half_planes_22x15(hip, oracle):
     assert np.all(st[rc != 1] == -3)
     ok = rc == 1
     assert (np.abs(sol[ok, 0] - ua[ok, 0]) / np.maximum(1.0, np.abs(ua[ok, 0]))).max() <= 1e-5  # |u| up to 20 here
+
+
+@pytest.mark.parametrize("B", [1, 2, 777])
+def test_two_problems_per_wave_do_not_see_each_other(hip, oracle, B):
+    """qp_inv.hpp pairs problems 2k and 2k+1 in one wavefront (an odd batch leaves the last half-wave idle): the answer
+    of a problem must not depend on its partner -- the first B of the 18 x 12 problems solved alone equal, bit for bit,
+    the same problems inside a batch of 2 048, with a different partner for every odd index when B is odd."""
+    d, Hd, c, A, b, lb, ub, be = _config_qps(oracle, 5, 2048)
+    full = _solve(hip, Hd, c, A, b, lb, ub, be)
+    part = _solve(hip, Hd[:B], c[:B], A[:B], b[:B], lb[:B], ub[:B], be)
+    for x, y in zip(full, part):
+        assert np.array_equal(x[:B], y)
+    # and shifted by one: every problem changes its partner and its half of the wave
+    sh = _solve(hip, Hd[1:B + 1], c[1:B + 1], A[1:B + 1], b[1:B + 1], lb[1:B + 1], ub[1:B + 1], be)
+    for x, y in zip(full, sh):
+        assert np.array_equal(x[1:B + 1], y)

@@ -70,3 +70,36 @@ def test_full_size_properties(hip):
     h2 = gpu_util.run_filter(4, B // 2, first=B // 2)
     assert np.array_equal(np.concatenate([h1["uact"], h2["uact"]], axis=1), out["uact"])
     assert np.array_equal(np.concatenate([h1["rc"], h2["rc"]]), rc)
+
+
+def test_two_role_pass_is_bitwise_the_fused_pass(hip):
+    """Segway, pass 1 dealt to two waves (x on one SIMD, gradients + sensitivity one block behind on another)
+    against the fused pass (ASIF_HIP_TB_SPLIT=0, read once per process: each side in its own process): rows, diagnostics,
+    uAct, relax, rc bitwise identical on a ragged batch that mixes all three branches -- a batch above the switch-over and
+    its shards below it must agree, which is what the multi-GPU path is tested on."""
+    import hashlib
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests'); import gpu_util\n"
+            "r = gpu_util.run_assemble(4, 4099); f = gpu_util.run_filter(4, 4099, uact_init=7.0, relax_init=-7.0)\n"
+            "print(json.dumps({k: hashlib.sha256(v.tobytes()).hexdigest() for k, v in "
+            "(('A', r['A']), ('b', r['b']), ('code', r['code']), ('diag', r['diag']), ('uact', f['uact']), ('relax', f['relax']), ('rc', f['rc']))}))\n"
+            % (root, root))
+    res = []
+    for v in ("1", "0"):
+        o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ASIF_HIP_TB_SPLIT=v), capture_output=True,
+                           text=True, timeout=300)
+        assert o.returncode == 0, o.stderr[-1500:]
+        res.append(json.loads(o.stdout.strip().split("\n")[-1]))
+    assert res[0] == res[1]
+
+
+@pytest.mark.parametrize("B", [1, 63, 65, 1000])
+def test_small_and_ragged_batches_on_the_two_role_pass(hip, oracle, B):
+    out = gpu_util.run_filter(4, B, uact_init=7.0, relax_init=-7.0)
+    ua, rl, rc = gpu_util.oracle_filter(oracle, 4, out["x"], out["udes"], uact_init=7.0, relax_init=-7.0)
+    assert np.array_equal(out["rc"], rc)
+    assert np.abs(out["uact"] - ua).max() <= 1e-6
