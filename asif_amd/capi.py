@@ -29,11 +29,14 @@ CONFIGS = {
     10: (MODEL_INVERTED_PENDULUM, 5, 16384),
     # not a BASELINE.json config and not a reference example: class ASIF on the synthetic two-input model
     11: (8, EXPLICIT, 65536),
+    # not a BASELINE.json config: examples/DoubleIntegrator_implicit_tb.cpp (2 101-step trajectory under ASIFimplicitTB)
+    12: (9, IMPLICIT_TB, 65536),
 }
 MODEL_PLANAR_TWO_INPUT = 8
 IMPLICIT_RB = 5
 MODEL_INVERTED_PENDULUM_TB = 6
 MODEL_DOUBLE_INTEGRATOR_IMPLICIT = 7
+MODEL_DOUBLE_INTEGRATOR_TB = 9
 
 EXPORTS = [
     "asif_hip_version", "asif_hip_error_string", "asif_hip_device_count", "asif_hip_default_options",

@@ -134,6 +134,15 @@ extern "C" int asif_hip_default_options(int model, int variant, asif_hip_options
 		o->relaxReachLb = 5.0;
 		o->relaxLb = 10.0;
 		break;
+	case ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_TB: // examples/DoubleIntegrator_implicit_tb.cpp:18-19,107-112
+		o->lb[0] = -1.0;
+		o->ub[0] = 1.0;
+		o->backTrajHorizon = 2.0;
+		o->backTrajDt = 0.001;
+		o->relaxLb = 10.0;
+		o->relaxTTS = 5.0;
+		o->relaxMinOrtho = 5.0;
+		break;
 	case ASIF_HIP_MODEL_INVERTED_PENDULUM_TB: // examples/InvertedPendulum_ImplicitTB.cpp:19-22,106-114
 		o->lb[0] = -1.5;
 		o->ub[0] = 1.5;
@@ -281,7 +290,8 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 		}
 		return ASIF_HIP_OK;
 	}
-	if ((model == ASIF_HIP_MODEL_SEGWAY || model == ASIF_HIP_MODEL_INVERTED_PENDULUM_TB) && variant == ASIF_HIP_IMPLICIT_TB) {
+	if ((model == ASIF_HIP_MODEL_SEGWAY || model == ASIF_HIP_MODEL_INVERTED_PENDULUM_TB ||
+	     model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_TB) && variant == ASIF_HIP_IMPLICIT_TB) {
 		d.nx = model == ASIF_HIP_MODEL_SEGWAY ? 4 : 2; d.nu = 1; d.npSS = 4; d.npBS = 1;
 		d.npBTSS = 4;                           // examples/segway_implicit_tb.cpp:16
 		d.nv = d.nu + 1;                        // src/asif_implicit_tb.cpp:122
@@ -849,6 +859,7 @@ static int stage_ckpt(asif_hip_ctx *ctx, FilterArgs &a)
 	case ASIF_HIP_MODEL_INVERTED_PENDULUM:
 	case ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT:
 	case ASIF_HIP_MODEL_INVERTED_PENDULUM_TB:
+	case ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_TB:
 	case ASIF_HIP_MODEL_SEGWAY: need = (int64_t)ctx->dims.npBTSS * (nz + 2) * a.ld; break;
 	default: return ASIF_HIP_EINVAL;
 	}
@@ -924,6 +935,14 @@ static int run_filter(asif_hip_ctx *ctx, FilterArgs a, bool assemble_only, hipSt
 		}
 		if (int r = stage_ckpt(ctx, a)) return r;
 		return launch_tb_pendulum(ctx->dev, ctx->solver, a, assemble_only, stream);
+	}
+	if (ctx->model == ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_TB && ctx->variant == ASIF_HIP_IMPLICIT_TB) {
+		if (!assemble_only) {
+			int r = stage_rows(ctx, a);
+			if (r) return r;
+		}
+		if (int r = stage_ckpt(ctx, a)) return r;
+		return launch_tb_di(ctx->dev, ctx->solver, a, assemble_only, stream);
 	}
 	if (ctx->model == ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST && ctx->variant == ASIF_HIP_ROBUST)
 		return launch_robust_ip(ctx->dev, ctx->solver, a, assemble_only, stream); // fused, nothing staged

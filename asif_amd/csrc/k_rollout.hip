@@ -62,6 +62,8 @@ int launch_plant_step(int model, const DevOptions &o, int64_t B, int64_t ld, dou
 		return launch_step<Segway>(o, B, ld, dt, x, uact, rc, nfail, xlog, ulog, rclog, s);
 	case ASIF_HIP_MODEL_INVERTED_PENDULUM_TB:
 		return launch_step<InvertedPendulumTB>(o, B, ld, dt, x, uact, rc, nfail, xlog, ulog, rclog, s);
+	case ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_TB:
+		return launch_step<DoubleIntegratorTB>(o, B, ld, dt, x, uact, rc, nfail, xlog, ulog, rclog, s);
 	default:
 		return ASIF_HIP_EUNSUPPORTED;
 	}

@@ -742,4 +742,9 @@ int launch_tb_pendulum(const DevOptions &o, const asif_hip_solver &S, const Filt
 	return launch_tb<InvertedPendulumTB>(o, S, a, assemble_only, stream);
 }
 
+int launch_tb_di(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only, hipStream_t stream)
+{
+	return launch_tb<DoubleIntegratorTB>(o, S, a, assemble_only, stream);
+}
+
 } // namespace asif

@@ -68,6 +68,9 @@ int launch_tb_segway(const DevOptions &o, const asif_hip_solver &S, const Filter
 int launch_tb_pendulum(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                        hipStream_t stream);
 
+// same class, model = DoubleIntegratorTB (examples/DoubleIntegrator_implicit_tb.cpp)
+int launch_tb_di(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only, hipStream_t stream);
+
 // robust explicit filter (class ASIFrobust), model = InvertedPendulumRobust (half-plane safety set)
 int launch_robust_ip(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                      hipStream_t stream);

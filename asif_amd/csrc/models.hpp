@@ -483,6 +483,35 @@ struct DoubleIntegratorImplicit {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Double integrator of the time-to-backup-set example, examples/DoubleIntegrator_implicit_tb.cpp:13-103: box,
+// dynamics and backup controller of the implicit example above; the backup set is the disc x'x <= Pv^2 (P = I,
+// Pv = 0.01).  The example fills two of the Hessian's four entries (:49) and the class reads four
+// (src/asif_implicit_tb.cpp:494,623): taken as the whole of mPpPt = -2 I here and in the oracle (or_models.c).
+struct DoubleIntegratorTB : DoubleIntegratorImplicit {
+	static constexpr int kTrajBlock = 16; // 2 101-sample trajectory (7 001 after the example's updateOptions)
+	static constexpr bool kTbUnrollSteps = true;
+	// :41-57  h = Pv^2 - sum_ij P_ij x_i x_j in the example's loop order, Dh = mPpPt x, DDh = mPpPt
+	__device__ static double backupSetValue(const DevOptions &, const double (&x)[NX])
+	{
+		double v = 0.01 * 0.01;
+		v -= 1.0 * x[0] * x[0];
+		v -= 0.0 * x[0] * x[1];
+		v -= 0.0 * x[1] * x[0];
+		v -= 1.0 * x[1] * x[1];
+		return v;
+	}
+	__device__ static bool backupSetInside(const DevOptions &o, const double (&x)[NX]) { return backupSetValue(o, x) >= 0.0; }
+	__device__ static void backupSet(const DevOptions &o, const double (&x)[NX], double &h, double (&Dh)[NX],
+	                                 double (&DDh)[NX * NX])
+	{
+		h = backupSetValue(o, x);
+		Dh[0] = (0.0 + -2.0 * x[0]) + 0.0 * x[1];
+		Dh[1] = (0.0 + 0.0 * x[0]) + -2.0 * x[1];
+		DDh[0] = -2.0; DDh[1] = 0.0; DDh[2] = 0.0; DDh[3] = -2.0;
+	}
+};
+
+// ---------------------------------------------------------------------------------------------
 // Inverted pendulum of the time-to-backup-set example, examples/InvertedPendulum_ImplicitTB.cpp:14-99:
 // asymmetric box, half-space backup set x0 >= pi/2 - 0.1, backup controller tracking the velocity pi/10.
 // Dynamics and their gradients are the pendulum's (:67-74, :87-94).

@@ -2,7 +2,10 @@
 // next to filterBatch() (everything on the GPU) on the same seeded states.  The model callbacks are the
 // reference examples' (examples/InvertedPendulum_Implicit.cpp:31-80, examples/segway_implicit_tb.cpp:27-212);
 // the compiled device functors are reused as host functions so both paths see the same model.
-//   usage: backup_filters implicit|tb N      prints  i,uAct,relax0,relax1,rc,uActBatch,rcBatch
+//   usage: backup_filters implicit|tb|tbdi N      prints  i,uAct,relax0,relax1,rc,uActBatch,rcBatch
+//          backup_filters tbdi-loop STEPS         the closed loop of examples/DoubleIntegrator_implicit_tb.cpp:105-160
+//                                                 (fused-gradient constructor, updateOptions at half time); prints
+//                                                 i,x0,x1,uAct,relax,TTS,rc,updated with the state the filter was called on
 #include <asif++.h>
 #include <cmath>
 #include <cstdio>
@@ -61,6 +64,15 @@ struct HostModel {
 		M::dynamicsAndGradients(kNoOpts, xs, ff, gg, A, Bm);
 		for (int i = 0; i < M::NX * M::NX; i++) { Df[i] = A[i]; Dg[i] = Bm[i]; }
 	}
+	// the fused callback of the second constructor (include/asif_implicit_tb.h:74-84): f, g and d(f + g u)/dx
+	static void dynamicsWithGradient(const double *x, const double *u, double *f, double *g, double *d_fcl_dx)
+	{
+		static_assert(M::NU == 1, "single-input models");
+		double Df[M::NX * M::NX], Dg[M::NX * M::NX];
+		dynamics(x, f, g);
+		gradients(x, Df, Dg);
+		for (int i = 0; i < M::NX * M::NX; i++) d_fcl_dx[i] = Df[i] + Dg[i] * u[0];
+	}
 	static void controller(const double *x, double *u, double *Du)
 	{
 		double xs[M::NX], uu[1], D[M::NX];
@@ -76,6 +88,61 @@ int main(int argc, char **argv)
 	if (argc < 3) return 2;
 	const bool tb = !std::strcmp(argv[1], "tb");
 	const long N = std::atol(argv[2]);
+	if (!std::strncmp(argv[1], "tbdi", 4)) {
+		typedef HostModel<asif::DoubleIntegratorTB> H;
+		const double lb[1] = {-1.0}, ub[1] = {1.0};
+		ASIF::ASIFimplicitTB::Options opts; // examples/DoubleIntegrator_implicit_tb.cpp:107-112
+		opts.backTrajHorizon = 2.0;
+		opts.backTrajDt = 0.001;
+		opts.relaxSafeLb = 10.0;
+		opts.relaxTTS = 5.0;
+		opts.relaxMinOrtho = 5.0;
+		ASIF::ASIFimplicitTB flt(2, 1, 4, 4, H::safetySet, H::backupSet4, H::dynamicsWithGradient, H::controller);
+		if (flt.initialize(lb, ub, opts) != 1 || flt.bindDeviceModel(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_TB) != 0) return 3;
+		if (!std::strcmp(argv[1], "tbdi-loop")) {
+			std::printf("i,x0,x1,uAct,relax,TTS,rc,updated\n");
+			const double dt = 0.001, tEnd = dt * (double)N; // the example runs N = 5000
+			double x[2] = {0.1, 0.1}, t = 0.0;
+			const double ud[1] = {0.9};
+			bool updated = false;
+			for (long i = 0; i < N; i++) {
+				if (!updated && t > tEnd / 2) {
+					opts.backTrajHorizon = 7.0;
+					updated = true;
+					if (flt.updateOptions(opts) != 1) return 5;
+				}
+				double ua[1] = {0.0}, rl = 0.0;
+				const int32_t rc = flt.filter(x, ud, ua, rl);
+				std::printf("%ld,%.17g,%.17g,%.17g,%.17g,%.17g,%d,%d\n", i, x[0], x[1], ua[0], rl, flt.TTS_, rc, (int)updated);
+				double f[2], g[2];
+				H::dynamics(x, f, g);
+				for (int k = 0; k < 2; k++) x[k] += dt * (f[k] + g[k] * ua[0]);
+				t += dt;
+			}
+			// the batched path after updateOptions(): the last state, as a batch of one
+			double ua[1] = {0.0}, rl[1] = {0.0};
+			int32_t rc = 0;
+			if (flt.filterBatch(1, x, ud, ua, rl, &rc) != 0) return 4;
+			std::printf("%ld,%.17g,%.17g,%.17g,%.17g,%.17g,%d,%d\n", N, x[0], x[1], ua[0], rl[0], 0.0, rc, 2);
+			return 0;
+		}
+		std::printf("i,uAct,relax0,relax1,rc,uActBatch,rcBatch\n");
+		std::vector<double> bx(2 * N), bu(N), ba(N, 0.0), br(N, 0.0);
+		std::vector<int32_t> brc(N, 0);
+		for (long i = 0; i < N; i++) {
+			bx[i] = -0.04 + 0.08 * rng(12, i, 0);
+			bx[N + i] = -0.04 + 0.08 * rng(12, i, 1);
+			bu[i] = -1.5 + 3.0 * rng(12, i, 2);
+		}
+		if (flt.filterBatch(N, bx.data(), bu.data(), ba.data(), br.data(), brc.data()) != 0) return 4;
+		for (long i = 0; i < N; i++) {
+			const double x[2] = {bx[i], bx[N + i]}, ud[1] = {bu[i]};
+			double ua[1] = {0.0}, rl = 0.0;
+			const int32_t rc = flt.filter(x, ud, ua, rl);
+			std::printf("%ld,%.17g,%.17g,%.17g,%d,%.17g,%d\n", i, ua[0], rl, flt.TTS_, rc, ba[i], brc[i]);
+		}
+		return 0;
+	}
 	std::printf("i,uAct,relax0,relax1,rc,uActBatch,rcBatch\n");
 	if (!tb) {
 		typedef HostModel<asif::InvertedPendulum> H;

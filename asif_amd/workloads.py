@@ -47,6 +47,9 @@ def make_batch(cfg, B, first=0):
     elif cfg == 11:  # synthetic two-input model under class ASIF (not a reference example): nx = 2, nu = 2
         x = np.stack([-1.6 + 3.2 * uniform(11, i, 0), -1.6 + 3.2 * uniform(11, i, 1)])
         u = np.stack([-1.5 + 3.0 * uniform(11, i, 2), -1.5 + 3.0 * uniform(11, i, 3)])
+    elif cfg == 12:  # double integrator TB (examples/DoubleIntegrator_implicit_tb.cpp): see or_make_batch
+        x = np.stack([-0.04 + 0.08 * uniform(12, i, 0), -0.04 + 0.08 * uniform(12, i, 1)])
+        u = (-1.5 + 3.0 * uniform(12, i, 2))[None, :]
     else:
         raise ValueError(f"unknown config {cfg}")
     return np.ascontiguousarray(x), np.ascontiguousarray(u)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- QP solves/s of the batched CBF-QP filter() hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2..10|qp] [--batch B] [--kernel 100Hz]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2..12|qp] [--batch B] [--kernel 100Hz]
                     [--presolve 1] [--polish 0|1|2] [--no-cpu-baseline] [--no-pcie]
                     [--shape c2|c3|c4|c5full|rz38|rz62|rz86] [--lanes 64]       (with --config qp)
 
@@ -41,7 +41,7 @@ VALU_ISSUE_CYCLES = 4    # one wave's FP64 / FP32 vector instruction occupies it
 PROFILE_ROUND = "r03"
 
 # algorithmic HBM bytes per instance of the state->input path: read 8(nx+nu), write 8(nu+nrelax)+4
-ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44, 6: 52, 7: 44, 8: 44, 9: 52, 10: 52, 11: 60}
+ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44, 6: 52, 7: 44, 8: 44, 9: 52, 10: 52, 11: 60, 12: 44}
 IMPLICIT_RB_CFG = 10  # ASIFimplicitRB on the pendulum model; not a BASELINE.json config
 REALIZABLE_CFG = 6  # ASIFrealizable on the sampled double integrator; not a BASELINE.json config
 ROBUST_DATA_CFG = 7  # ASIFrobust on the shipped data: examples/DoubleIntegrator_Robust.cpp + KernelData_70-135kg.h
@@ -57,6 +57,7 @@ WORKLOAD = {
     10: "C10 ASIFimplicitRB::filter on the InvertedPendulum_Implicit model (backup input held 10 steps, interval "
         "margins under x_unc, two 4-16-16-1 ReLU residual networks with seeded weights)",
     11: "C11 class ASIF on a synthetic two-input model (nx=2, nu=2, five half-planes; no reference example has nu > 1)",
+    12: "C12 DoubleIntegrator_implicit_tb (ASIFimplicitTB::filter, 2 101-step backup trajectory, nv=2 nc=18)",
 }
 
 
@@ -140,7 +141,7 @@ def cpu_baseline(cfg, gpu_uact, gpu_rc, x, udes, seconds=15.0):
         o = rb_options(O, model, variant)
         o.set_learning(O.Learning.from_dict(workloads.make_learning()))
     cores = host_cores()
-    probe = {2: 20000, 3: 16, 4: 256, 5: 2000, 8: 16, 9: 512, 10: 16, 11: 20000}[cfg]
+    probe = {2: 20000, 3: 16, 4: 256, 5: 2000, 8: 16, 9: 512, 10: 16, 11: 20000, 12: 64}[cfg]
     xs, us = O.make_batch(cfg, probe)
     t = time.perf_counter()
     O.filter_batch(model, variant, o, xs, us, O.SOLVER_ADMM, None, 1)
@@ -151,7 +152,7 @@ def cpu_baseline(cfg, gpu_uact, gpu_rc, x, udes, seconds=15.0):
     ua_admm, _, rc_admm = O.filter_batch(model, variant, o, xs, us, O.SOLVER_ADMM, None, cores,
                                          uact_init=np.zeros((n, gpu_uact.shape[0])))
     dt = time.perf_counter() - t
-    m = min(x.shape[1], {2: 65536, 3: 16384, 4: 32768, 5: 8192, 8: 16384, 9: 65536, 10: 16384, 11: 65536}[cfg])  # the full batch
+    m = min(x.shape[1], {2: 65536, 3: 16384, 4: 32768, 5: 8192, 8: 16384, 9: 65536, 10: 16384, 11: 65536, 12: 65536}[cfg])  # the full batch
     ua, _, rc = O.filter_batch(model, variant, o, np.ascontiguousarray(x[:, :m].T),
                                np.ascontiguousarray(udes[:, :m].T), O.SOLVER_EXACT, None, cores,
                                uact_init=np.zeros((m, gpu_uact.shape[0])))
@@ -778,7 +779,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="all",
                     help="all (default): C2 is the line's value, C3 / C4 (one GPU's share) / C5 ride in `configs`, C1 in `c1`; "
-                         "2..11: one filter config; qp: pre-assembled QPs (see --shape)")
+                         "2..12: one filter config; qp: pre-assembled QPs (see --shape)")
     ap.add_argument("--shape", default="c2", choices=sorted(QP_SHAPES), help="--config qp: which problems")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0)

@@ -70,9 +70,10 @@ enum asif_hip_model {
 	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_ROBUST = 5, /* examples/DoubleIntegrator_Robust.cpp:17-58 (asif_hip_create_robust_data) */
 	ASIF_HIP_MODEL_INVERTED_PENDULUM_TB = 6,     /* examples/InvertedPendulum_ImplicitTB.cpp:14-99 (ASIF_HIP_IMPLICIT_TB) */
 	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_IMPLICIT = 7, /* examples/DoubleIntegrator_implicit.cpp:13-90 (ASIF_HIP_IMPLICIT) */
-	ASIF_HIP_MODEL_PLANAR_TWO_INPUT = 8 /* NOT an example of the reference: synthetic nx = 2, nu = 2 model (x' = Fx + Gu,
-	                                     * five half-planes) so that class ASIF's nu > 1 code (src/asif.cpp:279-303,
-	                                     * 314-352) has a device path and a parity test */
+	ASIF_HIP_MODEL_PLANAR_TWO_INPUT = 8, /* NOT an example of the reference: synthetic nx = 2, nu = 2 model (x' = Fx + Gu,
+	                                      * five half-planes) so that class ASIF's nu > 1 code (src/asif.cpp:279-303,
+	                                      * 314-352) has a device path and a parity test */
+	ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_TB = 9 /* examples/DoubleIntegrator_implicit_tb.cpp:13-103 (ASIF_HIP_IMPLICIT_TB) */
 };
 
 enum asif_hip_variant {

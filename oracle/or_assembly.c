@@ -89,6 +89,15 @@ void or_default_options(int model, int variant, or_options *o)
 		o->relaxMinOrtho = 60.0;
 		o->backTrajMinOrtho = 0.001;
 		break;
+	case OR_MODEL_DOUBLE_INTEGRATOR_TB: /* examples/DoubleIntegrator_implicit_tb.cpp:18-19,107-112 */
+		o->lb[0] = -1.0;
+		o->ub[0] = 1.0;
+		o->backTrajHorizon = 2.0;
+		o->backTrajDt = 0.001;
+		o->relaxLb = 10.0;
+		o->relaxTTS = 5.0;
+		o->relaxMinOrtho = 5.0;
+		break;
 	case OR_MODEL_INVERTED_PENDULUM_ROBUST: {
 		o->lb[0] = -1.5;
 		o->ub[0] = 1.5;

@@ -260,6 +260,13 @@ void or_make_batch(int cfg, int64_t B, int64_t first, double *x, double *uDes)
 			uDes[2 * k + 0] = -1.5 + 3.0 * or_rng_uniform(11, i, 2);
 			uDes[2 * k + 1] = -1.5 + 3.0 * or_rng_uniform(11, i, 3);
 			break;
+		case 12: /* double integrator TB (examples/DoubleIntegrator_implicit_tb.cpp), seed 12 */
+			/* the backup set is the disc of radius 0.01 and the closed loop's slow pole is -0.51/s: within the 2.1 s
+			 * horizon only states within ~0.03 of the origin reach it; +-0.04 mixes inside / hit / never-hit */
+			x[2 * k + 0] = -0.04 + 0.08 * or_rng_uniform(12, i, 0);
+			x[2 * k + 1] = -0.04 + 0.08 * or_rng_uniform(12, i, 1);
+			uDes[k] = -1.5 + 3.0 * or_rng_uniform(12, i, 2);
+			break;
 		case 5: /* robust pendulum, seed 4 */
 			x[2 * k + 0] = -3.0 + 6.0 * or_rng_uniform(4, i, 0);
 			x[2 * k + 1] = -3.0 + 6.0 * or_rng_uniform(4, i, 1);

@@ -411,6 +411,28 @@ static void dii_grad(const void *ud, const double *x, double *Df, double *Dg)
 }
 
 /* ----------------------------------------------------------------------------
+ * Double integrator under the time-to-backup-set filter -- examples/DoubleIntegrator_implicit_tb.cpp:13-103:
+ * the box, controller and dynamics of the implicit example above, a circular backup set x'x <= Pv^2.
+ * The example's backupSet writes DDh[i] = mPpPt[i] for i < nx only (:49), i.e. two of the four entries of the
+ * Hessian, and the class reads all four from an uninitialised stack array (src/asif_implicit_tb.cpp:494,623):
+ * the last two are indeterminate in the reference.  Restated with the whole of mPpPt, the matrix that line
+ * indexes (UNPINNED by construction: no other choice is the reference's either). */
+static const double dit_P[4] = {1.0, 0.0, 0.0, 1.0};
+static const double dit_mPpPt[4] = {-2.0, 0.0, 0.0, -2.0};
+static const double dit_Pv = 0.01;
+
+static void dit_backup(const void *ud, const double *x, double *h, double *Dh, double *DDh)
+{
+	(void)ud;
+	h[0] = dit_Pv * dit_Pv; /* :41-57 */
+	for (int i = 0; i < 2; i++)
+		for (int j = 0; j < 2; j++) h[0] -= dit_P[i + j * 2] * x[i] * x[j];
+	or_matvec(dit_mPpPt, 2, 2, x, Dh);
+	if (DDh)
+		for (int i = 0; i < 4; i++) DDh[i] = dit_mPpPt[i];
+}
+
+/* ----------------------------------------------------------------------------
  * Synthetic two-input model for class ASIF (NOT from the reference: none of its examples has nu > 1, but
  * src/asif.cpp is written for any nu): x' = F x + G u with a non-diagonal input matrix, five half-planes. */
 static void p2_safety(const void *ud, const double *x, double *h, double *Dh)
@@ -432,7 +454,7 @@ static void p2_dynamics(const void *ud, const double *x, double *f, double *g)
 	g[2] = 0.3; g[3] = 1.0; /* column 1 */
 }
 
-static const or_model MODELS[7] = {
+static const or_model MODELS[8] = {
     {2, 1, 4, 0, di_safety, 0, di_dynamics, 0, 0, 0, 0, 0},
     {2, 1, 4, 1, ip_safety, ip_backup, ip_dynamics, ip_grad, ip_ctrl, 0, ip_safety_af, 10}, /* examples/InvertedPendulum_Implicit.cpp:17 */
     {4, 1, 4, 1, sg_safety, sg_backup, sg_dynamics, sg_grad, sg_ctrl, 0, 0, 4},
@@ -440,10 +462,11 @@ static const or_model MODELS[7] = {
     {2, 1, 4, 1, ipt_safety, ipt_backup, ip_dynamics, ip_grad, ipt_ctrl, 0, 0, 4}, /* dynamics :67-74,87-94 = the pendulum's */
     {2, 1, 4, 1, dii_safety, dii_backup, di_dynamics, dii_grad, dii_ctrl, 0, dii_safety_af, 4}, /* dynamics :57-63 = A x, B; npBTSS :17 */
     {2, 2, 5, 0, p2_safety, 0, p2_dynamics, 0, 0, 0, 0, 0},
+    {2, 1, 4, 1, dii_safety, dit_backup, di_dynamics, dii_grad, dii_ctrl, 0, 0, 4}, /* box :33-39, A x, B :59-65, K :67-74 as the implicit example; npBTSS :16 */
 };
 
 const or_model *or_model_get(int id)
 {
-	if (id < 0 || id > 6) return 0;
+	if (id < 0 || id > 7) return 0;
 	return &MODELS[id];
 }

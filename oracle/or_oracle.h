@@ -37,8 +37,9 @@ enum or_model_id {
 	OR_MODEL_INVERTED_PENDULUM_ROBUST = 3, /* examples/InvertedPendulum_Robust.cpp:20-79   */
 	OR_MODEL_INVERTED_PENDULUM_TB = 4,     /* examples/InvertedPendulum_ImplicitTB.cpp:14-99 */
 	OR_MODEL_DOUBLE_INTEGRATOR_IMPLICIT = 5, /* examples/DoubleIntegrator_implicit.cpp:13-90 */
-	OR_MODEL_PLANAR_TWO_INPUT = 6 /* NOT an example of the reference: a synthetic nx = 2, nu = 2 model for class ASIF,
-	                               * so that the nu > 1 loops of src/asif.cpp:279-303,314-352 are exercised */
+	OR_MODEL_PLANAR_TWO_INPUT = 6, /* NOT an example of the reference: a synthetic nx = 2, nu = 2 model for class ASIF,
+	                                * so that the nu > 1 loops of src/asif.cpp:279-303,314-352 are exercised */
+	OR_MODEL_DOUBLE_INTEGRATOR_TB = 7 /* examples/DoubleIntegrator_implicit_tb.cpp:13-103 */
 };
 
 enum or_variant_id {

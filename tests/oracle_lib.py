@@ -25,7 +25,8 @@ CONFIGS = {2: (MODEL_DI, VAR_EXPLICIT), 3: (MODEL_IP, VAR_IMPLICIT), 4: (MODEL_S
            8: (MODEL_IP_TB, VAR_TB),     # examples/InvertedPendulum_ImplicitTB.cpp (not a BASELINE.json config)
            9: (5, VAR_IMPLICIT),         # examples/DoubleIntegrator_implicit.cpp   (not a BASELINE.json config)
            10: (MODEL_IP, VAR_IMPLICIT_RB),  # ASIFimplicitRB on the pendulum model
-           11: (6, VAR_EXPLICIT)}        # class ASIF on the synthetic two-input model (no reference example has nu > 1)
+           11: (6, VAR_EXPLICIT),        # class ASIF on the synthetic two-input model (no reference example has nu > 1)
+           12: (7, VAR_TB)}              # examples/DoubleIntegrator_implicit_tb.cpp (not a BASELINE.json config)
 MODEL_P2 = 6
 
 

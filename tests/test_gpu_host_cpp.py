@@ -83,6 +83,56 @@ def test_tb_class_single_agent_and_batch(hip, oracle):
     assert np.abs(rows[:, 5] - ua[:, 0]).max() <= 1e-6
 
 
+def test_tb_class_double_integrator_single_agent_and_batch(hip, oracle):
+    """examples/DoubleIntegrator_implicit_tb.cpp's model through the class's fused-gradient constructor
+    (dynamicsWithGradient, include/asif_implicit_tb.h:74-84) and through filterBatch()."""
+    n = 300
+    rows = _run_backup("tbdi", n)
+    x, u = oracle.make_batch(12, n)
+    model, variant = oracle.CONFIGS[12]
+    ua, rl, rc = oracle.filter_batch(model, variant, oracle.default_options(model, variant), x, u, oracle.SOLVER_EXACT)
+    assert np.array_equal(rows[:, 4].astype(int), rc) and np.array_equal(rows[:, 6].astype(int), rc)
+    assert {1, 2, -3} <= set(rc.tolist())
+    assert np.abs(rows[:, 1] - ua[:, 0]).max() <= 1e-6
+    assert np.abs(rows[:, 5] - ua[:, 0]).max() <= 1e-6
+
+
+def test_double_integrator_tb_closed_loop(hip, oracle):
+    """The example's own loop (examples/DoubleIntegrator_implicit_tb.cpp:105-160): 5 000 control steps from (0.1, 0.1)
+    with uDes = 0.9, updateOptions(backTrajHorizon = 7) once t > 2.5 s.  Per step, on the state the program was in, the
+    input must be the exact optimum of the QP the reference assembles with the options in force (after the update the
+    trajectory has 7 001 samples: the (1 + backTrajExtend) factor is dropped, src/asif_implicit_tb.cpp:377)."""
+    steps = 5000
+    rows = _run_backup("tbdi-loop", steps)
+    assert rows.shape == (steps + 1, 8)
+    batch_row, rows = rows[-1], rows[:-1]
+    upd = rows[:, 7].astype(int)
+    first = int(np.argmax(upd))
+    assert 2499 <= first <= 2502 and np.all(upd[first:] == 1) and np.all(upd[:first] == 0)
+    model, variant = oracle.CONFIGS[12]
+    o1 = oracle.default_options(model, variant)
+    o2 = oracle.default_options(model, variant)
+    o2.backTrajHorizon = 7.0
+    o2.backTrajExtend = 0.0
+    assert oracle.dims(model, variant, o2).npBT == 7001
+    ud = np.full((steps, 1), 0.9)
+    x = np.ascontiguousarray(rows[:, 1:3])
+    ua = np.empty(steps)
+    rc = np.empty(steps, dtype=int)
+    for o, sl in ((o1, slice(0, first)), (o2, slice(first, steps))):
+        a, _, r = oracle.filter_batch(model, variant, o, x[sl], ud[sl], oracle.SOLVER_EXACT, nthreads=8)
+        ua[sl], rc[sl] = a[:, 0], r
+    assert np.array_equal(rows[:, 6].astype(int), rc), np.where(rows[:, 6].astype(int) != rc)[0][:10]
+    assert np.abs(rows[:, 3] - ua).max() <= 1e-6
+    assert {1, -3} <= set(rc.tolist())  # out of reach of the small backup set at first, filtering later
+    # the plant step of the example, reproduced from its own inputs
+    xn = x[:-1] + 0.001 * np.stack([x[:-1, 1], rows[:-1, 3]], axis=1)
+    assert np.abs(xn - x[1:]).max() <= 1e-15
+    # filterBatch() on the state after the last step, options as updated
+    a, _, r = oracle.filter_batch(model, variant, o2, batch_row[None, 1:3], np.array([[0.9]]), oracle.SOLVER_EXACT)
+    assert int(batch_row[6]) == r[0] and abs(batch_row[3] - a[0, 0]) <= 1e-6
+
+
 def test_robust_class_single_agent_and_batch(hip, oracle):
     """ASIF::ASIFrobust: host affine arithmetic (asif_affine.h) must reproduce the oracle's rows bit for bit
     (the oracle is pinned against the reference's libaffa); single-agent filter() solves the FULL 18-variable

@@ -26,7 +26,7 @@ def _poison(x):
     return np.array(idx)
 
 
-@pytest.mark.parametrize("cfg", [2, 3, 4, 5, 9, 11])
+@pytest.mark.parametrize("cfg", [2, 3, 4, 5, 9, 11, 12])
 @pytest.mark.parametrize("polish", [2, 1])
 def test_rc_matches_oracle_and_neighbours_untouched(hip, oracle, cfg, polish):
     B = 512 if cfg in (3,) else 1024
@@ -44,7 +44,7 @@ def test_rc_matches_oracle_and_neighbours_untouched(hip, oracle, cfg, polish):
     keep[bad] = False
     assert np.array_equal(out["rc"][keep], clean["rc"][keep])
     for k in ("uact", "relax"):
-        if cfg in (3, 4, 9):
+        if cfg in (3, 4, 9, 12):
             # trajectory kernels: a wave that holds a NaN lane re-runs its blocks on the checking step (trig evaluated
             # per step instead of carried along the block): its other lanes move by rounding, not more
             assert np.abs(out[k][..., keep] - clean[k][..., keep]).max() <= 1e-10, k

@@ -21,7 +21,7 @@ import numpy as np
 LB, UB, R_SAT = -1.5, 1.5, 0.1
 
 
-def _sat(u):
+def _sat(u, LB=LB, UB=UB):
     rng, mid = UB - LB, 0.5 * (UB + LB)
     uc = 2.0 * (u - mid) / rng
     bev = R_SAT * np.tan(np.pi / 8)
@@ -143,3 +143,57 @@ def test_ortho_row_is_the_reference_formula(oracle):
         np.testing.assert_allclose(Am[17, 0], row @ g, rtol=5e-2, atol=2e-4)
         checked += 1
     assert checked >= 8
+
+
+# ---- the double integrator of examples/DoubleIntegrator_implicit_tb.cpp: a CURVED backup set (disc of radius 0.01),
+# so the hit moves along the boundary with x0 and the Hessian term of the rows is live
+
+def _di_fcl(x):
+    return np.array([x[1], _sat(-10.0 * x[0] - 20.0 * x[1], -1.0, 1.0)])
+
+
+def _di_hit(x0, dt=1e-3, tmax=2.2):
+    hb = lambda xx: 1e-4 - xx @ xx
+    rk = lambda xx, h: (lambda k1: (lambda k2: (lambda k3: xx + h / 6 * (k1 + 2 * k2 + 2 * k3 + _di_fcl(xx + h * k3)))(
+        _di_fcl(xx + 0.5 * h * k2)))(_di_fcl(xx + 0.5 * h * k1)))(_di_fcl(xx))
+    x, t = np.array(x0, dtype=float), 0.0
+    assert hb(x) < 0
+    while t < tmax:
+        xn = rk(x, dt)
+        if hb(xn) >= 0:
+            lo, hi = 0.0, dt
+            for _ in range(50):
+                m = 0.5 * (lo + hi)
+                if hb(rk(x, m)) >= 0:
+                    hi = m
+                else:
+                    lo = m
+            return t + hi
+        x, t = xn, t + dt
+    raise AssertionError("backup set not reached")
+
+
+def test_tts_row_with_a_curved_backup_set(oracle):
+    model, variant = oracle.CONFIGS[12]
+    o = oracle.default_options(model, variant)
+    d = oracle.dims(model, variant, o)
+    assert (d.nv, d.nc, d.npBT) == (2, 18, 2101)
+    x, _ = oracle.make_batch(12, 160)
+    A, b, code, diag = oracle.assemble_batch(model, variant, o, x)
+    idx = [k for k in np.where(code == 1)[0] if 0.2 < diag[k, 0] < 1.9]  # away from the horizon's end and from t = 0
+    assert len(idx) >= 12
+    g = np.array([0.0, 1.0])
+    eps = 1e-6
+    checked = 0
+    for k in idx[:16]:
+        Am = A[k].reshape(2, 18).T
+        tau0 = _di_hit(x[k])
+        assert abs(diag[k, 0] - tau0) <= 2e-3 + 2e-3 * tau0, (diag[k, 0], tau0)
+        dtau_g = (_di_hit(x[k] + eps * g) - _di_hit(x[k] - eps * g)) / (2 * eps)
+        np.testing.assert_allclose(Am[16, 0], -dtau_g, rtol=3e-2, atol=2e-4)
+        f0 = np.array([x[k][1], 0.0])
+        dtau_f = (_di_hit(x[k] + eps * f0) - _di_hit(x[k] - eps * f0)) / (2 * eps)
+        hreach = o.backTrajHorizon - diag[k, 0]
+        np.testing.assert_allclose(b[k, 16], dtau_f - o.relaxTTS * hreach, rtol=3e-2, atol=5e-3)
+        checked += 1
+    assert checked >= 12

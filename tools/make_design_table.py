@@ -25,13 +25,13 @@ def fmt_rate(v):
 
 NAMES = {2: "C2 DI explicit", 3: "C3 pendulum implicit", 4: "C4 segway TB (one GPU's share)", 5: "C5 robust pendulum",
          6: "C6 realizable DI", 7: "C7 robust DI, shipped data", 8: "C8 pendulum TB", 9: "C9 DI implicit",
-         10: "C10 pendulum, `ASIFimplicitRB`", 11: "C11 two-input model, class `ASIF`"}
+         10: "C10 pendulum, `ASIFimplicitRB`", 11: "C11 two-input model, class `ASIF`", 12: "C12 DI TB"}
 
 
 def config_table():
     out = ["| config | batch / GPU | step | QP solves/s | HBM traffic per step (PMC) vs algorithmic | HBM `frac` | `roofline.valu` (+ SALU) | max\\|u−u_ref\\| | rc mismatches | OSQP-like envelope | CPU baseline (oracle, threads; 1 thread) |",
            "|---|---|---|---|---|---|---|---|---|---|---|"]
-    for c in range(2, 12):
+    for c in range(2, 13):
         b = j(f"c{c}_bench.json")
         if not b:
             continue

@@ -3,7 +3,7 @@
 O=gpurun_out/final_r03; mkdir -p $O
 # profile passes (kernel trace + FETCH / WRITE / SQ counter passes, each its own run): tools/prof_cfg.sh
 bash tools/prof_cfg.sh default > /dev/null 2>&1           # the driver's command: C2 + configs C3, C4, C5 + C1
-for c in 2 3 4 5 6 7 8 9 10 11; do bash tools/prof_cfg.sh c$c --config $c > /dev/null 2>&1; echo "prof c$c done"; done
+for c in 2 3 4 5 6 7 8 9 10 11 12; do bash tools/prof_cfg.sh c$c --config $c > /dev/null 2>&1; echo "prof c$c done"; done
 for sh in c2 c3 c4 c5full; do bash tools/prof_cfg.sh qp_$sh --config qp --shape $sh > /dev/null 2>&1; done
 bash tools/prof_cfg.sh qp_c5full_wave_polish0 --config qp --shape c5full --lanes 64 --polish 0 > /dev/null 2>&1
 bash tools/prof_cfg.sh c2_batch16m --config 2 --batch 16777216 --steps 20 --warmup 3 > /dev/null 2>&1
@@ -11,7 +11,7 @@ echo "profiles done"
 # bench records
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/default_driver_style_bench.json 2> $O/default.err
 timeout -k 10 300 python bench.py > $O/default_bench.json 2>> $O/default.err
-for c in 2 3 4 5 6 7 8 9 10 11; do timeout -k 10 300 python bench.py --config $c > $O/c${c}_bench.json 2> $O/c${c}_bench.err; echo "config $c rc $?"; done
+for c in 2 3 4 5 6 7 8 9 10 11 12; do timeout -k 10 300 python bench.py --config $c > $O/c${c}_bench.json 2> $O/c${c}_bench.err; echo "config $c rc $?"; done
 for p in 0 1; do timeout -k 10 300 python bench.py --config 2 --polish $p > $O/c2polish${p}_bench.json 2>/dev/null; done
 for sh in c2 c3 c4 c5full; do timeout -k 10 300 python bench.py --config qp --shape $sh > $O/qp_${sh}_bench.json 2>/dev/null; done
 timeout -k 10 300 python bench.py --config qp --shape c5full --lanes 64 --polish 0 > $O/qp_c5full_wave_polish0_bench.json 2>/dev/null
