@@ -72,6 +72,36 @@ struct BackupLoop {
 		return a / b;
 #endif
 	}
+	// The bevel's pair sq = sqrt(d), q = n / sq in one go, for d in [r^2/2, r^2] and |n| <= r (the arc of the soft
+	// saturation; r within satFastOk's range).  The square root's own refinement leaves h = 1/(2 sqrt(d)) to ~2^-50: 2h
+	// after ONE Newton step is the reciprocal the division's sequence would have built from v_rcp with two -- a
+	// transcendental and a Newton step less; d is never 0 or inf and the quotient never special here, so the sqrt's
+	// select and v_div_fixup go too.  Same bits as sqrt_plain_range / div_plain_range (checked on the device over the
+	// arc's whole range, tests/test_gpu_math_probe.py).
+	__device__ __forceinline__ static void bevel_arc(double d, double n, double &sq, double &q)
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		const double y = __builtin_amdgcn_rsq(d);
+		double g = d * y, h = 0.5 * y;
+		const double r0 = fma(-h, g, 0.5);
+		g = fma(g, r0, g);
+		h = fma(h, r0, h);
+		double e = fma(-g, g, d);
+		g = fma(e, h, g);
+		e = fma(-g, g, d);
+		g = fma(e, h, g);
+		sq = g;
+		double r = h + h;
+		const double e1 = fma(-g, r, 1.0);
+		r = fma(r, e1, r);
+		double qq = n * r;
+		const double t = fma(-g, qq, n);
+		q = fma(t, r, qq);
+#else
+		sq = sqrt(d);
+		q = n / sq;
+#endif
+	}
 	// bevelled smooth saturation of the backup input; DuSat is d uSat / d u in the reference's own
 	// (normalised-arc) convention -- reproduced literally.
 	// Four regions: linear, clamped high / low (selects), and the two bevels (sqrt + divide) as ONE evaluation on |uc|,
@@ -104,9 +134,9 @@ struct BackupLoop {
 			DuSat = clamped ? 0.0 : 1.0;
 			if (au > o.bevelStart && !clamped) { // divergent: skipped by the wave when no lane is in a bevel
 				const double d = r * r - (au - xc) * (au - xc);
-				const double sq = sqrt_plain_range(d);
+				double sq;
+				bevel_arc(d, xc - au, sq, DuSat);
 				const double us = 0.5 * (sq + yc) * range;
-				DuSat = div_plain_range(xc - au, sq);
 				uSat = neg ? middle - us : us + middle;
 			}
 		} else { // the reference's chain, region by region and in its order (src/asif_implicit.cpp:704-735)

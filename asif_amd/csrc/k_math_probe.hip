@@ -1,5 +1,5 @@
 // k_math_probe.hip -- self-test entry for the device math the trajectory kernels use in place of library calls
-// (models.hpp: sincos_fast, tanh_abs_accurate, rcp_newton; backup_traj.hpp: sqrt_plain_range, div_plain_range), so that
+// (models.hpp: sincos_fast, tanh_abs_accurate, rcp_newton; backup_traj.hpp: sqrt_plain_range, div_plain_range, bevel_arc), so that
 // their accuracy claims are tested on the device itself (tests/test_gpu_math_probe.py) and not only through the rows
 // they feed.  HOST pointers in and out; n values per call.
 #include <hip/hip_runtime.h>
@@ -35,6 +35,7 @@ __global__ void math_probe_kernel(int kind, int64_t n, const double *a, const do
 		r1 = cy.c;
 		break;
 	}
+	case ASIF_HIP_PROBE_BEVEL_ARC: BackupLoop<InvertedPendulum>::bevel_arc(x, y, r0, r1); break;
 	default: break;
 	}
 	o0[i] = r0;
@@ -46,8 +47,9 @@ __global__ void math_probe_kernel(int kind, int64_t n, const double *a, const do
 extern "C" int asif_hip_math_probe(int device, int32_t kind, int64_t n, const double *a, const double *b, double *out0,
                                    double *out1)
 {
-	if (n < 0 || kind < 0 || kind > ASIF_HIP_PROBE_SINCOS_CARRY || (n > 0 && (!a || !out0))) return ASIF_HIP_EINVAL;
-	if ((kind == ASIF_HIP_PROBE_DIV_PLAIN || kind == ASIF_HIP_PROBE_SINCOS_CARRY) && n > 0 && !b) return ASIF_HIP_EINVAL;
+	if (n < 0 || kind < 0 || kind > ASIF_HIP_PROBE_BEVEL_ARC || (n > 0 && (!a || !out0))) return ASIF_HIP_EINVAL;
+	if ((kind == ASIF_HIP_PROBE_DIV_PLAIN || kind == ASIF_HIP_PROBE_SINCOS_CARRY || kind == ASIF_HIP_PROBE_BEVEL_ARC) &&
+	    n > 0 && !b) return ASIF_HIP_EINVAL;
 	if (n == 0) return ASIF_HIP_OK;
 	hipError_t e = hipSetDevice(device);
 	if (e != hipSuccess) return ASIF_HIP_ENODEVICE;

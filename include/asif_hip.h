@@ -335,7 +335,8 @@ enum asif_hip_probe {
 	ASIF_HIP_PROBE_RCP = 3,
 	ASIF_HIP_PROBE_SQRT_PLAIN = 4,
 	ASIF_HIP_PROBE_DIV_PLAIN = 5,
-	ASIF_HIP_PROBE_SINCOS_CARRY = 6 /* sin / cos at a + 15 b: evaluated at a, then carried over 15 increments of b */
+	ASIF_HIP_PROBE_SINCOS_CARRY = 6, /* sin / cos at a + 15 b: evaluated at a, then carried over 15 increments of b */
+	ASIF_HIP_PROBE_BEVEL_ARC = 7     /* out0 = sqrt(a), out1 = b / sqrt(a) by the saturation bevel's joint sequence */
 };
 int asif_hip_math_probe(int device, int32_t kind, int64_t n, const double *a, const double *b, double *out0,
                         double *out1);

@@ -85,6 +85,26 @@ def test_bevel_sqrt_and_divide_are_the_ieee_results_on_their_ranges(hip):
     assert np.array_equal(q, a / b)
 
 
+def test_bevel_arc_pair_is_the_ieee_pair_over_the_arc(hip):
+    """backup_traj.hpp bevel_arc: sqrt(d) and n / sqrt(d) from ONE v_rsq (the division reuses the square root's
+    reciprocal estimate) must be bitwise what sqrt and divide give, for every satSharpness the options admit
+    (0.01 <= r <= 2): d in [r^2 / 2, r^2], |n| <= r."""
+    rng = np.random.default_rng(6)
+    r = np.concatenate([np.full(400000, 0.1), rng.uniform(0.01, 2.0, 1200000), np.full(200000, 0.01), np.full(200000, 2.0)])
+    t = rng.uniform(0.0, 1.0, r.size)
+    t[:1000] = 0.0
+    t[1000:2000] = 1.0
+    d = r * r * (0.5 + 0.5 * t)
+    n = np.sqrt(np.maximum(r * r - d, 0.0)) * rng.choice([-1.0, 1.0], r.size)  # as in the kernel: n^2 + d = r^2
+    n[2000:200000] = rng.uniform(-1.0, 1.0, 198000) * r[2000:200000]              # and anything else within |n| <= r
+    n[200000:200100] = 0.0
+    n[200100:200200] = np.spacing(1.0) * r[200100:200200]                           # one ulp inside the clamp threshold
+    sq, q = hip.math_probe(7, d, n)
+    ref = np.sqrt(d)
+    assert np.array_equal(sq, ref)
+    assert np.array_equal(q, n / ref)
+
+
 def test_carried_sincos_over_one_block(hip):
     """kTrigCarried (models.hpp): sin / cos evaluated at the block's first sample and rotated by the angle's increments
     for the 15 steps of a block: at the accumulated angle, within 1.5 + 15/2 ulp of 1 by construction, a few ulp in
