@@ -129,10 +129,15 @@ struct BackupLoop {
 		const double yc = 1 - r;
 		if constexpr (FAST) {
 			const double au = fabs(uc);
-			const bool clamped = au >= o.bevelStop, neg = uc < 0.0;
-			uSat = clamped ? (neg ? mi : ma) : u;
+			const bool clamped = au >= o.bevelStop;
+			// linear region: u lies strictly inside [mi, ma] (bevelStart < 1); clamped: beyond them (bevelStop > 1): a
+			// clamp gives both in two instructions, the bevel in between is overwritten below.  (The clamp drops a NaN
+			// input where the select kept it: u is NaN only next to a NaN or overflowing state, which the callers'
+			// alarm -- kStateSane -- sends through the checking step.)
+			uSat = min_num(max_num(u, mi), ma);
 			DuSat = clamped ? 0.0 : 1.0;
 			if (au > o.bevelStart && !clamped) { // divergent: skipped by the wave when no lane is in a bevel
+				const bool neg = uc < 0.0;
 				const double d = r * r - (au - xc) * (au - xc);
 				double sq;
 				bevel_arc(d, xc - au, sq, DuSat);

@@ -166,7 +166,8 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 	constexpr int MB = M::kTrajBlock, CK = NZ + 2;
 	TopK<K> topB;
 	topB.init();
-	double bmin = __builtin_huge_val();
+	RunningMargin<M> brun; // smallest margin of the current block
+	brun.reset();
 	double *ck = a.ckpt + i;
 	const int64_t ldc = a.ld;
 	double zs[NZ]; // state (and hold) at the first sample of the current block
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 #pragma unroll
 	for (int k = 0; k < NZ; k++) zs[k] = z[k];
 	auto commit = [&](int blk) { // close block blk: keep its checkpoint if it is among the K most critical so far
+		const double bmin = brun.value();
 		if (__any(bmin < topB.key[K - 1])) {
 			const int slot = topB.insert(bmin, blk);
 			if (slot >= 0) {
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 		const bool more = s0 + n < o.npBT;
 		auto run = [&](auto fast) {
 			constexpr int P = !decltype(fast)::value ? kTrigChecked : kFastTrig;
-			bmin = __builtin_huge_val();
+			brun.reset();
 			// reset: the step out of the block's first sample evaluates sin / cos afresh (kTrigCarried); a literal at every
 			// call site, so that the step is compiled in its two forms instead of choosing at run time
 			auto sample = [&](int k, bool reset) {
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 				double xs[NX];
 #pragma unroll
 				for (int c = 0; c < NX; c++) xs[c] = z[c];
-				bmin = fmin(bmin, M::safetyMin(o, xs));
+				brun.add(o, xs);
 			};
 			static_assert(MB >= 4 && MB % 4 == 0, "blocks of a multiple of four samples");
 			if (n == MB) { // full block: compile-time trip count, unrolled by four (loop control is SALU + a branch per step)
@@ -249,9 +251,9 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 			run(std::true_type());
 			bool bad = false;
 #pragma unroll
-			for (int c = 0; c < NZ; c++) bad = bad || (z[c] != z[c]);
-			if constexpr (trig_carry<M>::value) bad = bad || !M::trigCarryBounded(o, bmin);
-			else if constexpr (trig_by_margin<M>::value) bad = bad || !M::trigArgsBounded(bmin);
+			for (int c = 0; c < NZ; c++) bad = bad || !(fabs(z[c]) < kStateSane); // NaN included
+			if constexpr (trig_carry<M>::value) bad = bad || !M::trigCarryBounded(o, brun.value());
+			else if constexpr (trig_by_margin<M>::value) bad = bad || !M::trigArgsBounded(brun.value());
 			redo = __any(bad); // never on sane trajectories
 			if (redo) {
 #pragma unroll

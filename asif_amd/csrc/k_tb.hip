@@ -185,8 +185,11 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void tb_rows_kernel(DevOptions o_
 	TopK<K> topB;
 	double *ck = a.ckpt + i;
 	double zs[NZ]; // state at the first sample of the current block
-	double bmin;
+	RunningMargin<M> brun; // smallest margin of the current block
+	double hall; // smallest safety margin of the whole pass (kTrigUnchecked: it bounds the trig arguments)
 	auto commit = [&](int blk) { // close block blk
+		const double bmin = brun.value();
+		hall = fmin(hall, bmin);
 		if (__any(bmin < topB.key[K - 1])) {
 			const int slot = topB.insert(bmin, blk);
 			if (slot >= 0) {
@@ -202,7 +205,6 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void tb_rows_kernel(DevOptions o_
 	// the smallest safety margin seen (kTrigUnchecked: these models' margins bound the trig arguments, models.hpp) or
 	// by NaN poisoning (kTrigPoison: an argument outside the range turns the lane's state into NaN -- NaN never enters
 	// the backup set).  A lane out of range has the pass repeated with the checking version.
-	double hall; // smallest safety margin of the whole pass (kTrigUnchecked: it bounds the trig arguments)
 	// the fast step's trig mode (models.hpp): carried along the steps, bounded by the margin, or poisoning.  Carried:
 	// ONE form of the step (always the rotation); sin / cos are re-synchronised with a fresh evaluation where a block
 	// starts -- here at the block boundary, in pass 2 after loading a block's checkpoint: the same arithmetic from the
@@ -229,8 +231,9 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void tb_rows_kernel(DevOptions o_
 #pragma unroll
 		for (int k = 0; k < NZ; k++) zs[k] = z[k]; // block 0 starts at sample 0
 		if (P == kTrigCarried) resync();
-		bmin = M::safetyMin(o, x0);
-		hall = bmin;
+		brun.reset();
+		brun.add(o, x0);
+		hall = __builtin_huge_val();
 		done = inside || !live;
 		hit = false;
 		idxHit = 0;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void tb_rows_kernel(DevOptions o_
 				sLast = s;
 				if (opens) { // wave-uniform: close the previous block, open the next
 					commit(s / MB - 1);
-					bmin = __builtin_huge_val();
+					brun.reset();
 #pragma unroll
 					for (int k = 0; k < NZ; k++) zs[k] = z[k];
 					if (P == kTrigCarried) resync();
@@ -256,9 +259,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void tb_rows_kernel(DevOptions o_
 				double xs[NX];
 #pragma unroll
 				for (int k = 0; k < NX; k++) xs[k] = z[k];
-				const double hm = M::safetyMin(o, xs);
-				bmin = fmin(bmin, hm);
-				if constexpr (trig_by_margin<M>::value) hall = fmin(hall, hm);
+				brun.add(o, xs);
 				if (M::backupSetInside(o, xs)) {
 					hit = true;
 					done = true;
@@ -310,8 +311,9 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void tb_rows_kernel(DevOptions o_
 #pragma unroll
 		for (int k = 0; k < NZ; k++) zs[k] = z[k];
 		resync();
-		bmin = M::safetyMin(o, x0);
-		hall = bmin;
+		brun.reset();
+		brun.add(o, x0);
+		hall = __builtin_huge_val();
 		done = inside || !live;
 		hit = false;
 		idxHit = 0;
@@ -320,6 +322,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void tb_rows_kernel(DevOptions o_
 		tHit = 0.0;
 		auto commitX = [&](int blk) { // as commit(), the x part of the checkpoint; the slot goes to the Q wave
 			int slot = -1;
+			const double bmin = brun.value();
+			hall = fmin(hall, bmin);
 			if (__any(bmin < topB.key[K - 1])) {
 				slot = topB.insert(bmin, blk);
 				if (slot >= 0) {
@@ -353,14 +357,12 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void tb_rows_kernel(DevOptions o_
 						int slot = -1;
 						if (k == 0 && b > 0) { // wave-uniform: close the previous block, open this one
 							slot = commitX(b - 1);
-							bmin = __builtin_huge_val();
+							brun.reset();
 #pragma unroll
 							for (int e = 0; e < NX; e++) zs[e] = z[e];
 							resync();
 						}
-						const double hm = M::safetyMin(o, xs);
-						bmin = fmin(bmin, hm);
-						hall = fmin(hall, hm);
+						brun.add(o, xs);
 						if (M::backupSetInside(o, xs)) {
 							hit = true;
 							done = true;
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void tb_rows_kernel(DevOptions o_
 		else pass1(std::true_type());
 		bool bad = alarm;
 #pragma unroll
-		for (int k = 0; k < NZ; k++) bad = bad || (z[k] != z[k]);
+		for (int k = 0; k < NZ; k++) bad = bad || !(fabs(z[k]) < kStateSane); // NaN included
 		if constexpr (trig_carry<M>::value) bad = bad || !M::trigCarryBounded(o, hall);
 		else if constexpr (trig_by_margin<M>::value) bad = bad || !M::trigArgsBounded(hall);
 		redo = __any(bad); // never on sane trajectories

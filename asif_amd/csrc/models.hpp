@@ -103,6 +103,9 @@ __device__ __forceinline__ double fma_sc(double a, double b, double c)
 //                   both results, as libm does.
 constexpr int kTrigChecked = 0, kTrigPoison = 1, kTrigUnchecked = 2, kTrigCarried = 3;
 constexpr double kTrigFastRange = 1e5;
+// the fast trajectory step's alarm: a state component that is NaN or beyond this magnitude at the end of a block (of the
+// pass) sends the block (the pass) through the checking step; below it no product of the closed loop can overflow
+constexpr double kStateSane = 1e150;
 //   kTrigCarried    (models that declare kTrigCarry) sin / cos of the state's angle are CARRIED along the Euler steps:
 //                   evaluated by the fast path at the first sample of a block, then rotated by the angle's increment,
 //                   sin(a + d) = sin a + (sin a (cos d - 1) + cos a sin d) and its twin, with short polynomials for
@@ -188,6 +191,70 @@ __device__ __forceinline__ void sincos_fast(double x, double &s, double &c)
 #endif
 }
 
+// ---- the smallest safety margin over a run of samples ------------------------------------------------------------
+// fmin / fmax of values the compiler cannot prove canonical (loop-carried, selected) cost a canonicalising v_max each in
+// IEEE mode; the instructions themselves ignore a NaN operand and quiet a signalling one -- exactly fmax's contract --
+// so the hot loops name them directly: one instruction per maximum.
+__device__ __forceinline__ double max_num(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	double r;
+	asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+#else
+	return fmax(a, b);
+#endif
+}
+__device__ __forceinline__ double min_num(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	double r;
+	asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+#else
+	return fmin(a, b);
+#endif
+}
+__device__ __forceinline__ double max_abs2(double a, double b) // fmax(|a|, |b|)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	double r;
+	asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+#else
+	return fmax(fabs(a), fabs(b));
+#endif
+}
+// A model whose smallest margin is a non-increasing function of ONE magnitude (box |x_i| <= c: c - max |x_i|; in
+// general -max_i of the negated margins, negation being exact) declares kMarginByMagnitude with
+//   safetyMagnitude(o, x)  and  marginOfMagnitude(m)   such that   safetyMin(o, x) == marginOfMagnitude(safetyMagnitude(o, x))
+// bit for bit.  Rounding is monotone, so the smallest margin of a run of samples is marginOfMagnitude(largest magnitude),
+// again bit for bit: the run costs one maximum per sample and one subtraction per run (RunningMargin below) instead of
+// the margin and a minimum per sample.
+template <class M, class = void>
+struct margin_by_magnitude : std::false_type {};
+template <class M>
+struct margin_by_magnitude<M, std::enable_if_t<M::kMarginByMagnitude>> : std::true_type {};
+
+template <class M>
+struct RunningMargin {
+	double v;
+	__device__ __forceinline__ void reset()
+	{
+		v = margin_by_magnitude<M>::value ? -__builtin_huge_val() : __builtin_huge_val();
+	}
+	__device__ __forceinline__ void add(const DevOptions &o, const double (&x)[M::NX])
+	{
+		if constexpr (margin_by_magnitude<M>::value) v = max_num(v, M::safetyMagnitude(o, x));
+		else v = fmin(v, M::safetyMin(o, x));
+	}
+	__device__ __forceinline__ double value() const
+	{
+		if constexpr (margin_by_magnitude<M>::value) return M::marginOfMagnitude(v);
+		else return v;
+	}
+};
+
 // ---------------------------------------------------------------------------------------------
 // Double integrator, examples/DoubleIntegrator.cpp:12-61.  x = (position, velocity).
 struct DoubleIntegrator {
@@ -239,12 +306,12 @@ struct InvertedPendulum {
 		h[2] = x[1] + kPi;  Dh[2] = 0.0;  Dh[6] = 1.0;
 		h[3] = -x[1] + kPi; Dh[3] = 0.0;  Dh[7] = -1.0;
 	}
-	__device__ static double safetyMin(const DevOptions &, const double (&x)[NX])
-	{
-		// min(-x0 + pi, x0 + pi, x1 + pi, -x1 + pi) = pi - max(|x0|, |x1|), bit for bit: the smaller of the two sums of
-		// a pair is fl(pi - |x_k|), and rounding is monotone (two instructions instead of seven in the 5000-step loop)
-		return kPi - fmax(fabs(x[0]), fabs(x[1]));
-	}
+	// min(-x0 + pi, x0 + pi, x1 + pi, -x1 + pi) = pi - max(|x0|, |x1|), bit for bit: the smaller of the two sums of
+	// a pair is fl(pi - |x_k|), and rounding is monotone
+	static constexpr bool kMarginByMagnitude = true;
+	__device__ static double safetyMagnitude(const DevOptions &, const double (&x)[NX]) { return max_abs2(x[0], x[1]); }
+	__device__ static double marginOfMagnitude(double m) { return kPi - m; }
+	__device__ static double safetyMin(const DevOptions &o, const double (&x)[NX]) { return marginOfMagnitude(safetyMagnitude(o, x)); }
 	// |x0| <= pi - safetyMin: while the smallest margin of a block of samples stays above this floor, no sample of
 	// the block hands sincos_fast an argument near the end of its range (kTrigFastRange; the floor keeps 10 % clear of
 	// it so that rounding in the margin cannot matter) -- see kTrigUnchecked
@@ -429,11 +496,11 @@ struct DoubleIntegratorImplicit {
 		h[2] = x[1] - (-1.0);  Dh[2] = 0.0;  Dh[6] = 1.0;
 		h[3] = -x[1] + 1.0;    Dh[3] = 0.0;  Dh[7] = -1.0;
 	}
-	__device__ static double safetyMin(const DevOptions &, const double (&x)[NX])
-	{
-		// min(-x0 + 1, x0 - (-1), x1 - (-1), -x1 + 1) = 1 - max(|x0|, |x1|), bit for bit (see InvertedPendulum)
-		return 1.0 - fmax(fabs(x[0]), fabs(x[1]));
-	}
+	// min(-x0 + 1, x0 - (-1), x1 - (-1), -x1 + 1) = 1 - max(|x0|, |x1|), bit for bit (see InvertedPendulum)
+	static constexpr bool kMarginByMagnitude = true;
+	__device__ static double safetyMagnitude(const DevOptions &, const double (&x)[NX]) { return max_abs2(x[0], x[1]); }
+	__device__ static double marginOfMagnitude(double m) { return 1.0 - m; }
+	__device__ static double safetyMin(const DevOptions &o, const double (&x)[NX]) { return marginOfMagnitude(safetyMagnitude(o, x)); }
 	// the same set on interval_t operands over x +- x_unc (ASIFimplicitRB's safetySet_int), lower ends
 	__device__ static void safetySetLo(const DevOptions &o, const double (&x)[NX], double (&h)[NPSS])
 	{
@@ -533,10 +600,15 @@ struct InvertedPendulumTB {
 		h[2] = x[1] - (-kPi / 2.); Dh[2] = 0.0;  Dh[6] = 1.0;
 		h[3] = -x[1] + kPi / 2.;   Dh[3] = 0.0;  Dh[7] = -1.0;
 	}
-	__device__ static double safetyMin(const DevOptions &, const double (&x)[NX])
+	// min(-x0 + pi, x0 + pi/2, x1 + pi/2, -x1 + pi/2) = -max(x0 - pi, -x0 - pi/2, |x1| - pi/2), bit for bit: fl(a - b) =
+	// -fl(b - a), the smaller of the last two sums is fl(pi/2 - |x1|), and rounding is monotone
+	static constexpr bool kMarginByMagnitude = true;
+	__device__ static double safetyMagnitude(const DevOptions &, const double (&x)[NX])
 	{
-		return fmin(fmin(-x[0] + kPi, x[0] - (-kPi / 2.)), fmin(x[1] - (-kPi / 2.), -x[1] + kPi / 2.));
+		return max_num(max_num(x[0] - kPi, -x[0] - kPi / 2.), fabs(x[1]) - kPi / 2.);
 	}
+	__device__ static double marginOfMagnitude(double m) { return -m; }
+	__device__ static double safetyMin(const DevOptions &o, const double (&x)[NX]) { return marginOfMagnitude(safetyMagnitude(o, x)); }
 	// -pi/2 - hmin <= x0 <= pi - hmin: see InvertedPendulum::trigArgsBounded
 	static constexpr bool kTrigBoundedByMargin = true;
 	__device__ static bool trigArgsBounded(double hmin) { return hmin >= -0.9 * kTrigFastRange; }
