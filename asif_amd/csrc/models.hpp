@@ -88,6 +88,18 @@ __device__ __forceinline__ double fma_sc(double a, double b, double c)
 #endif
 }
 
+// a*b + c as the three-address instruction, every operand in vector registers
+__device__ __forceinline__ double fma3(double a, double b, double c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	double r;
+	asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+#else
+	return fma(a, b, c);
+#endif
+}
+
 // How the fast path's argument range (|x| <= 1e5) is policed (the same constant selects the backup loop's step form:
 // anything but kTrigChecked also takes BackupLoop::saturateSoft<FAST>, which needs DevOptions::satFastOk):
 //   kTrigChecked    one wave-level test per call and a branch that sane trajectories never take;
@@ -124,8 +136,10 @@ __device__ __forceinline__ void sincos_carry(double x, TrigCarry &cy)
 	const double d = x - cy.x;
 	const double d2 = d * d;
 	// sin d to d^7 and cos d - 1 to d^8: truncation d^9 / 9! and d^10 / 10!, 5e-18 and 3e-20 at |d| = 0.05
-	const double sd = fma(d * d2, fma(d2, fma(d2, -1.98412698412698412698e-04, 8.33333333333333333333e-03), -1.66666666666666666667e-01), d);
-	const double cm = d2 * fma(d2, fma(d2, fma(d2, 2.48015873015873015873e-05, -1.38888888888888888889e-03), 4.16666666666666666667e-02), -0.5);
+	// (Horner steps as three-address v_fma: the compiler's two-address v_fmac first copies the constant addend into
+	// the destination, one v_mov_b64 per step in this loop-carried context)
+	const double sd = fma(d * d2, fma3(d2, fma3(d2, -1.98412698412698412698e-04, 8.33333333333333333333e-03), -1.66666666666666666667e-01), d);
+	const double cm = d2 * fma3(d2, fma3(d2, fma3(d2, 2.48015873015873015873e-05, -1.38888888888888888889e-03), 4.16666666666666666667e-02), -0.5);
 	const double s = cy.s, c = cy.c;
 	cy.s = s + fma(s, cm, c * sd);
 	cy.c = c + fma(c, cm, -(s * sd));
