@@ -284,7 +284,7 @@ struct BackupLoop {
 		r.xg[1] = x[M::kGradStates[1]];
 		M::backupController(o, x, u, Du);
 		saturateSoft<true>(o, u[0], r.uSat, r.DuSat);
-		sincos_carry(x[M::kTrigAngle], cy);
+		sincos_carry<(M::NX <= 2)>(x[M::kTrigAngle], cy); // (the segway's kernels have no vector register to spare)
 		r.s = cy.s;
 		r.c = cy.c;
 		typename M::Trig t;

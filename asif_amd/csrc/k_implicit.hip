@@ -80,7 +80,7 @@ struct ImplicitLds {
 };
 
 template <class M, bool RB, bool DOPRI = false, int CKPT = kImCkptSpill>
-__global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, FilterArgs a)
+__global__ __launch_bounds__(256) void implicit_rows_kernel(DevOptions o_arg, FilterArgs a)
 {
 	// the soft saturation selects between these two and the input: as kernel arguments (SGPRs) they are copied into
 	// VGPRs at every Euler step; an opaque copy made once, here, stays in two VGPR pairs for the whole kernel
@@ -93,13 +93,17 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 	static_assert(!RB || NP >= NX, "Dh_index_ takes the first nx entries of a column of the npSS x nx product");
 	extern __shared__ double im_lds[];
 	using L = ImplicitLds<M>;
-	double *const pay = im_lds;                                                 // pass 2: states of the K most critical samples
-	double *const ckl = CKPT == kImCkptLds2 ? im_lds + L::kPay : im_lds;        // pass 1: checkpoints of the K selected blocks
-	double *const act = im_lds + (CKPT == kImCkptLds2 ? L::kPay + L::kCk : (L::kPay > L::kCk ? L::kPay : L::kCk));
+	// a workgroup is one to four waves that share nothing (launchers.hpp: waves_per_workgroup): each has its own regions
+	const int wv = (int)(threadIdx.x >> 6);
+	double *const wlds = im_lds + (size_t)wv * (L::bytes(CKPT, RB) / sizeof(double));
+	double *const pay = wlds;                                                 // pass 2: states of the K most critical samples
+	double *const ckl = CKPT == kImCkptLds2 ? wlds + L::kPay : wlds;          // pass 1: checkpoints of the K selected blocks
+	double *const act = wlds + (CKPT == kImCkptLds2 ? L::kPay + L::kCk : (L::kPay > L::kCk ? L::kPay : L::kCk));
 	(void)act;
 	(void)ckl;
-	const int lane = threadIdx.x;
+	const int lane = (int)(threadIdx.x & 63);
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i - lane >= a.B) return; // a wave past the end of the batch (wave-uniform; the kernel has no barrier)
 	const bool live = i < a.B;
 	if (!live) i = a.B - 1;
 
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(64) void implicit_rows_kernel(DevOptions o_arg, Fil
 			run(std::true_type());
 			bool bad = false;
 #pragma unroll
-			for (int c = 0; c < NZ; c++) bad = bad || !(fabs(z[c]) < kStateSane); // NaN included
+			for (int c = 0; c < NZ; c++) bad = bad || (c < NX ? !(fabs(z[c]) < kStateSane) : (z[c] != z[c])); // x: NaN or beyond any sane magnitude; Q: NaN (a stiff model's sensitivity may overflow under forward Euler, as it does upstream)
 			if constexpr (trig_carry<M>::value) bad = bad || !M::trigCarryBounded(o, brun.value());
 			else if constexpr (trig_by_margin<M>::value) bad = bad || !M::trigArgsBounded(brun.value());
 			redo = __any(bad); // never on sane trajectories
@@ -508,13 +512,14 @@ struct ImplicitPolicy {
 };
 
 template <class K>
-static int launch_with_lds(K kern, size_t bytes, int grid, const DevOptions &o, const FilterArgs &a, hipStream_t stream)
+static int launch_with_lds(K kern, size_t bytes, int64_t waves, int nw, const DevOptions &o, const FilterArgs &a, hipStream_t stream)
 {
+	bytes *= (size_t)nw;
 	if (bytes > 48 * 1024) {
 		const hipError_t he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 		if (he != hipSuccess) return (int)he;
 	}
-	hipLaunchKernelGGL(kern, dim3(grid), dim3(64), bytes, stream, o, a);
+	hipLaunchKernelGGL(kern, dim3((unsigned)((waves + nw - 1) / nw)), dim3(64 * nw), bytes, stream, o, a);
 	return (int)hipGetLastError();
 }
 
@@ -523,23 +528,30 @@ template <class M>
 static int launch_rows(const DevOptions &o, const FilterArgs &a, hipStream_t stream, bool rb)
 {
 	using L = ImplicitLds<M>;
-	const int grid = grid_for(a.B, 1, 64);
-	if (o.integrator == 1) // one pass, no checkpoints: payload region only
-		return launch_with_lds(implicit_rows_kernel<M, false, true>, L::bytes(kImCkptSpill, false), grid, o, a, stream);
-	static const int cus = []() {
-		int dev = 0, n = 256;
-		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-		return n > 0 ? n : 256;
-	}();
-	const size_t both = L::bytes(kImCkptLds2, rb);
-	const int per_cu = (int)((160 * 1024) / both);
-	const bool lds2 = per_cu >= 1 && (int64_t)grid <= (int64_t)(per_cu < 4 ? per_cu : 4) * cus;
-	if (rb) {
-		if (lds2) return launch_with_lds(implicit_rows_kernel<M, true, false, kImCkptLds2>, both, grid, o, a, stream);
-		return launch_with_lds(implicit_rows_kernel<M, true, false, kImCkptSpill>, L::bytes(kImCkptSpill, true), grid, o, a, stream);
+	const int64_t waves = grid_for(a.B, 1, 64);
+	const int cus = device_cus();
+	constexpr size_t kLds = 160 * 1024;
+	// four waves per workgroup when the launch is large (waves_per_workgroup), as far as their regions fit a CU's LDS
+	auto nwaves = [&](size_t bytes) {
+		int nw = waves_per_workgroup(waves);
+		while (nw > 1 && (size_t)nw * bytes > kLds) nw /= 2;
+		return nw;
+	};
+	if (o.integrator == 1) { // one pass, no checkpoints: payload region only
+		const size_t b = L::bytes(kImCkptSpill, false);
+		return launch_with_lds(implicit_rows_kernel<M, false, true>, b, waves, nwaves(b), o, a, stream);
 	}
-	if (lds2) return launch_with_lds(implicit_rows_kernel<M, false, false, kImCkptLds2>, both, grid, o, a, stream);
-	return launch_with_lds(implicit_rows_kernel<M, false, false, kImCkptSpill>, L::bytes(kImCkptSpill, false), grid, o, a, stream);
+	const size_t both = L::bytes(kImCkptLds2, rb), one = L::bytes(kImCkptSpill, rb);
+	const int per_cu = (int)(kLds / both);
+	const bool lds2 = per_cu >= 1 && waves <= (int64_t)(per_cu < 4 ? per_cu : 4) * cus;
+	const size_t b = lds2 ? both : one;
+	const int nw = nwaves(b);
+	if (rb) {
+		if (lds2) return launch_with_lds(implicit_rows_kernel<M, true, false, kImCkptLds2>, b, waves, nw, o, a, stream);
+		return launch_with_lds(implicit_rows_kernel<M, true, false, kImCkptSpill>, b, waves, nw, o, a, stream);
+	}
+	if (lds2) return launch_with_lds(implicit_rows_kernel<M, false, false, kImCkptLds2>, b, waves, nw, o, a, stream);
+	return launch_with_lds(implicit_rows_kernel<M, false, false, kImCkptSpill>, b, waves, nw, o, a, stream);
 }
 
 int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,

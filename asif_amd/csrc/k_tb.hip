@@ -124,9 +124,14 @@ __device__ __forceinline__ void tb_q_role(const DevOptions &o, const double *rin
 // Round 2 wrote a checkpoint to HBM whenever a block ENTERED the selection: on the segway, whose margins shrink along
 // the trajectory, nearly every 4-sample block does -- 171 MB of writes per 32 768 instances (PMC), 5.2 KB per instance.
 constexpr int kCkptLds2 = 1, kCkptSpill = 2;
+// waves per workgroup of the fused pass that the kernel is compiled for: the two-state models' kernels (200 VGPRs) take
+// up to four; the segway's sits at the 256-VGPR line, and a larger launch bound makes the compiler cross it further
+// (266 with AGPRs against 262)
+template <class M>
+constexpr int tb_max_wg_waves() { return M::NX <= 2 ? 4 : 1; }
 
 template <class M, int CKPT, bool SPLIT = false>
-__global__ __launch_bounds__(SPLIT ? 128 : 64) void tb_rows_kernel(DevOptions o_arg, FilterArgs a)
+__global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_rows_kernel(DevOptions o_arg, FilterArgs a)
 {
 	static_assert(!SPLIT || CKPT == kCkptSpill, "the two-role pass keeps its step records where the own-region checkpoints would be");
 	// the soft saturation selects between these two and the input: as kernel arguments (SGPRs) they are copied into
@@ -135,11 +140,16 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void tb_rows_kernel(DevOptions o_
 	asm("" : "+v"(o.lb[0]), "+v"(o.ub[0]));
 	constexpr int NX = M::NX, NP = M::NPSS, K = M::NPBTSS, NZ = NX + NX * NX;
 	constexpr int NC = K * NP + 2, NV = 2;
-	extern __shared__ double tb_lds[];
+	extern __shared__ double tb_lds_all[];
+	double *const tb_lds = tb_lds_all + (SPLIT ? 0 : (size_t)(threadIdx.x >> 6) * (CKPT == kCkptLds2 ? 2 : 1) * K * NZ * 64);
 	double *const pay = tb_lds;                                            // pass 2: states of the K most critical samples
 	double *const ckl = CKPT == kCkptLds2 ? tb_lds + K * NZ * 64 : tb_lds; // pass 1: states at the start of the K selected blocks
-	const int lane = SPLIT ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
-	int64_t i = (int64_t)blockIdx.x * 64 + lane;
+	// fused pass: a workgroup is one to four waves that share nothing (launchers.hpp: waves_per_workgroup), each with LDS
+	// regions of its own; two-role pass: the two waves of one 64-instance group
+	const int lane = (int)(threadIdx.x & 63);
+	const int wv = SPLIT ? 0 : (int)(threadIdx.x >> 6), nwv = SPLIT ? 1 : (int)(blockDim.x >> 6);
+	int64_t i = ((int64_t)blockIdx.x * nwv + wv) * 64 + lane;
+	if (!SPLIT && i - lane >= a.B) return; // a wave past the end of the batch (wave-uniform; the fused pass has no barrier)
 	const bool live = i < a.B;
 	if (!live) i = a.B - 1;
 	const int64_t ld = a.ld;
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void tb_rows_kernel(DevOptions o_
 		else pass1(std::true_type());
 		bool bad = alarm;
 #pragma unroll
-		for (int k = 0; k < NZ; k++) bad = bad || !(fabs(z[k]) < kStateSane); // NaN included
+		for (int k = 0; k < NZ; k++) bad = bad || (k < NX ? !(fabs(z[k]) < kStateSane) : (z[k] != z[k])); // x: NaN or beyond any sane magnitude; Q: NaN (a stiff model's sensitivity may overflow under forward Euler, as it does upstream)
 		if constexpr (trig_carry<M>::value) bad = bad || !M::trigCarryBounded(o, hall);
 		else if constexpr (trig_by_margin<M>::value) bad = bad || !M::trigArgsBounded(hall);
 		redo = __any(bad); // never on sane trajectories
@@ -678,11 +688,7 @@ static int launch_tb(const DevOptions &o, const asif_hip_solver &S, const Filter
 		const int grid = grid_for(a.B, 1, 64);
 		// a region of their own for the checkpoints costs LDS-limited occupancy (two waves per CU for the segway): taken
 		// when the batch does not need more than that
-		static const int cus = []() {
-			int dev = 0, n = 256;
-			if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-			return n > 0 ? n : 256;
-		}();
+		const int cus = device_cus();
 		const int per_cu = (int)((160 * 1024) / (2 * region));
 		const bool both = per_cu >= 1 && (int64_t)grid <= (int64_t)per_cu * cus;
 		hipError_t he = hipSuccess;
@@ -706,16 +712,20 @@ static int launch_tb(const DevOptions &o, const asif_hip_solver &S, const Filter
 		if (split) {
 		} else if (both) {
 			auto kern = tb_rows_kernel<M, kCkptLds2>;
-			if (2 * region > 48 * 1024)
-				he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * region));
+			int nw = waves_per_workgroup(grid); // four waves per workgroup when the launch is large, as far as LDS allows
+			while (nw > 1 && ((size_t)nw * 2 * region > 160 * 1024 || nw > tb_max_wg_waves<M>())) nw /= 2;
+			if (nw * 2 * region > 48 * 1024)
+				he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(nw * 2 * region));
 			if (he != hipSuccess) return (int)he;
-			hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 2 * region, stream, o, a);
+			hipLaunchKernelGGL(kern, dim3((grid + nw - 1) / nw), dim3(64 * nw), nw * 2 * region, stream, o, a);
 		} else {
 			auto kern = tb_rows_kernel<M, kCkptSpill>;
-			if (region > 48 * 1024)
-				he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)region);
+			int nw = waves_per_workgroup(grid);
+			while (nw > 1 && ((size_t)nw * region > 160 * 1024 || nw > tb_max_wg_waves<M>())) nw /= 2;
+			if (nw * region > 48 * 1024)
+				he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(nw * region));
 			if (he != hipSuccess) return (int)he;
-			hipLaunchKernelGGL(kern, dim3(grid), dim3(64), region, stream, o, a);
+			hipLaunchKernelGGL(kern, dim3((grid + nw - 1) / nw), dim3(64 * nw), nw * region, stream, o, a);
 		}
 	}
 	int e = (int)hipGetLastError();

@@ -1,5 +1,6 @@
 // launchers.hpp -- host-side launch functions, one per kernel family (each lives in its own .hip TU).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "asif_hip.h"
@@ -145,6 +146,32 @@ inline asif_hip_solver resolve_scaling(const asif_hip_solver &S, int path_defaul
 	// without a finish a check only tests residuals: OSQP-ish period instead of the finish paths' 1-2 iterations
 	if (r.check_interval <= 0) r.check_interval = r.polish == 0 ? 10 : check_default;
 	return r;
+}
+
+// Waves per workgroup for kernels whose waves are independent of one another (no LDS sharing, no barrier).  One-wave
+// workgroups are the natural unit, but the dispatcher places a workgroup's waves on different SIMDs of a CU and makes no
+// such promise ACROSS workgroups: from three one-wave workgroups per CU on, some SIMDs get two waves while others get
+// none, and kernels that run one latency-bound wave per SIMD lose 30-50 % (C12 at 65 536 instances: 372 us at one
+// workgroup per CU, 538 us at four; C3 at 65 536: 1 388 us, 968 us as four-wave workgroups).  So: four waves
+// per workgroup once the launch has more than two waves per CU.
+inline int device_cus()
+{
+	static const int cus = []() {
+		int dev = 0, n = 256;
+		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+		return n > 0 ? n : 256;
+	}();
+	return cus;
+}
+inline int waves_per_workgroup(int64_t waves)
+{
+	static const int forced = []() {
+		const char *e = getenv("ASIF_HIP_WG_WAVES"); // developer switch: 1, 2 or 4
+		const int v = e ? atoi(e) : 0;
+		return (v == 1 || v == 2 || v == 4) ? v : 0;
+	}();
+	if (forced) return forced;
+	return waves > (int64_t)2 * device_cus() ? 4 : 1;
 }
 
 inline int grid_for(int64_t B, int G, int block)

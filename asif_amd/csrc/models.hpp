@@ -131,6 +131,10 @@ struct TrigCarry {
 	double x, s, c; // angle at which s = sin, c = cos hold
 };
 constexpr double kTrigCarryMaxStep = 0.05; // truncation of the two polynomials there: 5e-18 and 3e-20
+// VREGS: the Horner steps as three-address v_fma with every constant in a vector register (14 registers for the 7
+// constants); false leaves the choice to the compiler (constants in scalar registers, two-address v_fmac) -- for the
+// segway's kernels, which have no vector register to spare.  Same values either way.
+template <bool VREGS = true>
 __device__ __forceinline__ void sincos_carry(double x, TrigCarry &cy)
 {
 	const double d = x - cy.x;
@@ -138,8 +142,9 @@ __device__ __forceinline__ void sincos_carry(double x, TrigCarry &cy)
 	// sin d to d^7 and cos d - 1 to d^8: truncation d^9 / 9! and d^10 / 10!, 5e-18 and 3e-20 at |d| = 0.05
 	// (Horner steps as three-address v_fma: the compiler's two-address v_fmac first copies the constant addend into
 	// the destination, one v_mov_b64 per step in this loop-carried context)
-	const double sd = fma(d * d2, fma3(d2, fma3(d2, -1.98412698412698412698e-04, 8.33333333333333333333e-03), -1.66666666666666666667e-01), d);
-	const double cm = d2 * fma3(d2, fma3(d2, fma3(d2, 2.48015873015873015873e-05, -1.38888888888888888889e-03), 4.16666666666666666667e-02), -0.5);
+	auto h = [](double a, double b, double c) { return VREGS ? fma3(a, b, c) : fma(a, b, c); };
+	const double sd = fma(d * d2, h(d2, h(d2, -1.98412698412698412698e-04, 8.33333333333333333333e-03), -1.66666666666666666667e-01), d);
+	const double cm = d2 * h(d2, h(d2, h(d2, 2.48015873015873015873e-05, -1.38888888888888888889e-03), 4.16666666666666666667e-02), -0.5);
 	const double s = cy.s, c = cy.c;
 	cy.s = s + fma(s, cm, c * sd);
 	cy.c = c + fma(c, cm, -(s * sd));
@@ -846,7 +851,7 @@ struct Segway {
 			sincos_fast<kTrigUnchecked>(x[2], cy.s, cy.c);
 			cy.x = x[2];
 		} else {
-			sincos_carry(x[2], cy);
+			sincos_carry<false>(x[2], cy);
 		}
 		Trig t;
 		t.s1 = cy.s;

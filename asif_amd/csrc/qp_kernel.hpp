@@ -37,7 +37,7 @@ template <class P>
 struct reads_staged_rows<P, std::enable_if_t<P::kStagedRows>> : std::true_type {};
 
 template <int NV, int NC, int G, class Policy>
-__global__ __launch_bounds__(64) void qp_policy_kernel(asif_hip_solver S, Policy pol)
+__global__ __launch_bounds__(256) void qp_policy_kernel(asif_hip_solver S, Policy pol)
 {
 	constexpr int RPL = (NC + G - 1) / G;
 	// G > 1: a wave covers 64 / G consecutive instances, i.e. 8 * 64 / G bytes of every SoA row -- less than the 128-byte
@@ -66,7 +66,8 @@ __global__ __launch_bounds__(64) void qp_policy_kernel(asif_hip_solver S, Policy
 template <int NV, int NC, int G, class Policy>
 static int launch_policy(const asif_hip_solver &S0, const Policy &pol, hipStream_t stream, int default_scaling = 2)
 {
-	const int block = 64;
+	// independent waves: four per workgroup when the launch is large (launchers.hpp: waves_per_workgroup)
+	const int block = 64 * waves_per_workgroup(grid_for(pol.B, G, 64));
 	const asif_hip_solver S = resolve_scaling(S0, default_scaling);
 	const unsigned nblk = grid_for(pol.B, G, block);
 	hipLaunchKernelGGL((qp_policy_kernel<NV, NC, G, Policy>), dim3((G > 1 && reads_staged_rows<Policy>::value) ? xcd_grid(nblk) : nblk), dim3(block), 0,
