@@ -237,9 +237,13 @@ def valu_roofline(sq, step_ms, tag):
             "issue_cycles_per_inst": VALU_ISSUE_CYCLES, "simd_cycles_available": avail, "frac": used / avail,
             "counters_source": f"profiles/{PROFILE_ROUND}/{tag}_sq_summary.json (rocprofv3 --pmc, separate pass of the "
                                "same command); duration measured live",
-            "note": "frac = share of all SIMD issue slots of the chip used by vector instructions over the step; "
-                    "with one wave per SIMD a dependent FP64 chain issues at best every ~8 cycles, so ~0.5 is the "
-                    "ceiling of a latency-bound kernel at this batch size"}
+            "single_wave_ceiling": 4.0 / 5.16,
+            "note": "frac = share of all SIMD issue slots of the chip (4 cycles per vector instruction: the 78.6 TFLOP/s "
+                    "FP64 peak) used by vector instructions over the step.  Measured on this part "
+                    "(profiles/r03/fp64_peak_microbench.txt, simd_mix_microbench.txt): ONE wave on a SIMD issues an "
+                    "independent v_fma_f64 every 5.16 cycles (59 TFLOP/s with a wave on every SIMD; 72 TFLOP/s needs four "
+                    "or more waves per SIMD) and a dependent one every 6.25, so 0.78 is the ceiling of a kernel whose batch "
+                    "gives a SIMD one wave, and a branch instruction costs such a wave 45-55 cycles"}
 
 
 def spawn_ranks(n):

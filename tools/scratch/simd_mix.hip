@@ -122,7 +122,7 @@ int main(int argc, char **argv)
 	const int only = argc > 1 ? atoi(argv[1]) : -1;
 	if (only < 0 || only == 0) run<0>("fma only");
 	if (only < 0 || only == 1) run<1>("fma + compare + select");
-	if (only < 0 || only == 2) run<2>("fma + never-taken exec-mask branch");
+	if (only < 0 || only == 2) run<2>("fma + sqrt under a condition (if-converted)");
 	if (only < 0 || only == 3) run<3>("multiply and add, not fused");
 	if (only < 0 || only == 4) run<4>("fma + 32-bit integer VALU");
 	if (only < 0 || only == 5) run<5>("fma + v_max_f64 / v_min_f64");
