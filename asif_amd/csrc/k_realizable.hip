@@ -179,13 +179,13 @@ __device__ __forceinline__ void fold_row(double a, double c, double &lo, double 
 // the scalar-load form (used when the kernel polytope is too large for LDS) has to drain its whole queue at
 // every wait (SMEM returns out of order) and spent ~0.2 us of load latency per facet per launch.
 template <int KB, bool LDSREC>
-__global__ __launch_bounds__(64) void realizable_filter_kernel(RzDev z, asif_hip_solver S, FilterArgs a,
+__global__ __launch_bounds__(256) void realizable_filter_kernel(RzDev z, asif_hip_solver S, FilterArgs a,
                                                                bool assemble_only)
 {
 	constexpr int NV = 2, RPL = KB;
 	extern __shared__ double srec[]; // [nF][8] when LDSREC
 	if (LDSREC) {
-		for (int k = threadIdx.x; k < z.nF * 8; k += 64)
+		for (int k = threadIdx.x; k < z.nF * 8; k += blockDim.x) // (one to four waves per workgroup share the table)
 			srec[k] = (k & 7) < 7 ? z.facetRec[(size_t)(k >> 3) * kRzRec + (k & 7)] : 0.0;
 		__syncthreads();
 	}
@@ -437,7 +437,8 @@ int launch_realizable(const RzDev &z, const asif_hip_solver &S0, const FilterArg
 	if (a.B <= 0) return 0;
 	const asif_hip_solver S = resolve_scaling(S0, 2);
 	if (z.maxCrit > kRzMaxCrit || z.npSSmax > 4) return ASIF_HIP_EUNSUPPORTED;
-	const dim3 grid(grid_for(a.B, 1, 64)), block(64);
+	const int nw = waves_per_workgroup(grid_for(a.B, 1, 64)); // independent waves (launchers.hpp)
+	const dim3 grid(grid_for(a.B, 1, 64 * nw)), block(64 * nw);
 	const size_t recBytes = (size_t)z.nF * 8 * sizeof(double);
 	const bool lds = recBytes <= 48 * 1024;
 	if (z.npSSmax <= 2) {
