@@ -120,6 +120,7 @@ struct BackupLoop {
 	template <bool FAST = false>
 	__device__ __forceinline__ static void saturateSoft(const DevOptions &o, double u, double &uSat, double &DuSat)
 	{
+#pragma clang fp contract(on) // fused where written as one, nowhere else: the same bits in every kernel this is inlined into
 		const double r = o.satSharpness;
 		const double mi = o.lb[0], ma = o.ub[0]; // in VGPRs already: see the rows kernels' prologue
 		const double range = o.satRange;
@@ -138,7 +139,8 @@ struct BackupLoop {
 			DuSat = clamped ? 0.0 : 1.0;
 			if (au > o.bevelStart && !clamped) { // divergent: skipped by the wave when no lane is in a bevel
 				const bool neg = uc < 0.0;
-				const double d = r * r - (au - xc) * (au - xc);
+				const double t = au - xc;
+				const double d = fma(-t, t, r * r);
 				double sq;
 				bevel_arc(d, xc - au, sq, DuSat);
 				const double us = 0.5 * (sq + yc) * range;
@@ -155,13 +157,17 @@ struct BackupLoop {
 				uSat = u;
 				DuSat = 1.0;
 			} else if (uc > o.bevelStart) {
-				const double sq = sqrt(r * r - (uc - xc) * (uc - xc));
+				const double t = uc - xc;
+				const double sq = sqrt(fma(-t, t, r * r));
 				DuSat = (xc - uc) / sq;
-				uSat = 0.5 * (sq + yc) * range + middle;
+				const double us = 0.5 * (sq + yc) * range;
+				uSat = us + middle;
 			} else if (uc < -o.bevelStart) {
-				const double sq = sqrt(r * r - (uc + xc) * (uc + xc));
+				const double t = uc + xc;
+				const double sq = sqrt(fma(-t, t, r * r));
 				DuSat = (xc + uc) / sq;
-				uSat = 0.5 * (-sq - yc) * range + middle;
+				const double us = 0.5 * (-sq - yc) * range;
+				uSat = us + middle;
 			} else { // NaN
 				uSat = u;
 				DuSat = 1.0;

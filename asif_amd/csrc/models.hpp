@@ -137,6 +137,7 @@ constexpr double kTrigCarryMaxStep = 0.05; // truncation of the two polynomials 
 template <bool VREGS = true>
 __device__ __forceinline__ void sincos_carry(double x, TrigCarry &cy)
 {
+#pragma clang fp contract(on)
 	const double d = x - cy.x;
 	const double d2 = d * d;
 	// sin d to d^7 and cos d - 1 to d^8: truncation d^9 / 9! and d^10 / 10!, 5e-18 and 3e-20 at |d| = 0.05
@@ -162,6 +163,7 @@ struct trig_by_margin<M, std::enable_if_t<M::kTrigBoundedByMargin>> : std::true_
 template <int POISON = kTrigChecked>
 __device__ __forceinline__ void sincos_fast(double x, double &s, double &c)
 {
+#pragma clang fp contract(on) // the same bits in every kernel this is inlined into (k_implicit.hip / k_tb.hip: two-role passes)
 	const double n = rint(x * 6.36619772367581382433e-01);
 	double r = fma(-n, 1.57079632679489655800e+00, x);
 	r = fma(-n, 6.12323399573676603587e-17, r);
@@ -409,6 +411,7 @@ struct InvertedPendulum {
 	// :63-71  u = K x, K = (-3,-3)
 	__device__ static void backupController(const DevOptions &, const double (&x)[NX], double (&u)[NU], double (&Du)[NU * NX])
 	{
+#pragma clang fp contract(on)
 		u[0] = -3.0 * x[0] + -3.0 * x[1];
 		Du[0] = -3.0;
 		Du[1] = -3.0;
@@ -562,6 +565,7 @@ struct DoubleIntegratorImplicit {
 	// :65-73  u = K x, K = (-10, -20)
 	__device__ static void backupController(const DevOptions &, const double (&x)[NX], double (&u)[NU], double (&Du)[NU * NX])
 	{
+#pragma clang fp contract(on)
 		u[0] = (0.0 + -10.0 * x[0]) + -20.0 * x[1];
 		Du[0] = -10.0;
 		Du[1] = -20.0;
@@ -645,6 +649,7 @@ struct InvertedPendulumTB {
 	// :76-85  u = K (vDes - omega)
 	__device__ static void backupController(const DevOptions &, const double (&x)[NX], double (&u)[NU], double (&Du)[NU * NX])
 	{
+#pragma clang fp contract(on)
 		u[0] = 10. * ((kPi / 10.) - x[1]);
 		Du[0] = 0.;
 		Du[1] = -10.;

@@ -47,3 +47,4 @@ def test_a_batch_equals_the_prefix_of_a_larger_one(hip, cfg, n, big):
     rs, rl = gpu_util.run_assemble(cfg, n), gpu_util.run_assemble(cfg, big)
     for k in ("A", "b", "code", "diag"):
         assert np.array_equal(rs[k], rl[k][..., :n], equal_nan=True), k
+
