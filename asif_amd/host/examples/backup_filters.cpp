@@ -3,6 +3,7 @@
 // reference examples' (examples/InvertedPendulum_Implicit.cpp:31-80, examples/segway_implicit_tb.cpp:27-212);
 // the compiled device functors are reused as host functions so both paths see the same model.
 //   usage: backup_filters implicit|tb|tbdi N      prints  i,uAct,relax0,relax1,rc,uActBatch,rcBatch
+//          backup_filters tb-loop STEPS [PUSH]    the closed loop of examples/segway_implicit_tb.cpp:236-275 (pitch rate PUSH at t = 0)
 //          backup_filters tbdi-loop STEPS         the closed loop of examples/DoubleIntegrator_implicit_tb.cpp:105-160
 //                                                 (fused-gradient constructor, updateOptions at half time); prints
 //                                                 i,x0,x1,uAct,relax,TTS,rc,updated with the state the filter was called on
@@ -86,7 +87,7 @@ struct HostModel {
 int main(int argc, char **argv)
 {
 	if (argc < 3) return 2;
-	const bool tb = !std::strcmp(argv[1], "tb");
+	const bool tb = !std::strncmp(argv[1], "tb", 2) && std::strncmp(argv[1], "tbdi", 4);
 	const long N = std::atol(argv[2]);
 	if (!std::strncmp(argv[1], "tbdi", 4)) {
 		typedef HostModel<asif::DoubleIntegratorTB> H;
@@ -143,7 +144,7 @@ int main(int argc, char **argv)
 		}
 		return 0;
 	}
-	std::printf("i,uAct,relax0,relax1,rc,uActBatch,rcBatch\n");
+	if (std::strcmp(argv[1], "tb-loop")) std::printf("i,uAct,relax0,relax1,rc,uActBatch,rcBatch\n");
 	if (!tb) {
 		typedef HostModel<asif::InvertedPendulum> H;
 		const double lb[1] = {-1.5}, ub[1] = {1.5};
@@ -181,6 +182,32 @@ int main(int argc, char **argv)
 		opts.backTrajMinOrtho = 0.001;
 		ASIF::ASIFimplicitTB flt(4, 1, 4, 4, H::safetySet, H::backupSet4, H::dynamics, H::gradients, H::controller);
 		if (flt.initialize(lb, ub, opts) != 1 || flt.bindDeviceModel(ASIF_HIP_MODEL_SEGWAY) != 0) return 3;
+		if (!std::strcmp(argv[1], "tb-loop")) {
+			// the closed loop of examples/segway_implicit_tb.cpp:236-275: from rest with uDes = 0, plant Euler at 1 ms,
+			// updateOptions(backTrajHorizon = 6) once t > tEnd / 2.  x0 is given a push (argv[3], pitch rate) so that the
+			// loop leaves the backup set and the filter has something to do; 0 reproduces the example literally.
+			const double dt = 0.001, tEnd = dt * (double)N; // the example runs to 10.99 s
+			double x[4] = {0.0, 0.0, 0.0, argc > 3 ? std::atof(argv[3]) : 0.0}, t = 0.0;
+			const double ud[1] = {0.0};
+			bool updated = false;
+			std::printf("i,x0,x1,x2,x3,uAct,relax,TTS,rc,updated\n");
+			for (long i = 0; i < N; i++) {
+				if (!updated && t > tEnd / 2) {
+					opts.backTrajHorizon = 6.0;
+					updated = true;
+					if (flt.updateOptions(opts) != 1) return 5;
+				}
+				double ua[1] = {0.0}, rl = 0.0;
+				const int32_t rc = flt.filter(x, ud, ua, rl);
+				std::printf("%ld,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%d,%d\n", i, x[0], x[1], x[2], x[3], ua[0], rl, flt.TTS_, rc,
+				            (int)updated);
+				double f[4], g[4];
+				H::dynamics(x, f, g);
+				for (int k = 0; k < 4; k++) x[k] += dt * (f[k] + g[k] * ua[0]);
+				t += dt;
+			}
+			return 0;
+		}
 		const double xb[4] = {3.0, 3.0, M_PI / 6, M_PI};
 		std::vector<double> bx(4 * N), bu(N), ba(N, 0.0), br(N, 0.0);
 		std::vector<int32_t> brc(N, 0);

@@ -47,11 +47,11 @@ def test_double_integrator_closed_loop(hip, oracle):
     assert rows[:, 4].min() < 0.0 and rows[:, 1].max() < 1.0 + 1e-6
 
 
-def _run_backup(kind, n):
+def _run_backup(kind, n, *extra):
     exe = os.path.join(HOST, "backup_filters")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", HOST, "-s"])
-    out = subprocess.run([exe, kind, str(n)], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([exe, kind, str(n)] + [str(e) for e in extra], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     return np.array([[float(v) for v in line.split(",")] for line in out.stdout.strip().split("\n")[1:]])
 
@@ -81,6 +81,37 @@ def test_tb_class_single_agent_and_batch(hip, oracle):
     assert {1, 2, -3} <= set(rc.tolist())
     assert np.abs(rows[:, 1] - ua[:, 0]).max() <= 1e-6
     assert np.abs(rows[:, 5] - ua[:, 0]).max() <= 1e-6
+
+
+def test_segway_tb_closed_loop(hip, oracle):
+    """BASELINE config 4's example loop (examples/segway_implicit_tb.cpp:236-275) through the C++ class, literally: from
+    rest, uDes = 0, plant Euler at 1 ms, updateOptions(backTrajHorizon = 6) at half time (1 600 of the example's 10 990
+    steps).  Rest is not an equilibrium of the model (the pitch's is 0.138 rad): the agent drifts out of the backup set
+    within a fraction of a second.  Every step's input must be the exact optimum of the QP the reference assembles on
+    the state the program was in (or the saturated backup controller where the reference applies it), with the options
+    in force: 316 samples before the update, 601 after (no 1 + backTrajExtend, src/asif_implicit_tb.cpp:377)."""
+    steps = 1600
+    rows = _run_backup("tb-loop", steps)
+    assert rows.shape == (steps, 10)
+    upd = rows[:, 9].astype(int)
+    first = int(np.argmax(upd))
+    assert 799 <= first <= 802 and np.all(upd[first:] == 1)
+    model, variant = oracle.CONFIGS[4]
+    o1 = oracle.default_options(model, variant)
+    o2 = oracle.default_options(model, variant)
+    o2.backTrajHorizon = 6.0
+    o2.backTrajExtend = 0.0
+    assert oracle.dims(model, variant, o1).npBT == 316 and oracle.dims(model, variant, o2).npBT == 601
+    x = np.ascontiguousarray(rows[:, 1:5])
+    ud = np.zeros((steps, 1))
+    ua = np.empty(steps)
+    rc = np.empty(steps, dtype=int)
+    for o, sl in ((o1, slice(0, first)), (o2, slice(first, steps))):
+        a, _, r = oracle.filter_batch(model, variant, o, x[sl], ud[sl], oracle.SOLVER_EXACT, nthreads=8)
+        ua[sl], rc[sl] = a[:, 0], r
+    assert np.array_equal(rows[:, 8].astype(int), rc), np.where(rows[:, 8].astype(int) != rc)[0][:10]
+    assert np.abs(rows[:, 5] - ua).max() <= 1e-6
+    assert 2 in rc and (rc != 2).sum() > 100  # starts inside the backup set, leaves it
 
 
 def test_tb_class_double_integrator_single_agent_and_batch(hip, oracle):
