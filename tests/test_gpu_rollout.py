@@ -97,7 +97,7 @@ def test_rollout_rejects_other_variants(hip):
     flt.close()
 
 
-@pytest.mark.parametrize("cfg,T,dt", [(3, 6, 0.001), (9, 25, 0.01), (4, 12, 0.01), (10, 5, 0.001)])
+@pytest.mark.parametrize("cfg,T,dt", [(3, 6, 0.001), (9, 25, 0.01), (4, 12, 0.01), (10, 5, 0.001), (12, 12, 0.001), (8, 3, 0.001)])
 def test_two_stage_filters_closed_loop(hip, oracle, cfg, T, dt):
     """Backup-trajectory classes (examples/InvertedPendulum_Implicit.cpp:113-136 and the like): T x (rows kernel, QP
     kernel, plant step) in stream order.  Checked on the logged states like the fused rollout: the oracle's exact
@@ -135,9 +135,9 @@ def test_two_stage_filters_closed_loop(hip, oracle, cfg, T, dt):
     assert np.array_equal(xlog[0], x)
     # the plant the examples integrate: f, g of the model at the state the filter saw
     def plant(xt):
-        if cfg in (3, 10):
+        if cfg in (3, 10, 8):
             return np.stack([xt[1], np.sin(xt[0])]), np.stack([0 * xt[0], 1 + 0 * xt[0]])
-        if cfg == 9:
+        if cfg in (9, 12):
             return np.stack([xt[1], 0 * xt[0]]), np.stack([0 * xt[0], 1 + 0 * xt[0]])
         return None, None
     for t in range(T):
