@@ -238,7 +238,7 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 	// the reference's USE_ODEINT build exists for ASIFimplicit, ASIFimplicitTB and ASIFimplicitRB; the device has it for
 	// ASIFimplicit (src/asif_implicit.cpp:427-460)
 	if (o.integrator != 0 && o.integrator != 1) return ASIF_HIP_EINVAL;
-	if (o.integrator == 1 && variant != ASIF_HIP_IMPLICIT) return ASIF_HIP_EUNSUPPORTED;
+	if (o.integrator == 1 && variant != ASIF_HIP_IMPLICIT && variant != ASIF_HIP_IMPLICIT_TB) return ASIF_HIP_EUNSUPPORTED; // (ASIFimplicitRB: held input, Euler only)
 	if (o.integrator == 1 && !(o.backTrajAbsTol > 0 && o.backTrajRelTol > 0)) return ASIF_HIP_EINVAL;
 	dev.integrator = o.integrator;
 	dev.trajAbsTol = o.backTrajAbsTol;

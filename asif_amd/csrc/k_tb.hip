@@ -130,7 +130,7 @@ constexpr int kCkptLds2 = 1, kCkptSpill = 2;
 template <class M>
 constexpr int tb_max_wg_waves() { return M::NX <= 2 ? 4 : 1; }
 
-template <class M, int CKPT, bool SPLIT = false>
+template <class M, int CKPT, bool SPLIT = false, bool DOPRI = false>
 __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_rows_kernel(DevOptions o_arg, FilterArgs a)
 {
 	static_assert(!SPLIT || CKPT == kCkptSpill, "the two-role pass keeps its step records where the own-region checkpoints would be");
@@ -404,6 +404,80 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 		alarm = flags[2] != 0;
 	  }
 	};
+	double zHit[NZ]; // the rows below are written for the state at idxHit
+	TopK<K> top;     // the K most critical samples of [0, idxHit], their states in LDS (payp)
+	top.init();
+	// Two-role pass: nothing is spilled.  Its step records are history by now, so K - 1 payload entries go where the
+	// ring was; the K-th goes into the slot of the checkpoint that pass 2 consumes FIRST (it is in registers before any
+	// payload is stored), and the other checkpoints stay in LDS until their turn.  (42 MB of HBM traffic per 32 768
+	// instances less than writing the survivors out and reading them back: 74 -> 32 MB.)
+	int slFirst = 0;
+	static_assert(!SPLIT || (K - 1) * NZ * 64 <= SL::kRing, "K - 1 payload entries fit the record ring");
+	auto payp = [&](int slot) -> double * { // entry `slot` of the payload, this lane's column
+		if constexpr (SPLIT) return (slot < K - 1 ? ring + slot * NZ * 64 : ckl + slFirst * NZ * 64) + lane;
+		else return pay + slot * NZ * 64 + lane;
+	};
+	if constexpr (DOPRI) {
+		// The reference's USE_ODEINT build (src/asif_implicit_tb.cpp:431-463): the samples are the dense output of an
+		// adaptive dopri5 at t = i backTrajDt instead of Euler steps.  The adaptive step straddles samples, so there is no
+		// per-block restart point: ONE pass with the exact per-sample selection, states parked in LDS; a lane stops at its
+		// first sample inside the backup set (nothing past it is ever read, :505-528).  Unpinned like the implicit class's
+		// (Boost absent; the controller is restated in oracle/or_assembly.c).
+		Dopri5<M> rk;
+		rk.init(o, z, o.trajDt);
+		done = inside || !live;
+		hit = false;
+		idxHit = 0;
+		sLast = 0;
+		t = 0.0;
+		tHit = 0.0;
+#pragma unroll
+		for (int k = 0; k < NZ; k++) zHit[k] = z[k];
+		{
+			const int slot = top.insert(M::safetyMin(o, x0), 0); // sample 0 (never a hit: `inside` is decided above)
+			if (slot >= 0) {
+				double *pp = payp(slot);
+#pragma unroll
+				for (int k = 0; k < NZ; k++) pp[k * 64] = z[k];
+			}
+		}
+		int guard = 200000; // as in k_implicit.hip: a stuck controller must not hang a wave
+#pragma unroll 1
+		for (int s = 1; s < o.npBT; s++) {
+			if (__all(done)) break;
+			const double ts = o.trajDt * (double)s; // backTraj_[i].first, :451
+			while (guard > 0 && __any(!done && rk.behind(ts))) {
+				rk.tryStep(o, !done && rk.behind(ts));
+				guard--;
+			}
+			rk.failed = rk.failed | (!done && rk.behind(ts));
+			double zs[NZ], xs[NX];
+			rk.dense(ts, zs);
+#pragma unroll
+			for (int k = 0; k < NX; k++) xs[k] = zs[k];
+			const double hm = done ? __builtin_huge_val() : M::safetyMin(o, xs);
+			if (__any(hm < top.key[K - 1])) {
+				const int slot = top.insert(hm, s);
+				if (slot >= 0) {
+					double *pp = payp(slot);
+#pragma unroll
+					for (int k = 0; k < NZ; k++) pp[k * 64] = zs[k];
+				}
+			}
+			if (!done) {
+				sLast = s;
+				t = ts;
+				if (M::backupSetInside(o, xs)) {
+					hit = true;
+					done = true;
+					idxHit = s;
+					tHit = ts;
+#pragma unroll
+					for (int k = 0; k < NZ; k++) zHit[k] = zs[k];
+				}
+			}
+		}
+	} else {
 	// (the fast pass also takes the soft saturation's short forms, valid for ordinary saturation constants --
 	// DevOptions::satFastOk, checked on the host; other options run the generic pass)
 	bool redo = !o.satFastOk;
@@ -418,7 +492,6 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 		redo = __any(bad); // never on sane trajectories
 	}
 	if (redo) pass1(std::false_type());
-	double zHit[NZ]; // the rows below are written for the state at idxHit
 #pragma unroll
 	for (int k = 0; k < NZ; k++) zHit[k] = z[k];
 	if constexpr (CKPT == kCkptSpill && !SPLIT) {
@@ -441,20 +514,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 
 	// ---- pass 2: re-integrate the selected blocks in increasing order, exact per-sample selection with the states
 	// parked in LDS; samples beyond the lane's last one (its hit) do not take part
-	TopK<K> top;
-	top.init();
 	int cur = -1;
 	const bool fast2 = o.satFastOk && !redo; // wave-uniform
-	// Two-role pass: nothing is spilled.  Its step records are history by now, so K - 1 payload entries go where the
-	// ring was; the K-th goes into the slot of the checkpoint that pass 2 consumes FIRST (it is in registers before any
-	// payload is stored), and the other checkpoints stay in LDS until their turn.  (42 MB of HBM traffic per 32 768
-	// instances less than writing the survivors out and reading them back: 74 -> 32 MB.)
-	int slFirst = 0;
-	static_assert(!SPLIT || (K - 1) * NZ * 64 <= SL::kRing, "K - 1 payload entries fit the record ring");
-	auto payp = [&](int slot) -> double * { // entry `slot` of the payload, this lane's column
-		if constexpr (SPLIT) return (slot < K - 1 ? ring + slot * NZ * 64 : ckl + slFirst * NZ * 64) + lane;
-		else return pay + slot * NZ * 64 + lane;
-	};
 #pragma unroll 1
 	for (int j = 0; j < K; j++) {
 		int nb = 0x7fffffff, sl = 0;
@@ -509,6 +570,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 				}
 			}
 		}
+	}
 	}
 #pragma unroll
 	for (int k = 0; k < NZ; k++) z[k] = zHit[k];
@@ -704,6 +766,16 @@ static int launch_tb(const DevOptions &o, const asif_hip_solver &S, const Filter
 		// a region of their own for the checkpoints costs LDS-limited occupancy (two waves per CU for the segway): taken
 		// when the batch does not need more than that
 		const int cus = device_cus();
+		if (o.integrator == 1) { // dopri5 dense output (USE_ODEINT): one pass, payload region only
+			auto kern = tb_rows_kernel<M, kCkptSpill, false, true>;
+			int nw = waves_per_workgroup(grid);
+			while (nw > 1 && ((size_t)nw * region > 160 * 1024 || nw > tb_max_wg_waves<M>())) nw /= 2;
+			if (nw * region > 48 * 1024) {
+				const hipError_t he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(nw * region));
+				if (he != hipSuccess) return (int)he;
+			}
+			hipLaunchKernelGGL(kern, dim3((grid + nw - 1) / nw), dim3(64 * nw), nw * region, stream, o, a);
+		} else {
 		const int per_cu = (int)((160 * 1024) / (2 * region));
 		const bool both = per_cu >= 1 && (int64_t)grid <= (int64_t)per_cu * cus;
 		hipError_t he = hipSuccess;
@@ -741,6 +813,7 @@ static int launch_tb(const DevOptions &o, const asif_hip_solver &S, const Filter
 				he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(nw * region));
 			if (he != hipSuccess) return (int)he;
 			hipLaunchKernelGGL(kern, dim3((grid + nw - 1) / nw), dim3(64 * nw), nw * region, stream, o, a);
+		}
 		}
 	}
 	int e = (int)hipGetLastError();

@@ -121,9 +121,11 @@ typedef struct asif_hip_options {
 	 * function; otherwise the npSSmax rows with the smallest h are kept per call, in ascending order of h
 	 * (src/asif.cpp:250-268; ties: lowest index first) and nc = npSSmax */
 	int32_t npSSmax;
-	/* backup-trajectory integrator of ASIFimplicit: 0 = forward Euler (the reference's default build), 1 = the
-	 * reference's USE_ODEINT build: dopri5 with dense output at the sample times (src/asif_implicit.cpp:427-460),
-	 * tolerances Options::backTrajAbsTol / backTrajRelTol (include/asif_implicit.h:29-30) */
+	/* backup-trajectory integrator of ASIFimplicit and ASIFimplicitTB: 0 = forward Euler (the reference's default
+	 * build), 1 = the reference's USE_ODEINT build: dopri5 with dense output at the sample times
+	 * (src/asif_implicit.cpp:427-460, src/asif_implicit_tb.cpp:431-463), tolerances Options::backTrajAbsTol /
+	 * backTrajRelTol (include/asif_implicit.h:29-30).  ASIFimplicitRB (held input: time-dependent rhs) and the
+	 * classes without a trajectory return ASIF_HIP_EUNSUPPORTED for 1. */
 	int32_t integrator;
 	double backTrajAbsTol, backTrajRelTol;
 } asif_hip_options;

@@ -505,7 +505,7 @@ static void integrate(const or_model *m, const or_options *o, int variant, int n
 	memset(&zoh, 0, sizeof(zoh));
 	zoh.dt = T->dt;
 	const int rb = variant == OR_VARIANT_IMPLICIT_RB;
-	const int dopri = o->integrator == 1 && variant == OR_VARIANT_IMPLICIT;
+	const int dopri = o->integrator == 1 && (variant == OR_VARIANT_IMPLICIT || variant == OR_VARIANT_IMPLICIT_TB); /* src/asif_implicit_tb.cpp:431-463 */
 	dopri5_t ds;
 	if (dopri) dopri5_init(&ds, m, o, z0, nz, T->dt);
 	for (int i = 0; i < n; i++) {

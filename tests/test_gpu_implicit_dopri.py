@@ -63,15 +63,17 @@ def test_tolerance_is_honoured(hip):
     assert d2 < 1e-3 * d1 and d2 <= 1e-6 and d1 <= 5e-2, (d1, d2)
 
 
-def test_only_the_plain_implicit_class_has_it(hip):
+def test_classes_without_it_refuse(hip):
     o = hip.default_options(hip.MODEL_INVERTED_PENDULUM, hip.IMPLICIT_RB)
     o.integrator = 1
     with pytest.raises(hip.AsifHipError):
         hip.Filter(hip.MODEL_INVERTED_PENDULUM, hip.IMPLICIT_RB, options=o)
-    o = hip.default_options(hip.MODEL_SEGWAY, hip.IMPLICIT_TB)
+    # (ASIFimplicitTB has it since round 3: tests/test_gpu_tb_dopri.py; ASIFimplicitRB's held input makes the rhs
+    # time-dependent and stays on forward Euler)
+    o = hip.default_options(hip.MODEL_DOUBLE_INTEGRATOR, hip.EXPLICIT)
     o.integrator = 1
     with pytest.raises(hip.AsifHipError):
-        hip.Filter(hip.MODEL_SEGWAY, hip.IMPLICIT_TB, options=o)
+        hip.Filter(hip.MODEL_DOUBLE_INTEGRATOR, hip.EXPLICIT, options=o)
 
 
 def test_failed_integration_fails_the_filter(hip, oracle):

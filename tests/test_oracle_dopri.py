@@ -82,3 +82,27 @@ def test_dopri5_failure_ends_and_fails_the_filter(oracle):
     assert not np.isfinite(b[:3]).all(axis=1).any() and np.isfinite(b[3]).all() and np.isfinite(A[3]).all()
     ua, rl, rc = oracle.filter_batch(model, variant, o, x, u, uact_init=np.full((4, 1), 7.0))
     assert list(rc) == [-1, -1, -1, 1]
+
+
+def test_tb_with_dopri5_hits_at_the_first_sample_after_the_continuous_hitting_time(oracle):
+    """ASIFimplicitTB in the USE_ODEINT build (src/asif_implicit_tb.cpp:431-463): the samples are dense output at
+    t = i backTrajDt, the hit is the first SAMPLE inside the backup set -- i.e. idxHit = ceil(tau / dt) for the continuous
+    hitting time tau, which tests/test_oracle_tb_rows_fd.py computes independently (RK4 + bisection, the double
+    integrator's disc); forward Euler at dt = 1e-3 can be a sample or two off."""
+    from test_oracle_tb_rows_fd import _di_hit
+    model, variant = oracle.CONFIGS[12]
+    o = oracle.default_options(model, variant)
+    o.integrator = 1
+    o.backTrajAbsTol = o.backTrajRelTol = 1e-10
+    x, _ = oracle.make_batch(12, 200)
+    A, b, code, diag = oracle.assemble_batch(model, variant, o, x)
+    idx = [k for k in np.where(code == 1)[0] if 0.05 < diag[k, 0] < 2.0][:20]
+    assert len(idx) >= 15
+    exact = 0
+    for k in idx:
+        tau = _di_hit(x[k])
+        want = int(np.ceil(tau / 1e-3 - 1e-6))
+        assert abs(int(diag[k, 2]) - want) <= 1, (diag[k, 2], tau)  # (a hitting time within 1e-9 of a sample may round either way)
+        exact += int(diag[k, 2]) == want
+        assert abs(diag[k, 0] - diag[k, 2] * 1e-3) <= 1e-12  # TTS_ = idxHit * backTrajDt: stamped, not accumulated (:451)
+    assert exact >= len(idx) - 1
