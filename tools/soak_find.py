@@ -23,7 +23,7 @@ for c in range(chunks):
     out = gpu_util.run_filter(cfg, B, first=first, uact_init=7.0, relax_init=-7.0)
     d = out["dims"]
     ua, rl, rc = O.filter_batch(model, variant, oo, np.ascontiguousarray(out["x"].T), np.ascontiguousarray(out["udes"].T),
-                                O.SOLVER_EXACT, None, os.cpu_count() or 8, uact_init=np.full((B, d.nu), 7.0))
+                                O.SOLVER_EXACT, None, min(os.cpu_count() or 8, 16), uact_init=np.full((B, d.nu), 7.0))
     for k in np.where(out["rc"] != rc)[0]:
         print(f"instance {first + k}: x {out['x'][:, k].tolist()} uDes {out['udes'][:, k].tolist()} device rc {out['rc'][k]} uAct "
               f"{out['uact'][:, k].tolist()} relax {out['relax'][:, k].tolist()} | oracle rc {rc[k]} uAct {ua[k].tolist()} relax {rl[k].tolist()}", flush=True)

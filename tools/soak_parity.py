@@ -19,7 +19,7 @@ O.build()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
 cfgs = [int(c) for c in sys.argv[2:]] or [2, 3, 4, 5, 8, 9, 11, 12]
 CHUNK = {2: 1 << 20, 3: 8192, 4: 1 << 17, 5: 1 << 18, 8: 4096, 9: 1 << 17, 11: 1 << 19, 12: 1 << 16}
-threads = os.cpu_count() or 8
+threads = min(os.cpu_count() or 8, 16)  # the GPU box's CPU share for one GPU
 print(f"host threads {threads}; budget {budget:.0f} s of oracle time per config", flush=True)
 for cfg in cfgs:
     model, variant = O.CONFIGS[cfg]
