@@ -2,7 +2,7 @@
 """Parity soak (GPU box): device filter() against the oracle's exact answer on MANY more seeded instances than the tests
 and the bench line check -- consecutive ranges of the same generators (workloads.make_batch(cfg, B, first)).  Prints per
 config: instances, rc mismatches, max |uAct - u_ref| over the instances that solved a QP, rc histogram.
-   python tools/soak_parity.py [seconds per config, default 20] [cfg ...]"""
+   python tools/soak_parity.py [seconds per config, default 20] [cfg ...] [--polish=0|1|2]"""
 import os
 import sys
 import time
@@ -16,8 +16,15 @@ import gpu_util  # noqa: E402
 import oracle_lib as O  # noqa: E402
 
 O.build()
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
-cfgs = [int(c) for c in sys.argv[2:]] or [2, 3, 4, 5, 8, 9, 11, 12]
+args = [a for a in sys.argv[1:] if not a.startswith("--polish=")]
+polish = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--polish=")]
+budget = float(args[0]) if len(args) > 0 else 20.0
+cfgs = [int(c) for c in args[1:]] or [2, 3, 4, 5, 8, 9, 11, 12]
+solver = None
+if polish:  # asif_hip_solver::polish: 2 = dual active-set stage first (default), 1 = ADMM + active-set finish, 0 = ADMM alone
+    from asif_amd import capi
+    solver = capi.default_solver(polish=polish[0])
+    print(f"solver mode polish = {polish[0]}", flush=True)
 CHUNK = {2: 1 << 20, 3: 8192, 4: 1 << 17, 5: 1 << 18, 8: 4096, 9: 1 << 17, 11: 1 << 19, 12: 1 << 16}
 threads = min(os.cpu_count() or 8, 16)  # the GPU box's CPU share for one GPU
 print(f"host threads {threads}; budget {budget:.0f} s of oracle time per config", flush=True)
@@ -28,7 +35,7 @@ for cfg in cfgs:
     hist = {}
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < budget:
-        out = gpu_util.run_filter(cfg, B, first=first, uact_init=7.0, relax_init=-7.0)
+        out = gpu_util.run_filter(cfg, B, first=first, uact_init=7.0, relax_init=-7.0, solver=solver)
         d = out["dims"]
         ua, rl, rc = O.filter_batch(model, variant, oo, np.ascontiguousarray(out["x"].T), np.ascontiguousarray(out["udes"].T),
                                     O.SOLVER_EXACT, None, threads, uact_init=np.full((B, d.nu), 7.0))
