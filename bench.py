@@ -481,6 +481,8 @@ def bench_qp(args, grp, dev):
                                "cpu_model": cpu_model(), "single_thread_value": 1.0 / per,
                                "sample": f"{m} of the same problems, OSQP-style ADMM restatement (eps 1e-3, max_iter 2000, "
                                          f"cold start) on one host thread"}
+        m = min(B, 65536)  # parity: a larger head of the batch than the timed CPU sample
+        host = {k: np.ascontiguousarray(q[k][:, :m].cpu().numpy().T) for k in ("Hd", "c", "A", "b", "lb", "ub")}
         if nv <= 3:
             ex, stex, _ = O.qp_solve_batch(nv, nc, host["Hd"], host["c"], host["A"], host["b"], host["lb"], host["ub"], be,
                                            O.SOLVER_EXACT)
@@ -491,7 +493,8 @@ def bench_qp(args, grp, dev):
         else:
             model, variant = O.CONFIGS[cfg]
             ua, rl, rc = O.filter_batch(model, variant, O.default_options(model, variant),
-                                        np.ascontiguousarray(q["x"][:, :m].T), np.ascontiguousarray(q["udes"][:, :m].T))
+                                        np.ascontiguousarray(q["x"][:, :m].T), np.ascontiguousarray(q["udes"][:, :m].T),
+                                        nthreads=host_cores())
             g = sol[:, :m].cpu().numpy().T
             out["parity"] = {"status_mismatches": int((st[:m] != rc).sum()),
                              "max_abs_err_vs_exact": float(np.abs(g[:, 0] - ua[:, 0]).max()), "checked_instances": m}
