@@ -549,21 +549,35 @@ struct AdmmSmall {
 		// (qp_lane.hpp: qp_data_nonfinite); latched here for every solver mode, the iterations skip a latched lane
 		const bool nonfinite = qp_data_nonfinite<NV, RPL, G>(in.Hd, in.c, in.lb, in.ub, in.A, in.b);
 		if (nonfinite) status = kStatusMaxIter;
+		// polish == 0 (the iterations alone): the same stage runs first as well, but its verdict is only kept for the lanes
+		// the iterations leave at max_iter -- the policy of the wave kernels (k_qp.hip: launch_qp_wave): a problem the
+		// iterations do not finish is answered by the exact method instead of a MAX_ITER status (profiles/r03/
+		// soak_parity.txt: 4e-5 of C3's instances ran to max_iter although an optimum exists)
+		int gi_kept = kGiUndecided;
+		double gi_x[NV];
+#pragma unroll
+		for (int j = 0; j < NV; j++) gi_x[j] = 0.0;
 		if constexpr (NV <= 3) {
-			if (finish_first && S_.polish != 0) {
+			if (finish_first) {
 				double xg[NV];
 				int gsteps;
 				const int v = GiSmall<NV, RPL, G>::solve_unchecked(in, (int)(threadIdx.x % G), 8 * NV + 4, xg, gsteps);
-				stat_rounds = gsteps;
-				if (nonfinite) {
-				} else if (v == kGiFailed) { // overflow inside the stage: nothing the iterations could do better
-					status = kStatusMaxIter;
-				} else if (v == kGiOptimal) {
-					status = kStatusSolved;
+				if (S_.polish == 0) {
+					gi_kept = v;
 #pragma unroll
-					for (int j = 0; j < NV; j++) xout[j] = xg[j];
-				} else if (v == kGiInfeasible) {
-					status = kStatusPrimalInf;
+					for (int j = 0; j < NV; j++) gi_x[j] = xg[j];
+				} else {
+					stat_rounds = gsteps;
+					if (nonfinite) {
+					} else if (v == kGiFailed) { // overflow inside the stage: nothing the iterations could do better
+						status = kStatusMaxIter;
+					} else if (v == kGiOptimal) {
+						status = kStatusSolved;
+#pragma unroll
+						for (int j = 0; j < NV; j++) xout[j] = xg[j];
+					} else if (v == kGiInfeasible) {
+						status = kStatusPrimalInf;
+					}
 				}
 			}
 		}
@@ -752,6 +766,15 @@ struct AdmmSmall {
 			iters = it;
 #pragma unroll
 			for (int j = 0; j < NV; j++) xout[j] = D[j] * x[j];
+		}
+		if (S_.polish == 0 && status == kStatusMaxIter && !nonfinite) { // see gi_kept above
+			if (gi_kept == kGiOptimal) {
+				status = kStatusSolved;
+#pragma unroll
+				for (int j = 0; j < NV; j++) xout[j] = gi_x[j];
+			} else if (gi_kept == kGiInfeasible) {
+				status = kStatusPrimalInf;
+			}
 		}
 		if (status == kStatusSolvedInaccurate) status = kStatusSolved; // src/qpwrapper_osqp.cpp:225
 	}

@@ -174,7 +174,7 @@ __device__ __forceinline__ void explicit_filter_body(const DevOptions &o, const 
 	AdmmSmall<NV, RPL, G> admm;
 	double sol[NV];
 	int status, iters;
-	admm.solve(qp, S, sol, status, iters, false, S.polish == 2);
+	admm.solve(qp, S, sol, status, iters, false, S.polish != 1);
 
 	if (live && g == 0) {
 		if (status == kStatusSolved) {
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(LIGHT ? 256 : 64) void explicit_rollout_kernel(DevO
 			const int verdict = GiSmall<NV, NC, 1>::template solve_with_pinned<NU>(qp, 0, 8 * NV + 4, sol, iters);
 			status = verdict == kGiOptimal ? kStatusSolved : kStatusPrimalInf;
 		} else {
-			admm.solve(qp, S, sol, status, iters, S.warm_start != 0 && t > 0, S.polish == 2);
+			admm.solve(qp, S, sol, status, iters, S.warm_start != 0 && t > 0, S.polish != 1);
 		}
 		if (live && a.xlog) {
 #pragma unroll

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void realizable_filter_kernel(RzDev z, asif_hi
 		int status = kStatusSolved, iters = 0;
 		if (z.npSSmax > 0) { // wave-uniform
 			AdmmSmall<NV, RPL, 1> admm;
-			admm.solve(qp, S, sol, status, iters, false, S.polish == 2);
+			admm.solve(qp, S, sol, status, iters, false, S.polish != 1);
 		} else { // no barrier rows, no delta: the QP is a clip
 			sol[0] = fmin(fmax(uDes, qp.lb[0]), qp.ub[0]);
 			sol[1] = 0.0;

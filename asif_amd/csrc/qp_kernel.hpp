@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void qp_policy_kernel(asif_hip_solver S, Polic
 	AdmmSmall<NV, RPL, G> admm;
 	double sol[NV];
 	int status, iters;
-	admm.solve(qp, S, sol, status, iters, false, S.polish == 2);
+	admm.solve(qp, S, sol, status, iters, false, S.polish != 1);
 	if (live && g == 0) pol.template store<NV>(i, sol, status, iters);
 }
 
