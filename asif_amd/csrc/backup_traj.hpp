@@ -38,7 +38,8 @@ struct BackupLoop {
 	// sqrt and divide as the compiler expands them (v_rsq / v_rcp, Newton steps in FMA, v_div_fixup), minus the
 	// rescaling of operands near the ends of the exponent range (v_div_scale, the ldexp pair around the sqrt).  Bit for
 	// bit the IEEE results whenever the rescaling would not have triggered: x = 0 or x >= 2^-767 for the sqrt; for a / b
-	// both magnitudes (a may be 0) within 2^+-255.  The caller guarantees that from the options (satFastOk).
+	// both magnitudes (a may be 0) within 2^+-255.  (The trajectory loop's bevel now takes the joint sequence bevel_arc below;
+	// these two stay as the sequences it is compared with on the device, k_math_probe.hip.)
 	__device__ __forceinline__ static double sqrt_plain_range(double x)
 	{
 #if defined(__HIP_DEVICE_COMPILE__)
