@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void qp_policy_kernel(asif_hip_solver S, Polic
 	// (C3's QP kernel: 44 -> 23 MB, 26.1 -> 25.4 us; C4's 14.2 -> 12.6 us).  Only for policies that read staged rows: a
 	// policy that reads 24 bytes per instance has nothing to share, and C5's 7.5 us kernel lost 0.75 us to it.
 	constexpr bool kRemap = G > 1 && reads_staged_rows<Policy>::value;
-	const int64_t nblk = (pol.B * G + blockDim.x - 1) / blockDim.x;
+	// (blockDim.x is 64 or 256: a shift -- the 64-bit division by a run-time value is a hundred scalar instructions)
+	const int64_t nblk = (pol.B * G + blockDim.x - 1) >> (31 - __clz((int)blockDim.x));
 	const int64_t blk = kRemap ? xcd_contiguous_index(blockIdx.x, nblk) : (int64_t)blockIdx.x;
 	if (blk >= nblk) return; // wave-uniform: padding block of the XCD-rounded grid
 	const int64_t tid = blk * blockDim.x + threadIdx.x;
