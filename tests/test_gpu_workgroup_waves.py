@@ -18,12 +18,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _digests(cfg, B, env):
+def _digests(cfg, B, env, integrator=0):
     code = ("import sys, json, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests'); import gpu_util\n"
-            "r = gpu_util.run_assemble(%d, %d); f = gpu_util.run_filter(%d, %d, uact_init=7.0, relax_init=-7.0)\n"
+            "from asif_amd import capi\n"
+            "o = capi.default_options(*capi.CONFIGS[%d][:2]); o.integrator = %d\n" % (ROOT, ROOT, cfg, integrator) +
+            "r = gpu_util.run_assemble(%d, %d, options=o); f = gpu_util.run_filter(%d, %d, options=o, uact_init=7.0, relax_init=-7.0)\n"
             "print(json.dumps({k: hashlib.sha256(v.tobytes()).hexdigest() for k, v in "
             "(('A', r['A']), ('b', r['b']), ('code', r['code']), ('diag', r['diag']), ('uact', f['uact']), "
-            "('relax', f['relax']), ('rc', f['rc']))}))\n" % (ROOT, ROOT, cfg, B, cfg, B))
+            "('relax', f['relax']), ('rc', f['rc']))}))\n" % (cfg, B, cfg, B))
     o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert o.returncode == 0, o.stderr[-1500:]
     return json.loads(o.stdout.strip().split("\n")[-1])
@@ -35,6 +37,12 @@ def test_one_and_four_waves_per_workgroup_give_the_same_bits(hip, cfg, B):
     four = _digests(cfg, B, {"ASIF_HIP_WG_WAVES": "4"})
     two = _digests(cfg, B, {"ASIF_HIP_WG_WAVES": "2"})
     assert one == four == two
+
+
+@pytest.mark.parametrize("cfg,B", [(3, 300), (12, 1000)])
+def test_the_adaptive_integrator_too(hip, cfg, B):
+    """integrator = 1 (dopri5 dense output, ASIFimplicit and ASIFimplicitTB): one and four waves per workgroup."""
+    assert _digests(cfg, B, {"ASIF_HIP_WG_WAVES": "1"}, integrator=1) == _digests(cfg, B, {"ASIF_HIP_WG_WAVES": "4"}, integrator=1)
 
 
 @pytest.mark.parametrize("cfg,n,big", [(9, 8192, 200000), (12, 4096, 70000), (3, 2048, 40000)])
