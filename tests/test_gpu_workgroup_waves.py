@@ -31,7 +31,7 @@ def _digests(cfg, B, env, integrator=0):
     return json.loads(o.stdout.strip().split("\n")[-1])
 
 
-@pytest.mark.parametrize("cfg,B", [(3, 1000), (9, 4099), (12, 4099), (8, 300), (4, 4099), (5, 4099)])
+@pytest.mark.parametrize("cfg,B", [(3, 1000), (9, 4099), (12, 4099), (8, 300), (4, 4099), (5, 4099), (10, 300), (11, 4099)])
 def test_one_and_four_waves_per_workgroup_give_the_same_bits(hip, cfg, B):
     one = _digests(cfg, B, {"ASIF_HIP_WG_WAVES": "1"})
     four = _digests(cfg, B, {"ASIF_HIP_WG_WAVES": "4"})
