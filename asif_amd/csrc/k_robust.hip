@@ -111,7 +111,9 @@ struct RobustPolicy {
 	template <int NV, int NC, int G>
 	__device__ __forceinline__ void load(int64_t i, int g, QpLaneData<NV, (NC + G - 1) / G> &qp) const
 	{
-		static_assert(NV == 2 && NC == kRobustRedRows && (G == 2 || G == 4 || G == 8), "reduced robust QP");
+		// NC: kRobustRedRows, or half of it when the set has no more than half the half-planes (the launcher's choice:
+		// BASELINE's C5 has four of eight, and rows that are padding cost what real ones cost)
+		static_assert(NV == 2 && (NC == kRobustRedRows || NC == kRobustRedRows / 2) && (G == 2 || G == 4 || G == 8), "reduced robust QP");
 		using M = InvertedPendulumRobust;
 		constexpr int MAXNP = M::MAXNP, RPL = (NC + G - 1) / G, H = G / 2;
 		const int N = o.nHalfPlanes;
@@ -175,11 +177,12 @@ int launch_robust_ip(const DevOptions &o, const asif_hip_solver &S, const Filter
 	const RobustPolicy p = {a.B, o, a};
 	int G = S.lanes_per_qp;
 	if (G == 0) G = a.B >= 32768 ? 2 : (a.B >= 16384 ? 4 : 8); // enough lane groups for one wave on every SIMD
+	const bool half = 2 * o.nHalfPlanes <= kRobustRedRows / 2; // every real row fits half the row budget
 	switch (G) {
 	// one Ruiz pass by default: these rows are well scaled and a second pass only costs finish rounds
-	case 2: return launch_policy<2, kRobustRedRows, 2>(S, p, stream, 1);
-	case 4: return launch_policy<2, kRobustRedRows, 4>(S, p, stream, 1);
-	case 8: return launch_policy<2, kRobustRedRows, 8>(S, p, stream, 1);
+	case 2: return half ? launch_policy<2, kRobustRedRows / 2, 2>(S, p, stream, 1) : launch_policy<2, kRobustRedRows, 2>(S, p, stream, 1);
+	case 4: return half ? launch_policy<2, kRobustRedRows / 2, 4>(S, p, stream, 1) : launch_policy<2, kRobustRedRows, 4>(S, p, stream, 1);
+	case 8: return half ? launch_policy<2, kRobustRedRows / 2, 8>(S, p, stream, 1) : launch_policy<2, kRobustRedRows, 8>(S, p, stream, 1);
 	default: return ASIF_HIP_EINVAL;
 	}
 }
