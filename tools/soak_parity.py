@@ -33,7 +33,7 @@ for cfg in cfgs:
     oo = O.default_options(model, variant)
     B, first, n, bad, worst = CHUNK[cfg], 1 << 24, 0, 0, 0.0  # ranges the tests and the bench do not touch
     hist = {}
-    t0 = time.perf_counter()
+    t0 = last_note = time.perf_counter()
     while time.perf_counter() - t0 < budget:
         out = gpu_util.run_filter(cfg, B, first=first, uact_init=7.0, relax_init=-7.0, solver=solver)
         d = out["dims"]
@@ -50,4 +50,7 @@ for cfg in cfgs:
             hist[int(k)] = hist.get(int(k), 0) + int(c)
         n += B
         first += B
+        if time.perf_counter() - last_note > 60.0:  # (a GPU box takes a silent command for hung after 7 minutes)
+            last_note = time.perf_counter()
+            print(f"  config {cfg}: {n} instances so far, rc mismatches {bad}", flush=True)
     print(f"config {cfg}: {n} instances, rc mismatches {bad}, max |uAct - u_ref| {worst:.3e}, rc {dict(sorted(hist.items()))}", flush=True)
