@@ -45,6 +45,22 @@ def test_default_options_match_oracle(capi, oracle):
                 assert a == b, (cfg, name)
 
 
+def test_model_and_variant_ids_match_the_header(capi):
+    """asif_amd/capi.py restates the enums of include/asif_hip.h by value: a model added on one side only would
+    silently bind another model."""
+    import os
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "asif_hip.h")).read()
+    ids = {m.group(1): int(m.group(2)) for m in re.finditer(r"ASIF_HIP_MODEL_([A-Z_0-9]+)\s*=\s*(\d+)", hdr)}
+    assert ids["DOUBLE_INTEGRATOR"] == capi.MODEL_DOUBLE_INTEGRATOR and ids["INVERTED_PENDULUM"] == capi.MODEL_INVERTED_PENDULUM
+    assert ids["SEGWAY"] == capi.MODEL_SEGWAY and ids["INVERTED_PENDULUM_ROBUST"] == capi.MODEL_INVERTED_PENDULUM_ROBUST
+    assert ids["INVERTED_PENDULUM_TB"] == capi.MODEL_INVERTED_PENDULUM_TB == capi.CONFIGS[8][0]
+    assert ids["DOUBLE_INTEGRATOR_IMPLICIT"] == capi.MODEL_DOUBLE_INTEGRATOR_IMPLICIT == capi.CONFIGS[9][0]
+    assert ids["PLANAR_TWO_INPUT"] == capi.MODEL_PLANAR_TWO_INPUT == capi.CONFIGS[11][0]
+    assert ids["DOUBLE_INTEGRATOR_TB"] == capi.MODEL_DOUBLE_INTEGRATOR_TB == capi.CONFIGS[12][0]
+    assert sorted(ids.values()) == list(range(len(ids)))  # dense, no duplicates
+
+
 def test_struct_layouts_match_header(capi):
     # sizes the C compiler gives the same structs (gcc on the public header)
     import subprocess, tempfile
