@@ -3,6 +3,8 @@
 // reference examples' (examples/InvertedPendulum_Implicit.cpp:31-80, examples/segway_implicit_tb.cpp:27-212);
 // the compiled device functors are reused as host functions so both paths see the same model.
 //   usage: backup_filters implicit|tb|tbdi N      prints  i,uAct,relax0,relax1,rc,uActBatch,rcBatch
+//          backup_filters implicit-loop|dii-loop|tbip-loop STEPS [RUN]   the main() loops of InvertedPendulum_Implicit.cpp,
+//                                                 DoubleIntegrator_implicit.cpp, InvertedPendulum_ImplicitTB.cpp
 //          backup_filters tb-loop STEPS [PUSH]    the closed loop of examples/segway_implicit_tb.cpp:236-275 (pitch rate PUSH at t = 0)
 //          backup_filters tbdi-loop STEPS         the closed loop of examples/DoubleIntegrator_implicit_tb.cpp:105-160
 //                                                 (fused-gradient constructor, updateOptions at half time); prints
@@ -89,6 +91,81 @@ int main(int argc, char **argv)
 	if (argc < 3) return 2;
 	const bool tb = !std::strncmp(argv[1], "tb", 2) && std::strncmp(argv[1], "tbdi", 4);
 	const long N = std::atol(argv[2]);
+	// ---- the closed loops of the three remaining backup-trajectory examples, each as its main() runs it (plant Euler at
+	// 1 ms, uDes constant); prints  i,x0,x1,uAct,relax0,relax1,rc,updated  with the state the filter was called on
+	if (!std::strcmp(argv[1], "implicit-loop") || !std::strcmp(argv[1], "dii-loop") || !std::strcmp(argv[1], "tbip-loop")) {
+		const int run = argc > 3 ? std::atoi(argv[3]) : 0;
+		const double dt = 0.001, tEnd = dt * (double)N;
+		std::printf("i,x0,x1,uAct,relax0,relax1,rc,updated\n");
+		auto plant = [&](auto dyn, double (&x)[2], double ua) {
+			double f[2], g[2];
+			dyn(x, f, g);
+			for (int k = 0; k < 2; k++) x[k] += dt * (f[k] + g[k] * ua);
+		};
+		if (!std::strcmp(argv[1], "implicit-loop")) { // examples/InvertedPendulum_Implicit.cpp:84-140, run `run` of its ten
+			typedef HostModel<asif::InvertedPendulum> H;
+			const double lb[1] = {-1.5}, ub[1] = {1.5}, ud[1] = {0.0};
+			ASIF::ASIFimplicit::Options opts;
+			opts.backTrajHorizon = 5.0;
+			opts.backTrajDt = 0.001;
+			opts.relaxReachLb = 5.0;
+			opts.relaxSafeLb = 10.0;
+			ASIF::ASIFimplicit flt(2, 1, 4, 1, 10, H::safetySet, H::backupSet3, H::dynamics, H::gradients, H::controller);
+			if (flt.initialize(lb, ub, opts) != 1) return 3;
+			double x[2] = {0.1 + (double)run * 0.29, 0.0};
+			for (long i = 0; i < N; i++) {
+				double ua[1] = {0.0}, rl[2] = {0.0, 0.0};
+				const int32_t rc = flt.filter(x, ud, ua, rl);
+				std::printf("%ld,%.17g,%.17g,%.17g,%.17g,%.17g,%d,0\n", i, x[0], x[1], ua[0], rl[0], rl[1], rc);
+				plant(H::dynamics, x, ua[0]);
+			}
+		} else if (!std::strcmp(argv[1], "dii-loop")) { // examples/DoubleIntegrator_implicit.cpp:87-150: fused-gradient constructor,
+			typedef HostModel<asif::DoubleIntegratorImplicit> H; // updateOptions(backTrajHorizon = 5) at half time
+			const double lb[1] = {-1.0}, ub[1] = {1.0}, ud[1] = {1.0};
+			ASIF::ASIFimplicit::Options opts;
+			opts.backTrajHorizon = 2.0;
+			opts.backTrajDt = 0.01;
+			opts.relaxReachLb = 5.0;
+			opts.relaxSafeLb = 10.0;
+			ASIF::ASIFimplicit flt(2, 1, 4, 1, 4, H::safetySet, H::backupSet3, H::dynamicsWithGradient, H::controller);
+			if (flt.initialize(lb, ub, opts) != 1) return 3;
+			opts.backTrajHorizon = 5.0;
+			double x[2] = {0.0, 0.0}, t = 0.0;
+			bool updated = false;
+			for (long i = 0; i < N; i++) {
+				if (!updated && t > tEnd / 2) {
+					updated = true;
+					if (flt.updateOptions(opts) != 1) return 5;
+				}
+				double ua[1] = {0.0}, rl[2] = {0.0, 0.0};
+				const int32_t rc = flt.filter(x, ud, ua, rl);
+				std::printf("%ld,%.17g,%.17g,%.17g,%.17g,%.17g,%d,%d\n", i, x[0], x[1], ua[0], rl[0], rl[1], rc, (int)updated);
+				plant(H::dynamics, x, ua[0]);
+				t += dt;
+			}
+		} else { // examples/InvertedPendulum_ImplicitTB.cpp:100-175, run `run` of its two
+			typedef HostModel<asif::InvertedPendulumTB> H;
+			const double lb[1] = {-1.5}, ub[1] = {1.5}, ud[1] = {0.0};
+			ASIF::ASIFimplicitTB::Options opts;
+			opts.backTrajHorizon = 11.0;
+			opts.backTrajDt = 0.001;
+			opts.relaxCost = 10.;
+			opts.relaxSafeLb = 10.0;
+			opts.relaxTTS = 30.0;
+			opts.relaxMinOrtho = 60.0;
+			opts.backTrajMinOrtho = 0.001;
+			ASIF::ASIFimplicitTB flt(2, 1, 4, 4, H::safetySet, H::backupSet4, H::dynamics, H::gradients, H::controller);
+			if (flt.initialize(lb, ub, opts) != 1) return 3;
+			double x[2] = {-0.1 + (double)run * 0.2, 0.0};
+			for (long i = 0; i < N; i++) {
+				double ua[1] = {0.0}, rl = 0.0;
+				const int32_t rc = flt.filter(x, ud, ua, rl);
+				std::printf("%ld,%.17g,%.17g,%.17g,%.17g,%.17g,%d,0\n", i, x[0], x[1], ua[0], rl, flt.TTS_, rc);
+				plant(H::dynamics, x, ua[0]);
+			}
+		}
+		return 0;
+	}
 	if (!std::strncmp(argv[1], "tbdi", 4)) {
 		typedef HostModel<asif::DoubleIntegratorTB> H;
 		const double lb[1] = {-1.0}, ub[1] = {1.0};

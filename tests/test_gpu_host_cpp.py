@@ -114,6 +114,39 @@ def test_segway_tb_closed_loop(hip, oracle):
     assert 2 in rc and (rc != 2).sum() > 100  # starts inside the backup set, leaves it
 
 
+@pytest.mark.parametrize("kind,cfg,steps,run", [("implicit-loop", 3, 300, 5), ("dii-loop", 9, 1200, 0), ("tbip-loop", 8, 160, 1)])
+def test_remaining_example_loops_step_by_step(hip, oracle, kind, cfg, steps, run):
+    """The main() loops of examples/InvertedPendulum_Implicit.cpp (run 5 of its ten start states),
+    examples/DoubleIntegrator_implicit.cpp (fused-gradient constructor, updateOptions(backTrajHorizon = 5) at half time)
+    and examples/InvertedPendulum_ImplicitTB.cpp (its second start state) through the C++ classes: every step's input is
+    the exact optimum of the QP the reference assembles on the state the program was in, rc identical, and the plant
+    step is the example's."""
+    rows = _run_backup(kind, steps, run)
+    assert rows.shape == (steps, 8)
+    model, variant = oracle.CONFIGS[cfg]
+    x = np.ascontiguousarray(rows[:, 1:3])
+    ud = np.full((steps, 1), 1.0 if cfg == 9 else 0.0)
+    upd = rows[:, 7].astype(int)
+    first = int(np.argmax(upd)) if upd.any() else steps
+    o1 = oracle.default_options(model, variant)
+    o2 = oracle.default_options(model, variant)
+    o2.backTrajHorizon = 5.0
+    ua = np.empty(steps)
+    rc = np.empty(steps, dtype=int)
+    for o, sl in ((o1, slice(0, first)), (o2, slice(first, steps))):
+        if sl.start >= sl.stop:
+            continue
+        a, _, r = oracle.filter_batch(model, variant, o, x[sl], ud[sl], oracle.SOLVER_EXACT, nthreads=8)
+        ua[sl], rc[sl] = a[:, 0], r
+    if cfg == 9:
+        assert 599 <= first <= 602 and oracle.dims(model, variant, o2).npBT == 501
+    assert np.array_equal(rows[:, 6].astype(int), rc), np.where(rows[:, 6].astype(int) != rc)[0][:10]
+    assert np.abs(rows[:, 3] - ua).max() <= 1e-6
+    f1 = np.sin(x[:-1, 0]) if cfg in (3, 8) else 0.0 * x[:-1, 0]
+    xn = x[:-1] + 0.001 * np.stack([x[:-1, 1], f1 + rows[:-1, 3]], axis=1)
+    assert np.abs(xn - x[1:]).max() <= 1e-15
+
+
 def test_tb_class_double_integrator_single_agent_and_batch(hip, oracle):
     """examples/DoubleIntegrator_implicit_tb.cpp's model through the class's fused-gradient constructor
     (dynamicsWithGradient, include/asif_implicit_tb.h:74-84) and through filterBatch()."""
