@@ -3,11 +3,12 @@
 // a text file ("N" then N lines "a0 a1"; tests write it from asif_amd/data/robust_halfplanes.json).
 // Single-agent filter() (host affine arithmetic, the full 22-variable QP on the GPU's wave-per-QP kernel) next to
 // filterBatch() on the same states, which are read from stdin as "x0 x1 uDes" lines.
-//   usage: di_robust halfplanes.txt < states.txt
+//   usage: di_robust halfplanes.txt < states.txt      |      di_robust halfplanes.txt --loop STEPS   (the example's main loop)
 //   prints  i,uAct,relax,rc,uActBatch,relaxBatch,rcBatch  and  "A,<i>,<nc*nv row entries>" lines
 #include <asif++.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 static const double m_max = 135., m_min = 70., K = 5.7, dK = 0.1, F = 23, DF = 2;
@@ -60,6 +61,23 @@ int main(int argc, char **argv)
 	asif_hip_default_robust_data_options(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_ROBUST, &md); // same m, K, F intervals
 	if (flt.bindDeviceData(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_ROBUST, flat.data(), N, md) != 0) return 3;
 
+	if (argc > 3 && !std::strcmp(argv[2], "--loop")) {
+		// the example's own loop (examples/DoubleIntegrator_Robust.cpp:88-131): from rest with uDes = 20, the plant stepped
+		// at 10 ms with the heaviest mass (dynamicsExact, m_mean = 135); prints  i,x0,x1,uAct,relax,rc  with the state the
+		// filter was called on
+		const long steps = std::atol(argv[3]);
+		const double dt = 0.01, m_mean = 135., ud[1] = {20.0};
+		double x[2] = {0.0, 0.0};
+		std::printf("i,x0,x1,uAct,relax,rc\n");
+		for (long i = 0; i < steps; i++) {
+			double ua[1] = {0.0}, rl = 0.0;
+			const int32_t rc = flt.filter(x, ud, ua, rl);
+			std::printf("%ld,%.17g,%.17g,%.17g,%.17g,%d\n", i, x[0], x[1], ua[0], rl, rc);
+			const double f[2] = {x[1], -F * x[1] / m_mean}, g[2] = {0., K / m_mean};
+			for (int k = 0; k < 2; k++) x[k] += dt * (f[k] + g[k] * ua[0]);
+		}
+		return 0;
+	}
 	std::vector<double> xs, us;
 	double a, b, c;
 	while (std::scanf("%lf %lf %lf", &a, &b, &c) == 3) {

@@ -298,6 +298,34 @@ def test_robust_class_on_shipped_data(hip, oracle, tmp_path):
     assert np.abs(res[ok, 1] - ua[ok, 0]).max() <= 1e-6
 
 
+def test_double_integrator_robust_closed_loop(hip, oracle, tmp_path):
+    """The main() loop of examples/DoubleIntegrator_Robust.cpp:88-131 (600 steps of 10 ms from rest, uDes = 20, the shipped
+    100 half-planes with npSSmax = 5) through ASIF::ASIFrobust: every step's 22 x 15 QP is solved on the GPU and must give
+    the oracle's return code and, where solved, its input on the state the program was in."""
+    exe = os.path.join(HOST, "di_robust")
+    hp = oracle.load_halfplanes()
+    hfile = tmp_path / "hp.txt"
+    with open(hfile, "w") as f:
+        f.write(f"{hp.shape[0]}\n")
+        for a in hp:
+            f.write(f"{float(a[0])!r} {float(a[1])!r}\n")
+    steps = 600
+    out = subprocess.run([exe, str(hfile), "--loop", str(steps)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = np.array([[float(v) for v in l.split(",")] for l in out.stdout.strip().split("\n")[1:]])
+    assert rows.shape == (steps, 6)
+    x = np.ascontiguousarray(rows[:, 1:3])
+    z = oracle.RobustData(hp)
+    ua, rl, rc = z.filter(x, np.full((steps, 1), 20.0))
+    assert np.array_equal(rows[:, 5].astype(int), rc), np.where(rows[:, 5].astype(int) != rc)[0][:10]
+    ok = rc == 1
+    assert ok.sum() > steps // 2
+    # (the lifted problem's inputs reach 20: 1e-5, the north star's bound, is 5e-7 of that; measured 1.6e-6)
+    assert np.abs(rows[ok, 3] - ua[ok, 0]).max() <= 1e-5 and np.abs(rows[ok, 4] - rl[ok, 0]).max() <= 1e-5
+    # the agent is driven towards the boundary of the safe set and the filter takes the input away from uDes
+    assert rows[:, 3].min() < 19.0 and rows[0, 3] > 19.9
+
+
 @pytest.mark.parametrize("plain", [False, True])
 def test_implicit_rb_class_single_agent_and_batch(hip, oracle, plain):
     """ASIF::ASIFimplicitRB (held backup input, interval margins from the user's safetySet_int on host AAF operands,
