@@ -6,11 +6,12 @@
 //     nFacets lines    v0 v1  n0 n1  a_0 .. a_{maxActive-1}
 // Single-agent filter() (facet QPs and the eliminated QP on the GPU through QPWrapperHip, affine arithmetic on
 // the host) next to filterBatch() on the same states, which are read from stdin as "x0 x1 uDes" lines.
-//   usage: realizable_di kernel.txt < states.txt
+//   usage: realizable_di kernel.txt < states.txt      |      realizable_di kernel.txt --loop STEPS   (the example's main loop)
 //   prints  i,uAct,relax0,relax1,rc,nCrit,uActBatch,relax1Batch,rcBatch  and  "A,<i>,<nc*nv row entries>" / "b,<i>,..."
 #include <asif++.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 static const double m_min = 70., m_max = 75., K = 5.7, dK = 0.1, F = 23, DF = 2;
@@ -64,6 +65,43 @@ int main(int argc, char **argv)
 	asif_hip_default_realizable_options(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_SAMPLED, &md); // same m, K, F intervals
 	if (flt.bindDeviceModel(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_SAMPLED, md) != 0) return 3;
 
+	if (argc > 3 && !std::strcmp(argv[2], "--loop")) {
+		// the example's own loop (examples/DoubleIntegrator_RealizableSampled.cpp:96-190): the plant stepped at 1 kHz with
+		// the mean mass, the filter called on every tenth step (dtPerSample = 10: the 100 Hz kernel), its input passed
+		// through the example's moving bounds (they close in on the filtered input when it leaves uDes and relax by
+		// 20 * dtPerSample * 0.001 per sample otherwise).  Prints one line per FILTER call:
+		//   step,x0,x1,uFilter,relax0,relax1,rc,uAct     (x: the state handed to filter())
+		const long steps = std::atol(argv[3]);
+		const double dt = 0.001, m_mean = (m_min + m_max) / 2., ud[1] = {20.0};
+		const unsigned per = 10;
+		const double sc = 20. * per * 0.001;
+		double x[2] = {0.0, 0.0}, uAct = 0.0, lo = -20., hi = 20.;
+		std::printf("step,x0,x1,uFilter,relax0,relax1,rc,uAct\n");
+		for (long i = 0; i < steps; i++) {
+			if (i % per == 0) {
+				double uf[1] = {0.0}, rl[2] = {0.0, 0.0};
+				const int32_t rc = flt.filter(x, ud, uf, rl);
+				uAct = uf[0];
+				if (uAct > ud[0] && uAct > lo) {
+					lo = uAct;
+					hi = lo > hi ? lo : hi + sc;
+				} else if (uAct < ud[0] && uAct < hi) {
+					hi = uAct;
+					lo = lo > hi ? hi : lo - sc;
+				} else {
+					lo -= sc;
+					hi += sc;
+				}
+				lo = lo < -20. ? -20. : lo;
+				hi = hi > 20. ? 20. : hi;
+				uAct = uAct > hi ? hi : (uAct < lo ? lo : uAct);
+				std::printf("%ld,%.17g,%.17g,%.17g,%.17g,%.17g,%d,%.17g\n", i, x[0], x[1], uf[0], rl[0], rl[1], rc, uAct);
+			}
+			const double f[2] = {x[1], -F * x[1] / m_mean}, g[2] = {0., K / m_mean};
+			for (int k = 0; k < 2; k++) x[k] += dt * (f[k] + g[k] * uAct);
+		}
+		return 0;
+	}
 	std::vector<double> xs, us;
 	double a, b, c;
 	while (std::scanf("%lf %lf %lf", &a, &b, &c) == 3) {

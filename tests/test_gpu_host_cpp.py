@@ -266,6 +266,37 @@ def test_realizable_class_single_agent_and_batch(hip, oracle, tmp_path):
     assert np.abs(res[ok, 7] - rl[ok, 1]).max() <= 1e-6
 
 
+def test_realizable_sampled_closed_loop(hip, oracle, tmp_path):
+    """The main() loop of examples/DoubleIntegrator_RealizableSampled.cpp:96-190 (the 100 Hz kernel: plant at 1 kHz, the
+    filter on every tenth step, uDes = 20, the example's moving input bounds) through ASIF::ASIFrealizable: 300 filter
+    calls, each solving its facet QPs and the lifted 38 x 29 problem on the GPU; return code and filtered input against
+    the oracle on the state the program was in."""
+    exe = os.path.join(HOST, "realizable_di")
+    k = oracle.load_kernel("100Hz")
+    kfile = tmp_path / "kernel.txt"
+    with open(kfile, "w") as f:
+        nF, nA = k["facetVertices"].shape[0], k["maxActiveConstraints"]
+        f.write(f"{k['vertices'].shape[0]} {nF} {k['maxCriticalFacets']} {nA}\n")
+        for v in k["vertices"]:
+            f.write(f"{float(v[0])!r} {float(v[1])!r}\n")
+        for i in range(nF):
+            f.write(" ".join([str(int(t)) for t in k["facetVertices"][i]] + [repr(float(t)) for t in k["facetNormals"][i]] +
+                             [str(int(t)) for t in k["facetActive"][i]]) + "\n")
+    steps = 3000
+    out = subprocess.run([exe, str(kfile), "--loop", str(steps)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = np.array([[float(v) for v in l.split(",")] for l in out.stdout.strip().split("\n")[1:]])
+    assert rows.shape == (steps // 10, 8)
+    x = np.ascontiguousarray(rows[:, 1:3])
+    z = oracle.Realizable(k)
+    ua, rl, rc = z.filter(x, np.full((len(x), 1), 20.0))
+    assert np.array_equal(rows[:, 6].astype(int), rc), np.where(rows[:, 6].astype(int) != rc)[0][:10]
+    ok = rc == 1
+    assert ok.sum() > len(x) // 2
+    assert np.abs(rows[ok, 3] - ua[ok, 0]).max() <= 1e-5  # (inputs up to 20; the north star's bound)
+    assert rows[:, 3].min() < 19.0  # the filter does intervene on the way to the kernel's boundary
+
+
 def test_robust_class_on_shipped_data(hip, oracle, tmp_path):
     """ASIF::ASIFrobust as examples/DoubleIntegrator_Robust.cpp builds it (npSSmax = 5 of the 100 shipped half-planes):
     rows bit-identical to the oracle's; single-agent filter() solves the full 22 x 15 QP on the wave-per-QP LDS
