@@ -2,11 +2,12 @@
 // (ROBUST flavour: g[1] in [0.8, 1.2]) with the box half-planes of SURVEY 8(d): single-agent filter()
 // (affine-arithmetic rows on the host, the full 18-variable QP on the GPU's wave-per-QP kernel) next to
 // filterBatch() on the same seeded states.
-//   usage: robust_pendulum N    prints  i,uAct,relax,rc,uActBatch,rcBatch, then "A,<i>,<216 row entries>" lines
+//   usage: robust_pendulum --loop STEPS [P [UDES]]   (the example's main loop)   |   robust_pendulum N    prints  i,uAct,relax,rc,uActBatch,rcBatch, then "A,<i>,<216 row entries>" lines
 #include <asif++.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 static const double pMin = 0.8, pMax = 1.2;
@@ -51,6 +52,26 @@ int main(int argc, char **argv)
 	asif_hip_options md;
 	asif_hip_default_options(ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST, ASIF_HIP_ROBUST, &md); // same half-planes, pMin, pMax
 	if (flt.bindDeviceModel(ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST, md) != 0) return 3;
+	if (argc > 2 && !std::strcmp(argv[1], "--loop")) {
+		// the example's own loop (examples/InvertedPendulum_Robust.cpp:134-175, ROBUST flavour): from (0.5, 0) with
+		// uDes = 0 by default; UDES = +-1.5 drives the velocity into its half-plane, where the filter takes the input
+		// back -- the position rows have Lgh = 0 and can only be relaxed); the plant's input gain p is one of the
+		// example's three values pMin + i (pMax - pMin) / 2.  Prints step,x0,x1,uAct,relax,rc with x the state handed to
+		// filter().
+		const long steps = std::atol(argv[2]);
+		const double p = argc > 3 ? std::atof(argv[3]) : 1.0, dt = 0.01;
+		double x[2] = {0.5, 0.0};
+		const double ud[1] = {argc > 4 ? std::atof(argv[4]) : 0.0};
+		std::printf("step,x0,x1,uAct,relax,rc\n");
+		for (long i = 0; i < steps; i++) {
+			double ua[1] = {0.0}, rl = 0.0;
+			const int32_t rc = flt.filter(x, ud, ua, rl);
+			std::printf("%ld,%.17g,%.17g,%.17g,%.17g,%d\n", i, x[0], x[1], ua[0], rl, rc);
+			const double f[2] = {x[1], std::sin(x[0])}, g[2] = {0., p};
+			for (int k = 0; k < 2; k++) x[k] += dt * (f[k] + g[k] * ua[0]);
+		}
+		return 0;
+	}
 	std::vector<double> bx(2 * N), bu(N), ba(N, 0.0), br(N, 0.0);
 	std::vector<int32_t> brc(N, 0);
 	for (long i = 0; i < N; i++) {

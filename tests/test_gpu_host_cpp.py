@@ -222,6 +222,33 @@ def test_robust_class_single_agent_and_batch(hip, oracle):
     assert np.abs(res[:, 4] - ua[:, 0]).max() <= 1e-6
 
 
+@pytest.mark.parametrize("p,ud,steps", [(0.8, 0.0, 280), (1.0, 1.5, 155), (1.2, -1.5, 210)])
+def test_robust_pendulum_closed_loop(hip, oracle, p, ud, steps):
+    """The main() loop of examples/InvertedPendulum_Robust.cpp:134-175 (ROBUST flavour: steps of 10 ms from (0.5, 0), plant
+    gain p in {pMin, 1, pMax}) through ASIF::ASIFrobust: each step's affine-arithmetic rows on the host and its
+    18-variable QP on the GPU, return code / input / relaxation against the oracle on the state the program was in.
+    With the example's uDes = 0 the pendulum falls towards x0 = pi and the box's position rows (Lgh = 0) can only be
+    relaxed, more at every step, until the state leaves the box at step 282; with uDes = +-1.5 the velocity reaches its
+    half-plane and the filter takes the input back."""
+    exe = os.path.join(HOST, "robust_pendulum")
+    out = subprocess.run([exe, "--loop", str(steps), repr(p), repr(ud)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = np.array([[float(v) for v in l.split(",")] for l in out.stdout.strip().split("\n")[1:]])
+    assert rows.shape == (steps, 6)
+    x = np.ascontiguousarray(rows[:, 1:3])
+    model, variant = oracle.CONFIGS[5]
+    o = oracle.default_options(model, variant)
+    ua, rl, rc = oracle.filter_batch(model, variant, o, x, np.full((steps, 1), ud), oracle.SOLVER_EXACT)
+    assert np.array_equal(rows[:, 5].astype(int), rc) and np.all(rc == 1)
+    assert np.abs(rows[:, 3] - ua[:, 0]).max() <= 1e-5
+    assert (np.abs(rows[:, 4] - rl[:, 0]) / np.maximum(1.0, np.abs(rl[:, 0]))).max() <= 1e-5
+    assert np.abs(x).max() < np.pi
+    if ud == 0.0:
+        assert rows[-1, 4] > 20.0 and np.abs(rows[:, 3]).max() <= 1e-5  # relaxed, never actuated
+    else:
+        assert np.abs(rows[:, 3] - ud).max() > 0.3  # the filter acts through the velocity rows
+
+
 def test_realizable_class_single_agent_and_batch(hip, oracle, tmp_path):
     """ASIF::ASIFrealizable: facet search through facetSolver_ (2 x 5 QPs on the GPU), host affine arithmetic and
     the full 29 x 38 rows must reproduce the oracle's rows bit for bit; single-agent filter() (the lifted 38 x 29
