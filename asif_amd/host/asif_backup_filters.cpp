@@ -367,6 +367,15 @@ int32_t ASIFimplicit::updateConstraints(const double x[])
 			Lgh[r + j * npTC_] = Lg;
 		}
 	}
+	// :556-583 (the reference grows the three by push_back at every initialize(); only the first npTC entries are ever
+	// written or meaningful)
+	Lfh_out_.assign(Lfh.begin(), Lfh.end());
+	Lgh_out_.assign(npTC_, std::vector<double>(nu_, 0.0));
+	Dh_out_.assign(npTC_, std::vector<double>(nx_, 0.0));
+	for (uint32_t i = 0; i < npTC_; i++) {
+		for (uint32_t j = 0; j < nu_; j++) Lgh_out_[i][j] = Lgh[nu_ * i + j];
+		for (uint32_t j = 0; j < nx_; j++) Dh_out_[i][j] = Dh[nx_ * i + j];
+	}
 	if (options_.use_learning) // :585-588
 		update_weights(&learning_data_, x, nx_, Dh_index_.data(), Lfh.data(), Lgh.data(), nu_);
 	std::fill(A_.begin(), A_.end(), 0.0);

@@ -3,6 +3,7 @@
 // reference examples' (examples/InvertedPendulum_Implicit.cpp:31-80, examples/segway_implicit_tb.cpp:27-212);
 // the compiled device functors are reused as host functions so both paths see the same model.
 //   usage: backup_filters implicit|tb|tbdi N      prints  i,uAct,relax0,relax1,rc,uActBatch,rcBatch
+//          backup_filters implicit-out N          prints  Lfh_out_[41], Lgh_out_[41][0], Dh_out_[41][2] after each filter()
 //          backup_filters implicit-loop|dii-loop|tbip-loop STEPS [RUN]   the main() loops of InvertedPendulum_Implicit.cpp,
 //                                                 DoubleIntegrator_implicit.cpp, InvertedPendulum_ImplicitTB.cpp
 //          backup_filters tb-loop STEPS [PUSH]    the closed loop of examples/segway_implicit_tb.cpp:236-275 (pitch rate PUSH at t = 0)
@@ -238,6 +239,20 @@ int main(int argc, char **argv)
 			bx[i] = -1.5 + 3.0 * rng(2, i, 0);
 			bx[N + i] = -1.5 + 3.0 * rng(2, i, 1);
 			bu[i] = -1.5 + 3.0 * rng(2, i, 2);
+		}
+		if (!std::strcmp(argv[1], "implicit-out")) {
+			// the class's public Lfh_out_ / Lgh_out_ / Dh_out_ (include/asif_implicit.h:122-124) after each filter():
+			// one line of 41 + 41 + 82 numbers per instance
+			for (long i = 0; i < N; i++) {
+				const double x[2] = {bx[i], bx[N + i]}, ud[1] = {bu[i]};
+				double ua[1] = {0.0};
+				(void)flt.filter(x, ud, ua);
+				if (flt.Lfh_out_.size() != 41 || flt.Lgh_out_.size() != 41 || flt.Dh_out_.size() != 41) return 6;
+				for (int r = 0; r < 41; r++) std::printf("%.17g,", flt.Lfh_out_[r]);
+				for (int r = 0; r < 41; r++) std::printf("%.17g,", flt.Lgh_out_[r][0]);
+				for (int r = 0; r < 41; r++) std::printf("%.17g,%.17g%s", flt.Dh_out_[r][0], flt.Dh_out_[r][1], r == 40 ? "\n" : ",");
+			}
+			return 0;
 		}
 		if (flt.filterBatch(N, bx.data(), bu.data(), ba.data(), br.data(), brc.data()) != 0) return 4;
 		for (long i = 0; i < N; i++) {

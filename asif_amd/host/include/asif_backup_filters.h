@@ -101,6 +101,12 @@ public:
 	double hBackupEnd_, hSafetyNow_;
 	int index_debug_;
 	std::vector<double> Dh_index_, h_index_;
+	// the rows' ingredients as the class publishes them for the learning pipeline (include/asif_implicit.h:122-124),
+	// before the learned residual is added; index arithmetic as upstream (src/asif_implicit.cpp:556-583: entry [i][j]
+	// is element nx*i + j of the column-major npTC x nx array Dh, resp. nu*i + j of Lgh -- for nu = 1 that is Lgh of
+	// row i; for Dh it is NOT row i's gradient)
+	std::vector<double> Lfh_out_;
+	std::vector<std::vector<double>> Lgh_out_, Dh_out_;
 	LearningData learning_data_; // include/asif_implicit.h:125
 
 	// with options.use_learning the weights of learning_data_ are uploaded too (fill it first)

@@ -71,6 +71,26 @@ def test_implicit_class_single_agent_and_batch(hip, oracle):
     assert np.abs(rows[ok, 2] - rl[ok, 0]).max() <= 1e-5 and np.abs(rows[ok, 3] - rl[ok, 1]).max() <= 1e-5
 
 
+def test_implicit_class_published_lie_derivatives(hip, oracle):
+    """The three vectors ASIFimplicit publishes for the learning pipeline (include/asif_implicit.h:122-124) after a
+    single-agent filter(): Lfh_out_ = -b and Lgh_out_[.][0] = the input column of the oracle's rows; Dh_out_ with the
+    reference's index arithmetic (src/asif_implicit.cpp:556-561: entry [i][j] is element nx i + j of the COLUMN-major
+    npTC x nx array) -- Dh is recovered from the rows through f = (x1, sin x0), g = (0, 1)."""
+    n = 12
+    out = _run_backup("implicit-out", n)
+    assert out.shape == (n, 41 + 41 + 82)
+    x, _ = oracle.make_batch(3, n)
+    model, variant = oracle.CONFIGS[3]
+    A, b, code, _ = oracle.assemble_batch(model, variant, oracle.default_options(model, variant), x)
+    for i in range(n):
+        Lfh, Lgh, Dho = out[i, :41], out[i, 41:82], out[i, 82:].reshape(41, 2)
+        np.testing.assert_allclose(Lfh, -b[i], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(Lgh, A[i][:41], rtol=1e-12, atol=1e-13)
+        f0, f1 = x[i, 1], np.sin(x[i, 0])
+        Dh = np.concatenate([(Lfh - Lgh * f1) / f0, Lgh])  # column-major 41 x 2: d/dx0 then d/dx1
+        np.testing.assert_allclose(Dho.reshape(-1), Dh, rtol=1e-9, atol=1e-9 * np.abs(Dh).max() / abs(f0))
+
+
 def test_tb_class_single_agent_and_batch(hip, oracle):
     n = 300
     rows = _run_backup("tb", n)
