@@ -516,7 +516,7 @@ static int launch_with_lds(K kern, size_t bytes, int64_t waves, int nw, const De
 {
 	bytes *= (size_t)nw;
 	if (bytes > 48 * 1024) {
-		const hipError_t he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+		const hipError_t he = allow_dynamic_lds((const void *)kern, bytes);
 		if (he != hipSuccess) return (int)he;
 	}
 	hipLaunchKernelGGL(kern, dim3((unsigned)((waves + nw - 1) / nw)), dim3(64 * nw), bytes, stream, o, a);

@@ -160,7 +160,7 @@ static int launch_lds(const asif_hip_solver &S0, const QpArgs &a, hipStream_t st
 	if (bytes > 160 * 1024) return ASIF_HIP_EUNSUPPORTED;
 	auto kern = qp_lds_kernel<VPT, RPT, FULLH>;
 	if (bytes > 48 * 1024) {
-		hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+		hipError_t e = allow_dynamic_lds((const void *)kern, bytes);
 		if (e != hipSuccess) return (int)e;
 	}
 	hipLaunchKernelGGL(kern, dim3(xcd_grid(a.B)), dim3(64), bytes, stream, S, a);
@@ -179,7 +179,7 @@ static int launch_inv(const asif_hip_solver &S0, const QpArgs &a, hipStream_t st
 	const size_t bytes = QPW * inv_half_doubles(NVMAX, NCMAX, HW) * sizeof(double);
 	auto kern = qp_inv_kernel<NVMAX, NCMAX, HW>;
 	if (bytes > 48 * 1024) {
-		hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+		hipError_t e = allow_dynamic_lds((const void *)kern, bytes);
 		if (e != hipSuccess) return (int)e;
 	}
 	hipLaunchKernelGGL(kern, dim3(xcd_grid((a.B + QPW - 1) / QPW)), dim3(64), bytes, stream, S, a);

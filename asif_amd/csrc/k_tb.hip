@@ -771,7 +771,7 @@ static int launch_tb(const DevOptions &o, const asif_hip_solver &S, const Filter
 			int nw = waves_per_workgroup(grid);
 			while (nw > 1 && ((size_t)nw * region > 160 * 1024 || nw > tb_max_wg_waves<M>())) nw /= 2;
 			if (nw * region > 48 * 1024) {
-				const hipError_t he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(nw * region));
+				const hipError_t he = allow_dynamic_lds((const void *)kern, nw * region);
 				if (he != hipSuccess) return (int)he;
 			}
 			hipLaunchKernelGGL(kern, dim3((grid + nw - 1) / nw), dim3(64 * nw), nw * region, stream, o, a);
@@ -791,7 +791,7 @@ static int launch_tb(const DevOptions &o, const asif_hip_solver &S, const Filter
 				auto kern = tb_rows_kernel<M, kCkptSpill, true>;
 				const size_t bytes = TbSplitLds<M>::bytes();
 				if (bytes > 48 * 1024)
-					he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+					he = allow_dynamic_lds((const void *)kern, bytes);
 				if (he != hipSuccess) return (int)he;
 				hipLaunchKernelGGL(kern, dim3(grid), dim3(128), bytes, stream, o, a);
 			}
@@ -802,7 +802,7 @@ static int launch_tb(const DevOptions &o, const asif_hip_solver &S, const Filter
 			int nw = waves_per_workgroup(grid); // four waves per workgroup when the launch is large, as far as LDS allows
 			while (nw > 1 && ((size_t)nw * 2 * region > 160 * 1024 || nw > tb_max_wg_waves<M>())) nw /= 2;
 			if (nw * 2 * region > 48 * 1024)
-				he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(nw * 2 * region));
+				he = allow_dynamic_lds((const void *)kern, nw * 2 * region);
 			if (he != hipSuccess) return (int)he;
 			hipLaunchKernelGGL(kern, dim3((grid + nw - 1) / nw), dim3(64 * nw), nw * 2 * region, stream, o, a);
 		} else {
@@ -810,7 +810,7 @@ static int launch_tb(const DevOptions &o, const asif_hip_solver &S, const Filter
 			int nw = waves_per_workgroup(grid);
 			while (nw > 1 && ((size_t)nw * region > 160 * 1024 || nw > tb_max_wg_waves<M>())) nw /= 2;
 			if (nw * region > 48 * 1024)
-				he = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(nw * region));
+				he = allow_dynamic_lds((const void *)kern, nw * region);
 			if (he != hipSuccess) return (int)he;
 			hipLaunchKernelGGL(kern, dim3((grid + nw - 1) / nw), dim3(64 * nw), nw * region, stream, o, a);
 		}

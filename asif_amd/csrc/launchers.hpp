@@ -154,6 +154,17 @@ inline asif_hip_solver resolve_scaling(const asif_hip_solver &S, int path_defaul
 // none, and kernels that run one latency-bound wave per SIMD lose 30-50 % (C12 at 65 536 instances: 372 us at one
 // workgroup per CU, 538 us at four; C3 at 65 536: 1 388 us, 968 us as four-wave workgroups).  So: four waves
 // per workgroup once the launch has more than two waves per CU.
+// Dynamic LDS above the 48 KB a kernel may ask for by default: the limit is raised to the whole 160 KB of a CU, never to
+// the size of this launch -- the attribute belongs to the kernel, not to the launch, and two host threads driving two
+// handles on one device (asif_hip_filter_batch_host_multi) may launch the same kernel with different sizes: whoever sets
+// the smaller one last must not pull the limit under the other's launch.
+constexpr size_t kLdsPerCu = 160 * 1024;
+inline hipError_t allow_dynamic_lds(const void *kern, size_t bytes)
+{
+	if (bytes <= 48 * 1024) return hipSuccess;
+	return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
+}
+
 inline int device_cus()
 {
 	static const int cus = []() {
