@@ -118,8 +118,12 @@ struct BackupLoop {
 	// positive thresholds the same regions, NaN in none of them either way -- and takes sqrt and divide without the
 	// rescaling steps: nonzero d >= ulp(r^2)/2, sq in [r 2^-27, r], |xc - au| in {0} U [ulp(xc)/2, bevelL], far from the
 	// thresholds where the IEEE sequences rescale.  Same bits, ~10 VALU issues fewer per step.
-	template <bool FAST = false>
-	__device__ __forceinline__ static void saturateSoft(const DevOptions &o, double u, double &uSat, double &DuSat)
+	// NOBEVEL (with FAST): the step of a block that is EXPECTED to stay clear of both bevels (bevel_rate below): no
+	// divergent block and no branch at all -- the linear and the clamped regions only -- and *seen latches a lane that
+	// was in a bevel after all, for the caller to repeat the block with the full step.
+	template <bool FAST = false, bool NOBEVEL = false>
+	__device__ __forceinline__ static void saturateSoft(const DevOptions &o, double u, double &uSat, double &DuSat,
+	                                                    bool *seen = nullptr)
 	{
 #pragma clang fp contract(on) // fused where written as one, nowhere else: the same bits in every kernel this is inlined into
 		const double r = o.satSharpness;
@@ -138,7 +142,9 @@ struct BackupLoop {
 			// alarm -- kStateSane -- sends through the checking step.)
 			uSat = min_num(max_num(u, mi), ma);
 			DuSat = clamped ? 0.0 : 1.0;
-			if (au > o.bevelStart && !clamped) { // divergent: skipped by the wave when no lane is in a bevel
+			if constexpr (NOBEVEL) {
+				*seen = *seen || (au > o.bevelStart && !clamped);
+			} else if (au > o.bevelStart && !clamped) { // divergent: skipped by the wave when no lane is in a bevel
 				const bool neg = uc < 0.0;
 				const double t = au - xc;
 				const double d = fma(-t, t, r * r);
@@ -184,10 +190,10 @@ struct BackupLoop {
 		double u, tLast;
 	};
 
-	template <bool HOLD, int POISON = kTrigChecked>
+	template <bool HOLD, int POISON = kTrigChecked, bool NOBEVEL = false>
 	__device__ __forceinline__ static void closedLoopT(const DevOptions &o, const double (&x)[NX], double (&fCL)[NX],
 	                                                   double (&DfCL)[NX * NX], Hold &hold, double t,
-	                                                   TrigCarry *cy = nullptr, bool reset = true)
+	                                                   TrigCarry *cy = nullptr, bool reset = true, bool *seen = nullptr)
 	{
 		double f[NX], g[NX], Df[NX * NX], Dg[NX * NX], u[1], Du[NX], uSat, DuSat;
 		M::backupController(o, x, u, Du);
@@ -200,7 +206,7 @@ struct BackupLoop {
 			}
 			us = hold.u;
 		}
-		saturateSoft<POISON != kTrigChecked>(o, us, uSat, DuSat);
+		saturateSoft<POISON != kTrigChecked, NOBEVEL>(o, us, uSat, DuSat, seen);
 		if constexpr (POISON == kTrigCarried) M::dynamicsAndGradientsCarried(o, x, f, g, Df, Dg, *cy, reset);
 		else M::template dynamicsAndGradients<POISON>(o, x, f, g, Df, Dg);
 		if constexpr (M::kInputOnLastState) {
@@ -375,14 +381,15 @@ struct BackupLoop {
 	// one forward-Euler step of [x; vec Q] (src/asif_implicit.cpp:470-477: rhs*dt + previous); t is the time
 	// the reference stamps on this rhs (src/asif_implicit_robust.cpp:567: i*backTrajDt for the step INTO sample i)
 	// POISON: the model's sin / cos never branch; out-of-range arguments turn the state into NaN (see sincos_fast)
-	template <bool HOLD, int POISON = kTrigChecked>
+	template <bool HOLD, int POISON = kTrigChecked, bool NOBEVEL = false>
 	__device__ __forceinline__ static void eulerStepT(const DevOptions &o, double (&z)[NZ], Hold &hold, double t,
-	                                                  TrigCarry *cy = nullptr, bool reset = true)
+	                                                  TrigCarry *cy = nullptr, bool reset = true, bool *seen = nullptr)
 	{
+		static_assert(!NOBEVEL || POISON != kTrigChecked, "the bevel-free step is a form of the fast step");
 		double x[NX], fCL[NX], DfCL[NX * NX], zd[NZ];
 #pragma unroll
 		for (int i = 0; i < NX; i++) x[i] = z[i];
-		closedLoopT<HOLD, POISON>(o, x, fCL, DfCL, hold, t, cy, reset);
+		closedLoopT<HOLD, POISON, NOBEVEL>(o, x, fCL, DfCL, hold, t, cy, reset, seen);
 #pragma unroll
 		for (int i = 0; i < NX; i++) zd[i] = fCL[i];
 #pragma unroll

@@ -210,14 +210,16 @@ __global__ __launch_bounds__(256) void implicit_rows_kernel(DevOptions o_arg, Fi
 		const int s0 = blk * MB;
 		const int n = (o.npBT - s0) < MB ? (o.npBT - s0) : MB; // samples of this block
 		const bool more = s0 + n < o.npBT;
-		auto run = [&](auto fast) {
+		bool bevelSeen = false; // bevel-free flavour: some step of the block met a bevel after all
+		auto run = [&](auto fast, auto nobevel) {
 			constexpr int P = !decltype(fast)::value ? kTrigChecked : kFastTrig;
+			constexpr bool NB = decltype(nobevel)::value;
 			brun.reset();
 			// reset: the step out of the block's first sample evaluates sin / cos afresh (kTrigCarried); a literal at every
 			// call site, so that the step is compiled in its two forms instead of choosing at run time
 			auto sample = [&](int k, bool reset) {
 				const int sidx = s0 + k;
-				if (k > 0) BackupLoop<M>::template eulerStepT<RB, P>(o, z, hold, (double)(unsigned)sidx * o.trajDt, &carry, reset);
+				if (k > 0) BackupLoop<M>::template eulerStepT<RB, P, NB>(o, z, hold, (double)(unsigned)sidx * o.trajDt, &carry, reset, &bevelSeen);
 				if (RB && sidx == o.nDebug) {
 #pragma unroll
 					for (int c = 0; c < NZ; c++) zDbg[c] = z[c];
@@ -247,12 +249,42 @@ __global__ __launch_bounds__(256) void implicit_rows_kernel(DevOptions o_arg, Fi
 				for (int k = 2; k < n; k++) sample(k, false);
 			}
 			if (more) { // n == MB here (only the last block is partial)
-				BackupLoop<M>::template eulerStepT<RB, P>(o, z, hold, (double)(unsigned)(s0 + n) * o.trajDt, &carry, false);
+				BackupLoop<M>::template eulerStepT<RB, P, NB>(o, z, hold, (double)(unsigned)(s0 + n) * o.trajDt, &carry, false, &bevelSeen);
 			}
 		};
 		bool redo = !o.satFastOk; // options outside the fast step's preconditions (uniform): generic step throughout
-		if (!redo) {
-			run(std::true_type());
+		// A block none of whose lanes starts near a bevel runs the step without the bevel's divergent block and its
+		// branch (a branch costs a lone wave ~45 cycles, taken or not: an eighth of this step).  "Near" is a prediction
+		// (bevel_rate, models.hpp); bevelSeen is the check, and a block that met a bevel anyway is repeated.
+		bool far = false;
+		if constexpr (bevel_rate<M>::value > 0.0) {
+			if (!redo && n == MB && o.bevelFree) {
+				double xs[NX], u0[1], Du0[NX];
+#pragma unroll
+				for (int c = 0; c < NX; c++) xs[c] = z[c];
+				M::backupController(o, xs, u0, Du0);
+				const double au = fabs(((RB && o.backContDt > 0 ? hold.u : u0[0]) - o.satMiddle) * o.twoOverRange);
+				const double d = bevel_rate<M>::value * (double)MB * o.trajDt;
+				far = !__any(au > o.bevelStart - d && au < o.bevelStop + d);
+			}
+		}
+		if (far) {
+			bevelSeen = false;
+			run(std::true_type(), std::true_type());
+			bool bad = bevelSeen;
+#pragma unroll
+			for (int c = 0; c < NZ; c++) bad = bad || (c < NX ? !(fabs(z[c]) < kStateSane) : (z[c] != z[c]));
+			if constexpr (trig_carry<M>::value) bad = bad || !M::trigCarryBounded(o, brun.value());
+			else if constexpr (trig_by_margin<M>::value) bad = bad || !M::trigArgsBounded(brun.value());
+			far = !__any(bad);
+			if (!far) { // mispredicted (or an alarm): from the block's start again, with the full fast step first
+#pragma unroll
+				for (int c = 0; c < NZ; c++) z[c] = zs[c];
+				hold = hs;
+			}
+		}
+		if (!redo && !far) {
+			run(std::true_type(), std::false_type());
 			bool bad = false;
 #pragma unroll
 			for (int c = 0; c < NZ; c++) bad = bad || (c < NX ? !(fabs(z[c]) < kStateSane) : (z[c] != z[c])); // x: NaN or beyond any sane magnitude; Q: NaN (a stiff model's sensitivity may overflow under forward Euler, as it does upstream)
@@ -266,7 +298,7 @@ __global__ __launch_bounds__(256) void implicit_rows_kernel(DevOptions o_arg, Fi
 			}
 		}
 		if (redo) {
-			run(std::false_type());
+			run(std::false_type(), std::false_type());
 			anyRedo = true;
 		}
 		commit(blk);

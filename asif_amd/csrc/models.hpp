@@ -29,6 +29,9 @@ struct DevOptions {
 	// 2^+-100, finite bounds lb < ub.  The trajectory kernels then run their steps on BackupLoop's fast forms (fewer
 	// compares, sqrt / divide without rescaling steps; same bits); otherwise on the generic ones.
 	int satFastOk;
+	// 1 (default): blocks of Euler steps that start clear of both bevels run without the bevel code (bevel_rate below);
+	// 0 (ASIF_HIP_BEVEL_FREE=0, a developer switch): every block on the full fast step.  Same bits either way.
+	int bevelFree;
 	// input range of the soft saturation, host-evaluated: ub-lb, (ub+lb)/2 and 2/(ub-lb).  The kernel
 	// forms uc = (u - middle) * twoOverRange where the reference divides, 2*(u-middle)/range
 	// (src/asif_implicit.cpp:696): one rounding of difference, no FP64 divide in the 5000-step loop.
@@ -156,6 +159,14 @@ template <class M, class = void>
 struct trig_carry : std::false_type {};
 template <class M>
 struct trig_carry<M, std::enable_if_t<M::kTrigCarry>> : std::true_type {};
+// models that declare kBevelRate (how fast the backup input moves, in units of its normalised range per second, on the
+// trajectories of the model's example) let the rows kernels run a block of steps without the saturation's bevel code
+// when no lane starts the block within  rate x block length x backTrajDt  of a bevel; a prediction only -- a lane that
+// meets a bevel anyway is seen and the block repeated with the full step
+template <class M, class = void>
+struct bevel_rate { static constexpr double value = 0.0; };
+template <class M>
+struct bevel_rate<M, std::enable_if_t<(M::kBevelRate > 0.0)>> { static constexpr double value = M::kBevelRate; };
 template <class M, class = void>
 struct trig_by_margin : std::false_type {};
 template <class M>
@@ -313,6 +324,13 @@ struct InvertedPendulum {
 	static constexpr int NX = 2, NU = 1, NPSS = 4, NPBS = 1, NPBTSS = 10;
 	// samples per checkpoint block of the two-pass critical-sample search (k_implicit.hip): ~sqrt(npBT / 2 npBTSS)
 	static constexpr int kTrajBlock = 16; // measured: 8 is 1.7 % faster at twice the checkpoint memory, 32 is 2.7 % slower
+	// u = -3 (x0 + x1) moves by at most 0.05 of its half-range over 16 steps of 1 ms on the example's trajectories
+	// (tools/scratch/bevel_coherence.py: 60 % of a wave's blocks start that far from both bevels, 0.008 % of those meet
+	// one all the same)
+#ifndef ASIF_PENDULUM_BEVEL_DELTA
+#define ASIF_PENDULUM_BEVEL_DELTA 0.05
+#endif
+	static constexpr double kBevelRate = ASIF_PENDULUM_BEVEL_DELTA / (16 * 0.001);
 	// g = e_last and Dg = 0 for every state: lets the backup loop drop the generic formula's products with
 	// those constants (x*0, x*1, 0+x) -- same values, ~10 fewer FP64 issues per Euler step
 	static constexpr bool kInputOnLastState = true;

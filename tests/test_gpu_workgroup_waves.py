@@ -45,6 +45,14 @@ def test_the_adaptive_integrator_too(hip, cfg, B):
     assert _digests(cfg, B, {"ASIF_HIP_WG_WAVES": "1"}, integrator=1) == _digests(cfg, B, {"ASIF_HIP_WG_WAVES": "4"}, integrator=1)
 
 
+@pytest.mark.parametrize("cfg,B", [(3, 1000), (10, 300)])
+def test_blocks_without_the_bevel_code_give_the_same_bits(hip, cfg, B):
+    """The pendulum's rows kernel runs the blocks of Euler steps that start clear of both bevels of the soft saturation
+    on a step without the bevel code, checks afterwards that no lane met one and repeats the block otherwise
+    (k_implicit.hip, bevel_rate in models.hpp); ASIF_HIP_BEVEL_FREE=0 keeps every block on the full step."""
+    assert _digests(cfg, B, {"ASIF_HIP_BEVEL_FREE": "0"}) == _digests(cfg, B, {})
+
+
 @pytest.mark.parametrize("cfg,n,big", [(9, 8192, 200000), (12, 4096, 70000), (3, 2048, 40000)])
 def test_a_batch_equals_the_prefix_of_a_larger_one(hip, cfg, n, big):
     """n instances alone (few waves: one-wave workgroups, checkpoints in their own LDS region) and as the first n of a
