@@ -236,8 +236,14 @@ __global__ __launch_bounds__(256) void implicit_rows_kernel(DevOptions o_arg, Fi
 					sample(1, true);
 					sample(2, false);
 					sample(3, false);
+					if constexpr (!RB) { // the whole block in line: no loop control at all (C3 776 -> 763 us; the RB step is
+						               // larger and loses 2 % this way)
+#pragma unroll
+						for (int k = 4; k < MB; k++) sample(k, false);
+					} else {
 #pragma unroll 4
-					for (int k = 4; k < MB; k++) sample(k, false);
+						for (int k = 4; k < MB; k++) sample(k, false);
+					}
 				} else {
 #pragma unroll 4
 					for (int k = 0; k < MB; k++) sample(k, false);
