@@ -286,8 +286,13 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 			for (int s0 = 0; s0 < o.npBT; s0 += MB) {
 				if (__all(done)) break;
 				if (s0 > 0 && s0 + MB <= o.npBT) {
+					if constexpr (M::kTbUnrollWholeBlock) {
+#pragma unroll
+						for (int k = 0; k < MB; k++) sample(s0 + k, k == 0);
+					} else {
 #pragma unroll 4
-					for (int k = 0; k < MB; k++) sample(s0 + k, k == 0);
+						for (int k = 0; k < MB; k++) sample(s0 + k, k == 0);
+					}
 				} else {
 #pragma unroll 1
 					for (int k = (s0 == 0 ? 1 : 0); k < MB && s0 + k < o.npBT; k++) sample(s0 + k, k == 0 && s0 > 0);

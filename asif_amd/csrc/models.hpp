@@ -598,6 +598,9 @@ struct DoubleIntegratorImplicit {
 struct DoubleIntegratorTB : DoubleIntegratorImplicit {
 	static constexpr int kTrajBlock = 16; // 2 101-sample trajectory (7 001 after the example's updateOptions)
 	static constexpr bool kTbUnrollSteps = true;
+	// ... and a full block of this small step in line, no loop control (C12 411 -> 350 us; the pendulum's larger step
+	// gains nothing from eight or sixteen copies)
+	static constexpr bool kTbUnrollWholeBlock = true;
 	// :41-57  h = Pv^2 - sum_ij P_ij x_i x_j in the example's loop order, Dh = mPpPt x, DDh = mPpPt
 	__device__ static double backupSetValue(const DevOptions &, const double (&x)[NX])
 	{
@@ -627,6 +630,7 @@ struct InvertedPendulumTB {
 	static constexpr int NX = 2, NU = 1, NPSS = 4, NPBS = 1, NPBTSS = 4;
 	static constexpr int kTrajBlock = 32; // 11 551-sample trajectory, 4 critical samples (measured: 16 = 32 < 64 < 128)
 	static constexpr bool kTbUnrollSteps = true; // k_tb.hip: full blocks unrolled by four
+	static constexpr bool kTbUnrollWholeBlock = false;
 	// g = e_last and Dg = 0 for every state: lets the backup loop drop the generic formula's products with
 	// those constants (x*0, x*1, 0+x) -- same values, ~10 fewer FP64 issues per Euler step
 	static constexpr bool kInputOnLastState = true;
@@ -706,6 +710,7 @@ struct Segway {
 	static constexpr int NX = 4, NU = 1, NPSS = 4, NPBS = 1, NPBTSS = 4;
 	static constexpr int kTrajBlock = 4; // 316-sample trajectory, 4 critical samples (measured: 4 < 8 < 2 < 16)
 	static constexpr bool kTbUnrollSteps = false;
+	static constexpr bool kTbUnrollWholeBlock = false;
 	// the gradients (tanh, Df, Dg) and the 4 x 4 sensitivity are the larger half of the Euler step and x does not
 	// depend on them: pass 1 of the TB kernel may deal x and Q to two waves (k_tb.hip: tb_rows_split_kernel)
 	static constexpr bool kTbSplitRoles = true;
