@@ -229,11 +229,11 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 		                dev.bevelStart > 0 && dev.bevelStart < dev.bevelStop && std::isfinite(o.lb[0]) &&
 		                std::isfinite(o.ub[0]) && o.lb[0] < o.ub[0];
 		dev.satFastOk = ok ? 1 : 0;
-		static const bool bevel_free_off = []() {
+		static const int bevel_free = []() { // developer switch: 0 off, 2 predicts with no margin at all (many repeated blocks)
 			const char *v = getenv("ASIF_HIP_BEVEL_FREE");
-			return v && v[0] == '0';
+			return v && v[0] == '0' ? 0 : (v && v[0] == '2' ? 2 : 1);
 		}();
-		dev.bevelFree = bevel_free_off ? 0 : 1;
+		dev.bevelFree = bevel_free;
 	}
 
 	dev.satRange = o.ub[0] - o.lb[0];

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void implicit_rows_kernel(DevOptions o_arg, Fi
 				for (int c = 0; c < NX; c++) xs[c] = z[c];
 				M::backupController(o, xs, u0, Du0);
 				const double au = fabs(((RB && o.backContDt > 0 ? hold.u : u0[0]) - o.satMiddle) * o.twoOverRange);
-				const double d = bevel_rate<M>::value * (double)MB * o.trajDt;
+				const double d = o.bevelFree == 2 ? 0.0 : bevel_rate<M>::value * (double)MB * o.trajDt;
 				far = !__any(au > o.bevelStart - d && au < o.bevelStop + d);
 			}
 		}

@@ -253,10 +253,12 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 		typename BackupLoop<M>::Hold none = {0.0, 0.0};
 		// one sample: the step into it, the block bookkeeping where a block starts, margin and hit test; per-lane
 		// (lanes that reached the backup set sit out)
-		auto sample = [&](int s, bool opens) {
+		bool bevelSeen = false; // bevel-free steps: a lane met a bevel after all
+		auto sample = [&](int s, bool opens, auto nobevel) {
+			constexpr bool NB = decltype(nobevel)::value;
 			if (!done) {
 				if constexpr (tb_split_roles<M>::value && P == kTrigCarried) BackupLoop<M>::eulerStepRoles(o, z, carry);
-				else BackupLoop<M>::template eulerStepT<false, P>(o, z, none, 0.0, &carry, false);
+				else BackupLoop<M>::template eulerStepT<false, P, NB>(o, z, none, 0.0, &carry, false, &bevelSeen);
 				t = t + o.trajDt; // backTraj_[i].first accumulates, :475
 				sLast = s;
 				if (opens) { // wave-uniform: close the previous block, open the next
@@ -286,16 +288,73 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 			for (int s0 = 0; s0 < o.npBT; s0 += MB) {
 				if (__all(done)) break;
 				if (s0 > 0 && s0 + MB <= o.npBT) {
-					if constexpr (M::kTbUnrollWholeBlock) {
+					// As in k_implicit.hip: a block none of whose lanes starts near a bevel of the soft saturation runs the
+					// step without the bevel code and its branch (bevel_rate, models.hpp).  The sample that opens the block
+					// takes the full step; from there the block's start state is zs, so a block that met a bevel after all
+					// (bevelSeen) goes back to it and runs the full step.
+					bool far = false;
+					if constexpr (bevel_rate<M>::value > 0.0 && P != kTrigChecked) {
+						sample(s0, true, std::false_type());
+						if (o.bevelFree) {
+							double xs[NX], u0[1], Du0[NX];
 #pragma unroll
-						for (int k = 0; k < MB; k++) sample(s0 + k, k == 0);
+							for (int c = 0; c < NX; c++) xs[c] = z[c];
+							M::backupController(o, xs, u0, Du0);
+							const double au = fabs((u0[0] - o.satMiddle) * o.twoOverRange);
+							const double d = o.bevelFree == 2 ? 0.0 : bevel_rate<M>::value * (double)MB * o.trajDt;
+							far = !__any(!done && au > o.bevelStart - d && au < o.bevelStop + d);
+						}
+						if (far) {
+							const double t_b = t, tHit_b = tHit;
+							const int sLast_b = sLast, idxHit_b = idxHit;
+							const bool done_b = done, hit_b = hit;
+							bevelSeen = false;
+							if constexpr (M::kTbUnrollWholeBlock) {
+#pragma unroll
+								for (int k = 1; k < MB; k++) sample(s0 + k, false, std::true_type());
+							} else {
+#pragma unroll 4
+								for (int k = 1; k < MB; k++) sample(s0 + k, false, std::true_type());
+							}
+							if (__any(bevelSeen)) { // mispredicted: the block again from its first sample
+								far = false;
+								if (!done_b) { // (a lane that had reached the backup set before keeps the state it stopped in)
+#pragma unroll
+									for (int c = 0; c < NZ; c++) z[c] = zs[c];
+									if (P == kTrigCarried) resync();
+									double xs[NX];
+#pragma unroll
+									for (int c = 0; c < NX; c++) xs[c] = z[c];
+									brun.reset();
+									brun.add(o, xs);
+									t = t_b;
+									tHit = tHit_b;
+									sLast = sLast_b;
+									idxHit = idxHit_b;
+									done = done_b;
+									hit = hit_b;
+								}
+							}
+						}
+						if (!far) {
+							if constexpr (M::kTbUnrollWholeBlock) {
+#pragma unroll
+								for (int k = 1; k < MB; k++) sample(s0 + k, false, std::false_type());
+							} else {
+#pragma unroll 4
+								for (int k = 1; k < MB; k++) sample(s0 + k, false, std::false_type());
+							}
+						}
+					} else if constexpr (M::kTbUnrollWholeBlock) {
+#pragma unroll
+						for (int k = 0; k < MB; k++) sample(s0 + k, k == 0, std::false_type());
 					} else {
 #pragma unroll 4
-						for (int k = 0; k < MB; k++) sample(s0 + k, k == 0);
+						for (int k = 0; k < MB; k++) sample(s0 + k, k == 0, std::false_type());
 					}
 				} else {
 #pragma unroll 1
-					for (int k = (s0 == 0 ? 1 : 0); k < MB && s0 + k < o.npBT; k++) sample(s0 + k, k == 0 && s0 > 0);
+					for (int k = (s0 == 0 ? 1 : 0); k < MB && s0 + k < o.npBT; k++) sample(s0 + k, k == 0 && s0 > 0, std::false_type());
 				}
 			}
 		} else {
@@ -304,7 +363,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 #pragma unroll 1
 			for (int s = 1; s < o.npBT; s++) {
 				if (__all(done)) break;
-				sample(s, s % MB == 0);
+				sample(s, s % MB == 0, std::false_type());
 			}
 		}
 		commit(sLast / MB); // every lane's last (possibly partial) block

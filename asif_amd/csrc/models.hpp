@@ -30,7 +30,8 @@ struct DevOptions {
 	// compares, sqrt / divide without rescaling steps; same bits); otherwise on the generic ones.
 	int satFastOk;
 	// 1 (default): blocks of Euler steps that start clear of both bevels run without the bevel code (bevel_rate below);
-	// 0 (ASIF_HIP_BEVEL_FREE=0, a developer switch): every block on the full fast step.  Same bits either way.
+	// 0 (ASIF_HIP_BEVEL_FREE=0, a developer switch): every block on the full fast step; 2: the prediction without its
+	// margin, so that many blocks meet a bevel after all and are repeated (a test's way to that path).  Same bits always.
 	int bevelFree;
 	// input range of the soft saturation, host-evaluated: ub-lb, (ub+lb)/2 and 2/(ub-lb).  The kernel
 	// forms uc = (u - middle) * twoOverRange where the reference divides, 2*(u-middle)/range
@@ -597,6 +598,7 @@ struct DoubleIntegratorImplicit {
 // (src/asif_implicit_tb.cpp:494,623): taken as the whole of mPpPt = -2 I here and in the oracle (or_models.c).
 struct DoubleIntegratorTB : DoubleIntegratorImplicit {
 	static constexpr int kTrajBlock = 16; // 2 101-sample trajectory (7 001 after the example's updateOptions)
+	// (no kBevelRate: the bevel-free form of the block measured 8 % SLOWER on this small step, C12 350 -> 378 us)
 	static constexpr bool kTbUnrollSteps = true;
 	// ... and a full block of this small step in line, no loop control (C12 411 -> 350 us; the pendulum's larger step
 	// gains nothing from eight or sixteen copies)
@@ -629,6 +631,9 @@ struct DoubleIntegratorTB : DoubleIntegratorImplicit {
 struct InvertedPendulumTB {
 	static constexpr int NX = 2, NU = 1, NPSS = 4, NPBS = 1, NPBTSS = 4;
 	static constexpr int kTrajBlock = 32; // 11 551-sample trajectory, 4 critical samples (measured: 16 = 32 < 64 < 128)
+	// what the backup input moves in a 32-step block, with room: margins of 0.05 / 0.1 / 0.2 of the half-range measured
+	// 2 043 / 2 009 / 1 981 us on C8 (2 245 without the bevel-free form)
+	static constexpr double kBevelRate = 0.2 / (32 * 0.001);
 	static constexpr bool kTbUnrollSteps = true; // k_tb.hip: full blocks unrolled by four
 	static constexpr bool kTbUnrollWholeBlock = false;
 	// g = e_last and Dg = 0 for every state: lets the backup loop drop the generic formula's products with
