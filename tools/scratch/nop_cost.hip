@@ -20,6 +20,10 @@ __global__ __launch_bounds__(64) void k(int n, double *out)
 			                            : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m), "v"(q));
 			if (MODE == 3) asm volatile("v_fma_f64 %0, %0, %4, %5\n\ts_nop 0\n\tv_fma_f64 %1, %1, %4, %5\n\ts_nop 0\n\tv_fma_f64 %2, %2, %4, %5\n\ts_nop 0\n\tv_fma_f64 %3, %3, %4, %5\n\ts_nop 0"
 			                            : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m), "v"(q));
+			if (MODE == 5) asm volatile("s_mov_b32 s20, 0x12345678\n\ts_mov_b32 s21, 0x3ff12345\n\tv_fma_f64 %0, %0, s[20:21], %4\n\ts_mov_b32 s20, 0x22345678\n\ts_mov_b32 s21, 0x3ff22345\n\tv_fma_f64 %1, %1, s[20:21], %4\n\ts_mov_b32 s20, 0x32345678\n\ts_mov_b32 s21, 0x3ff32345\n\tv_fma_f64 %2, %2, s[20:21], %4\n\ts_mov_b32 s20, 0x42345678\n\ts_mov_b32 s21, 0x3ff42345\n\tv_fma_f64 %3, %3, s[20:21], %4"
+			                            : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(q) : "s20", "s21");
+			if (MODE == 6) asm volatile("v_fma_f64 %0, %0, %4, %8\n\tv_fma_f64 %1, %1, %5, %8\n\tv_fma_f64 %2, %2, %6, %8\n\tv_fma_f64 %3, %3, %7, %8"
+			                            : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m), "v"(m + 1e-9), "v"(m + 2e-9), "v"(m + 3e-9), "v"(q));
 			if (MODE == 4) asm volatile("v_fma_f64 %0, %0, %2, %3\n\tv_fma_f64 %1, %1, %2, %3" : "+v"(a), "+v"(e) : "v"(m), "v"(q));
 		}
 	}
@@ -51,5 +55,7 @@ int main()
 	run<2>("four independent chains", 4, d);
 	run<3>("four independent chains, s_nop 0 after every fma", 4, d);
 	run<4>("dependent chain + one independent fma in between (per pair)", 2, d);
+	run<5>("four independent chains, each constant a 64-bit literal (s_mov x2)", 4, d);
+	run<6>("four independent chains, the four constants in VGPRs", 4, d);
 	return 0;
 }
