@@ -302,21 +302,38 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 							M::backupController(o, xs, u0, Du0);
 							const double au = fabs((u0[0] - o.satMiddle) * o.twoOverRange);
 							const double d = o.bevelFree == 2 ? 0.0 : bevel_rate<M>::value * (double)MB * o.trajDt;
-							far = !__any(!done && au > o.bevelStart - d && au < o.bevelStop + d);
+							far = !__any(!done && ((au > o.bevelStart - d && au < o.bevelStop + d) || (o.bevelFree != 2 && !M::arrivalFar(o, xs, MB))));
 						}
 						if (far) {
 							const double t_b = t, tHit_b = tHit;
 							const int sLast_b = sLast, idxHit_b = idxHit;
 							const bool done_b = done, hit_b = hit;
 							bevelSeen = false;
-							if constexpr (M::kTbUnrollWholeBlock) {
+							// ... and without the per-sample questions "is this lane still integrating" and "has it reached the
+							// backup set": the first cannot change inside a block in which no lane arrives, so it is asked once
+							// for the block, and an arrival (each lane has one in its life) is latched like a bevel and the block
+							// repeated with the full sample.  Two divergent regions and their branches less per step.
+							bool hitSeen = false;
+							if (!done) {
+								auto quiet = [&]() {
+									BackupLoop<M>::template eulerStepT<false, P, true>(o, z, none, 0.0, &carry, false, &bevelSeen);
+									t = t + o.trajDt;
+									double xs[NX];
 #pragma unroll
-								for (int k = 1; k < MB; k++) sample(s0 + k, false, std::true_type());
-							} else {
+									for (int c = 0; c < NX; c++) xs[c] = z[c];
+									brun.add(o, xs);
+									hitSeen = hitSeen || M::backupSetInside(o, xs);
+								};
+								if constexpr (M::kTbUnrollWholeBlock) {
+#pragma unroll
+									for (int k = 1; k < MB; k++) quiet();
+								} else {
 #pragma unroll 4
-								for (int k = 1; k < MB; k++) sample(s0 + k, false, std::true_type());
+									for (int k = 1; k < MB; k++) quiet();
+								}
+								sLast = s0 + MB - 1;
 							}
-							if (__any(bevelSeen)) { // mispredicted: the block again from its first sample
+							if (__any(bevelSeen || hitSeen)) { // mispredicted: the block again from its first sample
 								far = false;
 								if (!done_b) { // (a lane that had reached the backup set before keeps the state it stopped in)
 #pragma unroll

@@ -31,7 +31,8 @@ struct DevOptions {
 	int satFastOk;
 	// 1 (default): blocks of Euler steps that start clear of both bevels run without the bevel code (bevel_rate below);
 	// 0 (ASIF_HIP_BEVEL_FREE=0, a developer switch): every block on the full fast step; 2: the prediction without its
-	// margin, so that many blocks meet a bevel after all and are repeated (a test's way to that path).  Same bits always.
+	// margin (and, in the TB pass, without asking whether a lane is about to reach the backup set), so that many blocks
+	// meet a bevel or an arrival after all and are repeated (a test's way to that path).  Same bits always.
 	int bevelFree;
 	// input range of the soft saturation, host-evaluated: ub-lb, (ub+lb)/2 and 2/(ub-lb).  The kernel
 	// forms uc = (u - middle) * twoOverRange where the reference divides, 2*(u-middle)/range
@@ -599,6 +600,7 @@ struct DoubleIntegratorImplicit {
 struct DoubleIntegratorTB : DoubleIntegratorImplicit {
 	static constexpr int kTrajBlock = 16; // 2 101-sample trajectory (7 001 after the example's updateOptions)
 	// (no kBevelRate: the bevel-free form of the block measured 8 % SLOWER on this small step, C12 350 -> 378 us)
+	__device__ static bool arrivalFar(const DevOptions &, const double (&)[NX], int) { return false; } // (unused: no quiet blocks)
 	static constexpr bool kTbUnrollSteps = true;
 	// ... and a full block of this small step in line, no loop control (C12 411 -> 350 us; the pendulum's larger step
 	// gains nothing from eight or sixteen copies)
@@ -673,6 +675,13 @@ struct InvertedPendulumTB {
 	}
 	__device__ static double backupSetValue(const DevOptions &, const double (&x)[NX]) { return x[0] - kPi / 2. + 0.1; }
 	__device__ static bool backupSetInside(const DevOptions &o, const double (&x)[NX]) { return backupSetValue(o, x) >= 0.0; }
+	// cannot arrive within `steps` Euler steps: the angle moves by at most (|omega| + 0.5) dt per step over a block (the
+	// 0.5 rad/s covers what the bounded input and gravity add to omega in 32 ms several times over).  A prediction for
+	// k_tb.hip's quiet blocks; an arrival it missed is seen and the block repeated.
+	__device__ static bool arrivalFar(const DevOptions &o, const double (&x)[NX], int steps)
+	{
+		return backupSetValue(o, x) + (double)steps * o.trajDt * (fabs(x[1]) + 0.5) < 0.0;
+	}
 	// :76-85  u = K (vDes - omega)
 	__device__ static void backupController(const DevOptions &, const double (&x)[NX], double (&u)[NU], double (&Du)[NU * NX])
 	{
@@ -716,6 +725,7 @@ struct Segway {
 	static constexpr int kTrajBlock = 4; // 316-sample trajectory, 4 critical samples (measured: 4 < 8 < 2 < 16)
 	static constexpr bool kTbUnrollSteps = false;
 	static constexpr bool kTbUnrollWholeBlock = false;
+	__device__ static bool arrivalFar(const DevOptions &, const double (&)[4], int) { return false; } // (unused: no quiet blocks)
 	// the gradients (tanh, Df, Dg) and the 4 x 4 sensitivity are the larger half of the Euler step and x does not
 	// depend on them: pass 1 of the TB kernel may deal x and Q to two waves (k_tb.hip: tb_rows_split_kernel)
 	static constexpr bool kTbSplitRoles = true;
