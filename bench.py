@@ -38,9 +38,13 @@ SHADER_CLOCK_HZ = 2.4e9  # MI355X peak engine clock
 N_SIMD = 256 * 4
 VALU_ISSUE_CYCLES = 4    # one wave's FP64 / FP32 vector instruction occupies its SIMD's issue for 4 cycles
                          # (MI355X_MICROARCH.md, row "vector-instruction ISSUE cost"; FP64 FMA: 16 lanes per cycle)
-PROFILE_ROUND = "r03"
+PROFILE_ROUNDS = ("r04", "r03")  # committed rocprofv3 summaries, newest first: a config not re-profiled this round keeps its last one
 
 # algorithmic HBM bytes per instance of the state->input path: read 8(nx+nu), write 8(nu+nrelax)+4
+# the dominant kernel of each config's step, as its name appears in a rocprofv3 kernel trace
+DOMINANT_KERNEL = {2: "explicit_light_kernel", 3: "implicit_rows_kernel", 4: "tb_rows_kernel", 5: "qp_policy_kernel",
+                   6: "realizable_filter_kernel", 7: "robust_data", 8: "tb_rows_kernel", 9: "implicit_rows_kernel",
+                   10: "implicit_rows_kernel", 11: "explicit", 12: "tb_rows_kernel"}
 ALG_BYTES = {2: 44, 3: 52, 4: 60, 5: 44, 6: 52, 7: 44, 8: 44, 9: 52, 10: 52, 11: 60, 12: 44}
 IMPLICIT_RB_CFG = 10  # ASIFimplicitRB on the pendulum model; not a BASELINE.json config
 REALIZABLE_CFG = 6  # ASIFrealizable on the sampled double integrator; not a BASELINE.json config
@@ -208,15 +212,31 @@ def profile_numbers(tag):
     """Counter-derived numbers of the committed rocprofv3 passes of this command (profiles/<round>/): PMC passes cannot
     run inside this process.  Returns (traffic_bytes_per_step, sq summary dict or None, source string)."""
     traffic, sq, src = None, None, None
-    base = os.path.join(ROOT, "profiles", PROFILE_ROUND)
-    f = os.path.join(base, f"{tag}_pmc_summary.json")
-    if os.path.isfile(f):
-        traffic = json.load(open(f)).get("traffic_bytes_per_step")
-        src = f"profiles/{PROFILE_ROUND}/{tag}_pmc_summary.json"
-    f = os.path.join(base, f"{tag}_sq_summary.json")
-    if os.path.isfile(f):
-        sq = json.load(open(f))
+    for rnd in PROFILE_ROUNDS:
+        base = os.path.join(ROOT, "profiles", rnd)
+        f = os.path.join(base, f"{tag}_pmc_summary.json")
+        if traffic is None and os.path.isfile(f):
+            traffic = json.load(open(f)).get("traffic_bytes_per_step")
+            src = f"profiles/{rnd}/{tag}_pmc_summary.json"
+        f = os.path.join(base, f"{tag}_sq_summary.json")
+        if sq is None and os.path.isfile(f):
+            sq = json.load(open(f))
+            sq["_source"] = f"profiles/{rnd}/{tag}_sq_summary.json"
     return traffic, sq, src
+
+
+def rocprof_direct(tag, kernel_substr):
+    """AverageNs of the dominant kernel in the committed rocprofv3 --kernel-trace --stats summary of the DIRECT-launch
+    leg of this command alone (tools/prof_direct.sh: --graph 0 --no-pcie --no-cpu-baseline, nothing else in the
+    process): (average ns, calls, file) or None.  A reader recomputes roofline.frac_rocprof from that CSV."""
+    import csv
+    for rnd in PROFILE_ROUNDS:
+        f = os.path.join(ROOT, "profiles", rnd, f"{tag}_direct_kernel_stats.csv")
+        if os.path.isfile(f):
+            for r in csv.DictReader(open(f)):
+                if kernel_substr in r["Name"]:
+                    return float(r["AverageNs"]), int(r["Calls"]), f"profiles/{rnd}/{tag}_direct_kernel_stats.csv"
+    return None
 
 
 def valu_roofline(sq, step_ms, tag):
@@ -235,7 +255,7 @@ def valu_roofline(sq, step_ms, tag):
             "insts_salu_per_step": sq.get("insts_salu_per_step"), "frac_valu_plus_salu": slots,
             "waves_per_step": sq.get("waves_per_step"), "insts_valu_per_wave": sq.get("insts_valu_per_wave"),
             "issue_cycles_per_inst": VALU_ISSUE_CYCLES, "simd_cycles_available": avail, "frac": used / avail,
-            "counters_source": f"profiles/{PROFILE_ROUND}/{tag}_sq_summary.json (rocprofv3 --pmc, separate pass of the "
+            "counters_source": f"{sq.get('_source', tag)} (rocprofv3 --pmc, separate pass of the "
                                "same command); duration measured live",
             "single_wave_ceiling": 4.0 / 5.16,
             "note": "frac = share of all SIMD issue slots of the chip (4 cycles per vector instruction: the 78.6 TFLOP/s "
@@ -662,6 +682,7 @@ def bench_filter(args, grp, dev, cfg, headline):
     traffic, sq, traffic_src = (None, None, None)
     if B == default_b and (cfg != REALIZABLE_CFG or args.kernel == "100Hz"):
         traffic, sq, traffic_src = profile_numbers(tag)
+    direct = rocprof_direct(tag, DOMINANT_KERNEL.get(cfg, "asif")) if B == default_b else None
     working_set = (8 * (d.nx + 2 * d.nu + d.nrelax) + 4) * B
     note = ("HBM is the mandated roofline and not the one that binds: 44-60 algorithmic bytes against 10^3-10^6 FP64 "
             "operations per instance; see `valu` and DESIGN.md")
@@ -704,6 +725,13 @@ def bench_filter(args, grp, dev, cfg, headline):
                      # the explicit filter at 16 M: old outputs of failed instances re-read -- this is what the memory system did)
                      "traffic_frac": (traffic / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "kernel_avg_us": step_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
+                     # the same fraction from the committed profile instead of this run's event pair: algorithmic
+                     # bytes / AverageNs of the dominant kernel in the rocprofv3 kernel trace of the direct-launch leg
+                     # alone (tools/prof_direct.sh) / peak -- recomputable from the named CSV
+                     "frac_rocprof": (alg_bytes / direct[0] / HBM_PEAK_GBS) if direct else None,
+                     "rocprof_kernel_avg_ns": direct[0] if direct else None,
+                     "rocprof_calls": direct[1] if direct else None,
+                     "rocprof_source": direct[2] if direct else None,
                      "valu": valu_roofline(sq, step_ms, tag), "note": note},
     }
     if other is not None:
@@ -740,6 +768,8 @@ def compact(rec):
             "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
                          "traffic": r["traffic"], "traffic_source": r["traffic_source"], "kernel_avg_us": r["kernel_avg_us"],
                          "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+                         "frac_rocprof": r.get("frac_rocprof"), "rocprof_kernel_avg_ns": r.get("rocprof_kernel_avg_ns"),
+                         "rocprof_source": r.get("rocprof_source"),
                          "valu": v.get("frac"), "valu_plus_salu": v.get("frac_valu_plus_salu"),
                          "valu_counters_source": v.get("counters_source")},
             "parity": rec.get("parity"), "cpu_baseline": rec.get("cpu_baseline")}
