@@ -287,7 +287,10 @@ struct BackupLoop {
 	};
 	static constexpr int kRecordDoubles = 8;
 	// fast step of x alone (trig carried along the steps, soft saturation's short forms); returns the record of this step
-	__device__ __forceinline__ static StepRecord stepX(const DevOptions &o, double (&x)[NX], TrigCarry &cy)
+	// k: the model's constants as the caller's loop holds them (M::constants<PIN>() made before the loop: the groups of
+	// PIN in vector registers; values unchanged).  CARRYV: the same choice for the seven constants of sincos_carry.
+	template <bool CARRYV = false, class KC>
+	__device__ __forceinline__ static StepRecord stepX(const DevOptions &o, double (&x)[NX], TrigCarry &cy, const KC &k)
 	{
 #pragma clang fp contract(on)
 		static_assert(!M::kInputOnLastState, "role split is written for the general closed loop (the segway)");
@@ -295,9 +298,10 @@ struct BackupLoop {
 		double f[NX], g[NX], u[1], Du[NX];
 		r.xg[0] = x[M::kGradStates[0]];
 		r.xg[1] = x[M::kGradStates[1]];
-		M::backupController(o, x, u, Du);
+		M::backupController(o, x, u, Du, k);
 		saturateSoft<true>(o, u[0], r.uSat, r.DuSat);
-		sincos_carry<(M::NX <= 2)>(x[M::kTrigAngle], cy); // (the segway's kernels have no vector register to spare)
+		// (the segway's fused kernels have no vector register to spare for the seven constants; its x role has)
+		sincos_carry<(M::NX <= 2) || CARRYV>(x[M::kTrigAngle], cy);
 		r.s = cy.s;
 		r.c = cy.c;
 		typename M::Trig t;
@@ -305,7 +309,7 @@ struct BackupLoop {
 		t.c1 = cy.c;
 		t.s2 = 2.0 * t.s1 * t.c1;
 		t.c2 = (t.c1 - t.s1) * (t.c1 + t.s1);
-		const typename M::Shared h = M::dynamicsT(x, t, f, g);
+		const typename M::Shared h = M::dynamicsT(x, t, f, g, k);
 		r.iden = h.iden;
 		r.rg = h.rg;
 #pragma unroll
@@ -316,7 +320,8 @@ struct BackupLoop {
 		return r;
 	}
 	// the same step's update of Q (vec Q in q, column-major) from the record
-	__device__ __forceinline__ static void stepQ(const DevOptions &o, const StepRecord &r, double (&q)[NX * NX])
+	template <bool TANHV = false, class KC>
+	__device__ __forceinline__ static void stepQ(const DevOptions &o, const StepRecord &r, double (&q)[NX * NX], const KC &k)
 	{
 #pragma clang fp contract(on)
 		double xr[NX], g[NX], Df[NX * NX], Dg[NX * NX], u[1], Du[NX], DfCL[NX * NX], zd[NX * NX];
@@ -324,7 +329,7 @@ struct BackupLoop {
 		for (int i = 0; i < NX; i++) xr[i] = 0.0;
 		xr[M::kGradStates[0]] = r.xg[0];
 		xr[M::kGradStates[1]] = r.xg[1];
-		M::backupController(o, xr, u, Du); // Du is the constant gain; u is not used here
+		M::backupController(o, xr, u, Du, k); // Du is the constant gain; u is not used here
 		typename M::Trig t;
 		t.s1 = r.s;
 		t.c1 = r.c;
@@ -333,8 +338,8 @@ struct BackupLoop {
 		typename M::Shared h;
 		h.iden = r.iden;
 		h.rg = r.rg;
-		M::gainT(t, h, g);
-		M::gradientsGiven(xr, t, h, Df, Dg);
+		M::gainT(t, h, g, k);
+		M::template gradientsGiven<TANHV>(xr, t, h, Df, Dg, k);
 #pragma unroll
 		for (int i = 0; i < NX; i++) {
 			if (unitRow(i)) continue; // row i of DfCL Q is row i+1 of Q
@@ -370,8 +375,9 @@ struct BackupLoop {
 		for (int i = 0; i < NX; i++) x[i] = z[i];
 #pragma unroll
 		for (int i = 0; i < NX * NX; i++) q[i] = z[NX + i];
-		const StepRecord r = stepX(o, x, cy);
-		stepQ(o, r, q);
+		const typename M::Consts k = M::template constants<0>(); // plain literals
+		const StepRecord r = stepX(o, x, cy, k);
+		stepQ(o, r, q, k);
 #pragma unroll
 		for (int i = 0; i < NX; i++) z[i] = x[i];
 #pragma unroll

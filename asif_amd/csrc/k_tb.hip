@@ -61,43 +61,58 @@ __device__ __forceinline__ void tb_q_role(const DevOptions &o, const double *rin
 #pragma unroll
 	for (int e = 0; e < NX * NX; e++) q[e] = qs[e] = (e % (NX + 1) == 0) ? 1.0 : 0.0;
 	const int nblk = (npBT + MB - 1) / MB;
+	constexpr unsigned kPinQ = M::kPinQ;
+	const typename M::Consts kq = M::template constants<kPinQ>(); // made once: the pinned groups live in VGPRs from here on
 	auto keep = [&](int slot) { // Q part of the checkpoint of the block that just closed
 #pragma unroll
 		for (int e = 0; e < NX * NX; e++) ckl[(slot * NZ + NX + e) * 64 + lane] = qs[e];
 	};
+	auto record = [&](int buf, int k) { // the x wave's record of step k of the block in ring buffer `buf`
+		typename BL::StepRecord r;
+		const double *rec = ring + (size_t)((buf * MB + k) * NF) * 64 + lane;
+		r.xg[0] = rec[0 * 64];
+		r.xg[1] = rec[1 * 64];
+		r.uSat = rec[2 * 64];
+		r.DuSat = rec[3 * 64];
+		r.s = rec[4 * 64];
+		r.c = rec[5 * 64];
+		r.iden = rec[6 * 64];
+		r.rg = rec[7 * 64];
+		return r;
+	};
+	// one step of the sensitivity; the step into the first sample of a block closes the block before: its checkpoint's
+	// Q part goes to the slot the x wave chose, and the new block's start is noted
+	auto step = [&](const typename BL::StepRecord &r, int c, bool blockStart) {
+		BL::template stepQ<(kPinQ & M::kPinTanh) != 0>(o, r, q, kq);
+		if (blockStart) {
+			const int slot = (c >> 8) - 1;
+			if (slot >= 0) keep(slot);
+#pragma unroll
+			for (int e = 0; e < NX * NX; e++) qs[e] = q[e];
+		}
+	};
+	// A lane that did not step (it reached the backup set, or started inside it: a third of the segway's seeded batch)
+	// holds a stale record and sits the step out under the exec mask: one s_and_saveexec + skip branch per step where
+	// "compute and drop" paid two selects per entry of Q.  Whether the sample exists at all (the first block starts at
+	// sample 1, the last may be partial) is wave-uniform and goes into the same mask instead of a branch of its own -- a
+	// lone wave pays ~50 cycles for every branch instruction, taken or not.  Nothing hides an LDS round trip from a lone
+	// wave either: the block's control words are read together, and the record of step k + 1 is on its way while step k
+	// computes (the loads are unconditional -- a stale record is read and not used).
 #pragma unroll 1
 	for (int b = 0; b < nblk; b++) {
 		__syncthreads(); // A_b: buffer b & 1 holds block b (or the stop flag)
 		const int buf = b & 1;
 		if (flags[buf]) break; // wave-uniform
+		int c[MB];
+#pragma unroll
+		for (int k = 0; k < MB; k++) c[k] = ctl[(buf * MB + k) * 64 + lane]; // (stale where the sample does not exist)
+		typename BL::StepRecord rn = record(buf, 0);
 #pragma unroll
 		for (int k = 0; k < MB; k++) {
 			const int s = b * MB + k;
-			if (s == 0 || s >= npBT) continue; // wave-uniform
-			const int c = ctl[(buf * MB + k) * 64 + lane];
-			const bool act = (c & 1) != 0;
-			typename BL::StepRecord r;
-			const double *rec = ring + (size_t)((buf * MB + k) * NF) * 64 + lane;
-			r.xg[0] = rec[0 * 64];
-			r.xg[1] = rec[1 * 64];
-			r.uSat = rec[2 * 64];
-			r.DuSat = rec[3 * 64];
-			r.s = rec[4 * 64];
-			r.c = rec[5 * 64];
-			r.iden = rec[6 * 64];
-			r.rg = rec[7 * 64];
-			double qn[NX * NX];
-#pragma unroll
-			for (int e = 0; e < NX * NX; e++) qn[e] = q[e];
-			BL::stepQ(o, r, qn); // a lane that did not step holds a stale record: computed and dropped
-#pragma unroll
-			for (int e = 0; e < NX * NX; e++) q[e] = act ? qn[e] : q[e];
-			if (k == 0 && b > 0) { // the step into the first sample of block b closed block b - 1
-				const int slot = (c >> 8) - 1;
-				if (act && slot >= 0) keep(slot);
-#pragma unroll
-				for (int e = 0; e < NX * NX; e++) qs[e] = act ? q[e] : qs[e];
-			}
+			const typename BL::StepRecord r = rn;
+			if (k + 1 < MB) rn = record(buf, k + 1);
+			if ((s != 0) & (s < npBT) & ((c[k] & 1) != 0)) step(r, c[k], k == 0 && b > 0);
 		}
 	}
 	__syncthreads(); // B1: every lane's last-block slot is published
@@ -138,6 +153,12 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 	// VGPRs at every Euler step; an opaque copy made once, here, stays in two VGPR pairs for the whole kernel
 	DevOptions o = o_arg;
 	asm("" : "+v"(o.lb[0]), "+v"(o.ub[0]));
+	// two-role pass: the scalars the saturation and the step read at every sample, likewise -- the scalar file does not
+	// hold them next to the masks of the x role's per-sample tests and they came back from spill lanes (v_readlane), 18
+	// per step
+	if constexpr (SPLIT)
+		asm("" : "+v"(o.satMiddle), "+v"(o.twoOverRange), "+v"(o.bevelStop), "+v"(o.bevelStart), "+v"(o.satSharpness),
+		    "+v"(o.satRange), "+v"(o.trajDt));
 	constexpr int NX = M::NX, NP = M::NPSS, K = M::NPBTSS, NZ = NX + NX * NX;
 	constexpr int NC = K * NP + 2, NV = 2;
 	extern __shared__ double tb_lds_all[];
@@ -425,6 +446,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 			return slot;
 		};
 		const int nblk = (o.npBT + MB - 1) / MB;
+		constexpr unsigned kPinX = M::kPinX;
+		const typename M::Consts kx = M::template constants<kPinX>(); // made once: the pinned groups live in VGPRs from here on
 #pragma unroll 1
 		for (int b = 0; b < nblk; b++) {
 			const int buf = b & 1;
@@ -434,13 +457,13 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 #pragma unroll
 				for (int k = 0; k < MB; k++) { // unrolled: the record's LDS addresses are a base per buffer plus immediates
 					const int s = b * MB + k;
-					if (s == 0 || s >= o.npBT) continue; // wave-uniform
+					// (whether the sample exists -- wave-uniform -- in the lanes' mask rather than a branch of its own)
 					int c = 0;
-					if (!done) {
+					if ((s != 0) & (s < o.npBT) & !done) {
 						double xs[NX];
 #pragma unroll
 						for (int e = 0; e < NX; e++) xs[e] = z[e];
-						const typename BL::StepRecord r = BL::stepX(o, xs, carry);
+						const typename BL::StepRecord r = BL::template stepX<(kPinX & M::kPinCarry) != 0>(o, xs, carry, kx);
 #pragma unroll
 						for (int e = 0; e < NX; e++) z[e] = xs[e];
 						t = t + o.trajDt;

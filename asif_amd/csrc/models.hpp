@@ -5,6 +5,7 @@
 // The numeric constants are the workload definition and are restated from the cited example files.
 #pragma once
 #include <type_traits>
+#include <utility>
 #include <hip/hip_runtime.h>
 #include "asif_hip.h"
 
@@ -103,6 +104,22 @@ __device__ __forceinline__ double fma3(double a, double b, double c)
 #else
 	return fma(a, b, c);
 #endif
+}
+
+// A wave-uniform 64-bit constant held in a VGPR pair for as long as it is live.  FP64 instructions of gfx950 take no
+// 64-bit literal: a constant that is not in a register when it is needed costs two s_mov_b32 per use, and the ~100
+// scalar registers do not hold the segway step's ~110 constants -- the compiler re-materialises them, 30-40 scalar
+// moves per Euler step, and spills scalars to vector lanes on top (v_readlane to get them back).  The empty asm makes
+// the value opaque (nothing to re-materialise) and is free of side effects, so it is hoisted out of the loops and
+// merged where it repeats; which constants are pinned is chosen per role against the vector registers the role has
+// to spare (Segway::kPinX / kPinQ).  The value itself is untouched: same bits.
+template <bool PIN>
+__device__ __forceinline__ double vk(double c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	if constexpr (PIN) asm("" : "+v"(c));
+#endif
+	return c;
 }
 
 // How the fast path's argument range (|x| <= 1e5) is policed (the same constant selects the backup loop's step form:
@@ -458,24 +475,54 @@ __device__ __forceinline__ double rcp_newton(double d)
 // below 4e-16 over the whole line, which is what matters here: the model uses th and th^2 additively (a relative
 // error bound near y = 0 would cost the expm1 form).  ocml's tanh is ~160 vector instructions of double-double
 // arithmetic, a fifth of the segway's Euler step; this is ~35.  NaN stays NaN.
-__device__ __forceinline__ double tanh_abs_accurate(double y)
+// The constants come in through `c` (tanh_const(0..12) in order): a caller that runs this in a loop may hold them in
+// vector registers (vk above; made before the loop) and then asks for V3, the Horner steps as the three-address
+// instruction -- with the addend in a vector register the compiler's two-address form would copy it first.
+constexpr int kTanhConsts = 13;
+constexpr double tanh_const(int i)
+{
+	constexpr double t[kTanhConsts] = {
+		1.44269504088896338700e+00, 6.93147180369123816490e-01, 1.90821492927058770002e-10, // 1/ln 2, ln 2 high, low
+		2.08767569878680989792e-09, 2.50521083854417187751e-08, 2.75573192239858906526e-07, // 1/12!, 1/11!, 1/10!
+		2.75573192239858906526e-06, 2.48015873015873015873e-05, 1.98412698412698412698e-04, // 1/9!, 1/8!, 1/7!
+		1.38888888888888888889e-03, 8.33333333333333333333e-03, 4.16666666666666666667e-02, // 1/6!, 1/5!, 1/4!
+		1.66666666666666666667e-01,                                                         // 1/3!
+	};
+	return t[i];
+}
+struct TanhConsts { double v[kTanhConsts]; };
+template <bool PIN, int... I>
+__device__ __forceinline__ void fill_tanh_consts(TanhConsts &c, std::integer_sequence<int, I...>)
+{
+	((c.v[I] = vk<PIN>(tanh_const(I))), ...);
+}
+template <bool PIN = false>
+__device__ __forceinline__ TanhConsts tanh_consts()
+{
+	TanhConsts c;
+	fill_tanh_consts<PIN>(c, std::make_integer_sequence<int, kTanhConsts>());
+	return c;
+}
+template <bool V3 = false>
+__device__ __forceinline__ double tanh_abs_accurate(double y, const TanhConsts &c = tanh_consts<false>())
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+	auto h = [](double a, double b, double k) { return V3 ? fma3(a, b, k) : fma(a, b, k); };
 	const double a = fabs(y);
 	const double x = -2.0 * (a < 25.0 ? a : 25.0);
-	const double n = rint(x * 1.44269504088896338700e+00);
-	double r = fma(-n, 6.93147180369123816490e-01, x);
-	r = fma(-n, 1.90821492927058770002e-10, r);
-	double p = 2.08767569878680989792e-09; // 1/12!
-	p = fma(p, r, 2.50521083854417187751e-08);
-	p = fma(p, r, 2.75573192239858906526e-07);
-	p = fma(p, r, 2.75573192239858906526e-06);
-	p = fma(p, r, 2.48015873015873015873e-05);
-	p = fma(p, r, 1.98412698412698412698e-04);
-	p = fma(p, r, 1.38888888888888888889e-03);
-	p = fma(p, r, 8.33333333333333333333e-03);
-	p = fma(p, r, 4.16666666666666666667e-02);
-	p = fma(p, r, 1.66666666666666666667e-01);
+	const double n = rint(x * c.v[0]);
+	double r = fma(-n, c.v[1], x);
+	r = fma(-n, c.v[2], r);
+	double p = c.v[3];
+	p = h(p, r, c.v[4]);
+	p = h(p, r, c.v[5]);
+	p = h(p, r, c.v[6]);
+	p = h(p, r, c.v[7]);
+	p = h(p, r, c.v[8]);
+	p = h(p, r, c.v[9]);
+	p = h(p, r, c.v[10]);
+	p = h(p, r, c.v[11]);
+	p = h(p, r, c.v[12]);
 	p = fma(p, r, 0.5);
 	p = fma(p, r, 1.0);
 	p = fma(p, r, 1.0);
@@ -791,31 +838,106 @@ struct Segway {
 	// gets the exact expression behind one wave-level branch, so the decision is always the exact one.
 	__device__ static bool backupSetInside(const DevOptions &o, const double (&x)[NX])
 	{
-		double v = 0.05 * 0.05, mag = 0.05 * 0.05;
+		double v = 0.05 * 0.05;
 #pragma unroll
 		for (int i = 0; i < NX; i++) {
 			const double q = x[i] * (1.0 / xb(i)); // 1/xb folds to a constant
 			v -= q * q;
-			mag += q * q;
 		}
 		bool in = v >= 0.0;
 #if defined(__HIP_DEVICE_COMPILE__)
-		const bool close = !(fabs(v) > 1e-13 * mag);
+		// The two sums differ by rounding only: by far less than 1e-13 (c + sum q^2) = 1e-13 (2c - v), c = Pv^2.  A value
+		// within that of zero has |v| <= 2e-13 c / (1 - 1e-13) < 1e-15: the constant screens a superset, with no second
+		// accumulation (NaN compares false: close).
+		const bool close = !(fabs(v) > 1e-15);
 		if (__any(close)) {
 			if (close) in = backupSetValue(o, x) >= 0.0;
 		}
 #else
-		(void)mag;
 		in = backupSetValue(o, x) >= 0.0;
 #endif
 		return in;
 	}
+	// ---- The 64-bit constants of the Euler step.  The expressions below name them by value -- K_(group, 44.7214) --
+	// and read them out of a `Consts` the caller made: `constants<0>()` (the default argument) holds plain literals and
+	// folds away; `constants<PIN>()`, made ONCE before a loop, holds the groups named in PIN in vector registers
+	// (vk above) for as long as the loop runs.  A negative literal reads the entry of its magnitude, negated (free: a
+	// source modifier).  Which groups a role of the two-role TB pass pins: kPinX / kPinQ, chosen against the vector
+	// registers that role has to spare.  Values, and therefore bits, do not depend on any of it.
+	static constexpr unsigned kPinCtl = 1, kPinDyn = 2, kPinRg = 4, kPinGain = 8, kPinTanh = 16, kPinDfA = 32, kPinDfB = 64,
+	                          kPinDfC = 128, kPinCarry = 256;
+	// The two roles of the TB pass (k_tb.hip): the x role has registers to spare for every constant it reads, the
+	// sincos_carry polynomial's included; the Q role for the gradients', the gain's, the controller's and tanh's
+	// (62 + 13 constants: 150 VGPRs between the two roles, none spilled).  C4 244 -> 194 us together with the roles'
+	// exec-mask form, DESIGN 4.2.
+	static constexpr unsigned kPinX = kPinCtl | kPinDyn | kPinRg | kPinGain | kPinCarry;
+	static constexpr unsigned kPinQ = kPinCtl | kPinGain | kPinTanh | kPinDfA | kPinDfB | kPinDfC;
+	struct KEntry { unsigned grp; double mag; };
+	static constexpr int kNK = 60;
+	static constexpr KEntry kentry(int i)
+	{
+		constexpr KEntry t[kNK] = {
+			{kPinCtl, 44.7214}, {kPinCtl, 44.6528}, {kPinCtl, 150.1612}, {kPinCtl, 37.6492},
+			{kPinCtl, 0.1383244254},
+			{kPinDyn, 14.553176960783997}, {kPinDyn, 2.0831375273848773}, {kPinDyn, 0.59146430898882}, {kPinDyn, 0.33003710190723146},
+			{kPinDyn, 2.3707272057666411}, {kPinDyn, 5.8022648711803244}, {kPinDyn, 20.435579143645651}, {kPinDyn, 40.918271887954823},
+			{kPinDyn, 293.92471275850022}, {kPinDyn, 2.0831375273848769},
+			{kPinRg, 8.3593271361634187}, {kPinRg, 2.1243074194638587}, {kPinRg, 0.04116989207898096}, {kPinRg, 0.29573215449441},
+			{kPinGain, 1.4575004011882324}, {kPinGain, 0.20290365220710288}, {kPinGain, 0.551244194154502}, {kPinGain, 4.1706936767483551},
+			{kPinGain, 5.65378660671284}, {kPinGain, 2.0043013906215941},
+			{kPinDfA, 15.13175750513302}, {kPinDfA, 40.918271887954823}, {kPinDfA, 3.3849959169972448}, {kPinDfA, 30.26351501026604},
+			{kPinDfA, 8443.5211353581435}, {kPinDfA, 410.77609832706019}, {kPinDfA, 2950.692713500939}, {kPinDfA, 20808.641003022261},
+			{kPinDfA, 2106.5440939849238}, {kPinDfA, 15131.75750513302},
+			{kPinDfB, 1.18292861797764}, {kPinDfB, 4.1662750547697547}, {kPinDfB, 40.8711582872913}, {kPinDfB, 11.604529742360651},
+			{kPinDfB, 2.3707272057666411}, {kPinDfB, 0.41077609832706019}, {kPinDfB, 0.0975}, {kPinDfB, 5.8022648711803244},
+			{kPinDfB, 20.435579143645651}, {kPinDfB, 8.443521135358143}, {kPinDfB, 293.92471275850022}, {kPinDfB, 2.1065440939849238},
+			{kPinDfB, 20.808641003022259}, {kPinDfB, 0.59146430898881985}, {kPinDfB, 2.0831375273848769},
+			{kPinDfC, 0.6600742038144628}, {kPinDfC, 4.7414544115332831}, {kPinDfC, 0.1118494602519098}, {kPinDfC, 0.80343863413287053},
+			{kPinDfC, 0.59146430898882}, {kPinDfC, 2.0831375273848773}, {kPinDfC, 2.2990706749044238}, {kPinDfC, 1.1471739513016379},
+			{kPinDfC, 8.24039624751662}, {kPinDfC, 11.33189235811229},
+		};
+		return t[i];
+	}
+	static constexpr int kfind(unsigned grp, double lit)
+	{
+		for (int i = 0; i < kNK; i++)
+			if (kentry(i).grp == grp && (kentry(i).mag == lit || kentry(i).mag == -lit)) return i;
+		return -1;
+	}
+	template <int I>
+	struct KAt {
+		static_assert(I >= 0, "a constant of the segway's step that Segway::kentry does not list");
+		static constexpr int value = I;
+	};
+	struct Consts { double v[kNK]; TanhConsts th; };
+	template <unsigned PIN, int... I>
+	__device__ __forceinline__ static void fillConsts(Consts &k, std::integer_sequence<int, I...>)
+	{
+		((k.v[I] = vk<(PIN & kentry(I).grp) != 0>(kentry(I).mag)), ...);
+	}
+	template <unsigned PIN = 0>
+	__device__ __forceinline__ static Consts constants()
+	{
+		Consts k;
+		fillConsts<PIN>(k, std::make_integer_sequence<int, kNK>());
+		k.th = tanh_consts<(PIN & kPinTanh) != 0>();
+		return k;
+	}
+#define K_(G, lit) ((lit) < 0 ? -k.v[KAt<kfind(G, lit)>::value] : k.v[KAt<kfind(G, lit)>::value])
 	// :56-68  u = K (x + x_eq)
-	__device__ static void backupController(const DevOptions &, const double (&x)[NX], double (&u)[NU], double (&Du)[NU * NX])
+	__device__ static void backupController(const DevOptions &, const double (&x)[NX], double (&u)[NU], double (&Du)[NU * NX],
+	                                        const Consts &k = constants<0>())
 	{
 #pragma clang fp contract(on)
-		const double K0 = 44.7214, K1 = 44.6528, K2 = 150.1612, K3 = 37.6492;
-		u[0] = K0 * (0. + x[0]) + K1 * (0. + x[1]) + K2 * (-0.1383244254 + x[2]) + K3 * (0. + x[3]);
+		const double K0 = K_(kPinCtl, 44.7214), K1 = K_(kPinCtl, 44.6528), K2 = K_(kPinCtl, 150.1612), K3 = K_(kPinCtl, 37.6492);
+		// The example adds x_eq = (0, 0, -0.138.., 0) to every state.  `0. + x` differs from x for x = -0 only, which
+		// turns a product from -0 into +0; the third product is +0 whenever it is zero (a - a), and a sum that holds a +0
+		// or a nonzero term does not depend on the signs of its other zeros: same u, bit for bit, without the three adds.
+#if defined(__HIP_DEVICE_COMPILE__)
+		u[0] = K0 * x[0] + K1 * x[1] + K2 * (K_(kPinCtl, -0.1383244254) + x[2]) + K3 * x[3];
+#else
+		u[0] = K0 * (0. + x[0]) + K1 * (0. + x[1]) + K2 * (K_(kPinCtl, -0.1383244254) + x[2]) + K3 * (0. + x[3]);
+#endif
 		Du[0] = K0; Du[1] = K1; Du[2] = K2; Du[3] = K3;
 	}
 	struct Trig { double s1, c1, s2, c2; };
@@ -843,34 +965,35 @@ struct Segway {
 	// (fp contract(on) in the segway's functions: a multiply-add is fused where the SOURCE expression has one, never
 	// across statements -- hipcc's default also fuses across statements, by use counts that differ between the kernels
 	// these functions are inlined into; the two-role pass of k_tb.hip and the fused pass must give the same bits)
-	__device__ static Shared dynamicsT(const double (&X)[NX], const Trig &t, double (&f)[NX], double (&g)[NX * NU])
+	__device__ static Shared dynamicsT(const double (&X)[NX], const Trig &t, double (&f)[NX], double (&g)[NX * NU],
+	                                   const Consts &k = constants<0>())
 	{
 #pragma clang fp contract(on)
 		const double w2 = X[3] * X[3];
 		Shared h;
-		h.iden = rcp_newton((14.553176960783997 + -2.0831375273848773 * t.c2) + -0.59146430898882 * t.s2);
+		h.iden = rcp_newton((K_(kPinDyn, 14.553176960783997) + K_(kPinDyn, -2.0831375273848773) * t.c2) + K_(kPinDyn, -0.59146430898882) * t.s2);
 		f[0] = X[1];
-		f[1] = (w2 * (-0.33003710190723146 * t.c1 + 2.3707272057666411 * t.s1) +
-		        (5.8022648711803244 * t.c2 + -20.435579143645651 * t.s2)) * h.iden;
+		f[1] = (w2 * (K_(kPinDyn, -0.33003710190723146) * t.c1 + K_(kPinDyn, 2.3707272057666411) * t.s1) +
+		        (K_(kPinDyn, 5.8022648711803244) * t.c2 + K_(kPinDyn, -20.435579143645651) * t.s2)) * h.iden;
 		f[2] = X[3];
-		f[3] = h.iden * ((-40.918271887954823 * t.c1 + 293.92471275850022 * t.s1) +
-		                 w2 * (0.59146430898882 * t.c2 + -2.0831375273848769 * t.s2));
-		h.rg = rcp_newton(((8.3593271361634187 + -2.1243074194638587 * (t.c1 * t.c1)) +
-		                   -0.04116989207898096 * (t.s1 * t.s1)) + -0.29573215449441 * t.s2);
-		gainT(t, h, g);
+		f[3] = h.iden * ((K_(kPinDyn, -40.918271887954823) * t.c1 + K_(kPinDyn, 293.92471275850022) * t.s1) +
+		                 w2 * (K_(kPinDyn, 0.59146430898882) * t.c2 + K_(kPinDyn, -2.0831375273848769) * t.s2));
+		h.rg = rcp_newton(((K_(kPinRg, 8.3593271361634187) + K_(kPinRg, -2.1243074194638587) * (t.c1 * t.c1)) +
+		                   K_(kPinRg, -0.04116989207898096) * (t.s1 * t.s1)) + K_(kPinRg, -0.29573215449441) * t.s2);
+		gainT(t, h, g, k);
 		return h;
 	}
 	// the input gain from sin / cos and the two reciprocals (h.iden, h.rg in; h.gc, h.gs out): dynamicsT's own lines, on
 	// their own so that the Q role of the two-role pass (k_tb.hip) evaluates exactly them from the x role's record
-	__device__ static void gainT(const Trig &t, Shared &h, double (&g)[NX * NU])
+	__device__ static void gainT(const Trig &t, Shared &h, double (&g)[NX * NU], const Consts &k = constants<0>())
 	{
 #pragma clang fp contract(on)
 		g[0] = 0.0;
-		h.gc = 1.4575004011882324 * t.c1;
-		h.gs = 0.20290365220710288 * t.s1;
-		g[1] = 0.551244194154502 * ((4.1706936767483551 + h.gc) + h.gs) * h.rg;
+		h.gc = K_(kPinGain, 1.4575004011882324) * t.c1;
+		h.gs = K_(kPinGain, 0.20290365220710288) * t.s1;
+		g[1] = K_(kPinGain, 0.551244194154502) * ((K_(kPinGain, 4.1706936767483551) + h.gc) + h.gs) * h.rg;
 		g[2] = 0.0;
-		g[3] = -5.65378660671284 * ((2.0043013906215941 + h.gc) + h.gs) * h.iden;
+		g[3] = K_(kPinGain, -5.65378660671284) * ((K_(kPinGain, 2.0043013906215941) + h.gc) + h.gs) * h.iden;
 	}
 	__device__ static void dynamics(const DevOptions &, const double (&x)[NX], double (&f)[NX], double (&g)[NX * NU])
 	{
@@ -916,15 +1039,17 @@ struct Segway {
 	}
 	// the gradients from sin / cos, dynamicsT's shared terms and the two states they depend on (x[1], x[3])
 	static constexpr int kGradStates[2] = {1, 3};
+	// TANHV: `k` holds the constants of tanh's polynomial in vector registers (kPinTanh): three-address Horner steps
+	template <bool TANHV = false>
 	__device__ static void gradientsGiven(const double (&x)[NX], const Trig &t, const Shared &h, double (&Df)[NX * NX],
-	                                      double (&Dg)[NX * NU * NX])
+	                                      double (&Dg)[NX * NU * NX], const Consts &k = constants<0>())
 	{
 #pragma clang fp contract(on)
 		const double c1 = t.c1, s1 = t.s1, c2 = t.c2, s2 = t.s2;
 		const double w2 = x[3] * x[3];
-		const double th = tanh_abs_accurate(x[1] * 1000.0);
-		const double t25 = th * 15.13175750513302 - 40.918271887954823;
-		const double t26 = w2 * 3.3849959169972448 + th * 30.26351501026604;
+		const double th = tanh_abs_accurate<TANHV>(x[1] * 1000.0, k.th);
+		const double t25 = th * K_(kPinDfA, 15.13175750513302) - K_(kPinDfA, 40.918271887954823);
+		const double t26 = w2 * K_(kPinDfA, 3.3849959169972448) + th * K_(kPinDfA, 30.26351501026604);
 		// the example's t23 = 1 / (2.083.. c2 + 0.591.. s2 - 14.553..) and its d26 are the negatives of the two
 		// denominators above (same numbers, the last printed digit apart): one reciprocal each serves both
 		const double t23 = -h.iden, r26 = -h.rg;
@@ -933,34 +1058,35 @@ struct Segway {
 		Df[4] = 1.0;
 		// (th^2 K - K) terms as K (th^2 - 1): fewer operations and no cancellation between two rounded products
 		const double q = th * th - 1.0;
-		Df[5] = -t23 * q * ((8443.5211353581435 + 410.77609832706019 * s1) + 2950.692713500939 * c1);
-		Df[7] = t23 * q * ((20808.641003022261 + 2106.5440939849238 * s1) + 15131.75750513302 * c1);
+		Df[5] = -t23 * q * ((K_(kPinDfA, 8443.5211353581435) + K_(kPinDfA, 410.77609832706019) * s1) + K_(kPinDfA, 2950.692713500939) * c1);
+		Df[7] = t23 * q * ((K_(kPinDfA, 20808.641003022261) + K_(kPinDfA, 2106.5440939849238) * s1) + K_(kPinDfA, 15131.75750513302) * c1);
 		const double cth = c1 * th;
 		const double sth = s1 * th;
-		const double v = c2 * 1.18292861797764 - s2 * 4.1662750547697547;
+		const double v = c2 * K_(kPinDfB, 1.18292861797764) - s2 * K_(kPinDfB, 4.1662750547697547);
 		const double e3 = v * (t23 * t23);
-		Df[9] = t23 * ((((c2 * 40.8711582872913 + s2 * 11.604529742360651) - c1 * w2 * 2.3707272057666411) +
-		                cth * 0.41077609832706019) - s1 * t26 * 0.0975) -
-		        e3 * (((((c2 * -5.8022648711803244 + s2 * 20.435579143645651) + th * 8.443521135358143) -
-		                s1 * w2 * 2.3707272057666411) + sth * 0.41077609832706019) + c1 * t26 * 0.0975);
+		Df[9] = t23 * ((((c2 * K_(kPinDfB, 40.8711582872913) + s2 * K_(kPinDfB, 11.604529742360651)) - c1 * w2 * K_(kPinDfB, 2.3707272057666411)) +
+		                cth * K_(kPinDfB, 0.41077609832706019)) - s1 * t26 * K_(kPinDfB, 0.0975)) -
+		        e3 * (((((c2 * K_(kPinDfB, -5.8022648711803244) + s2 * K_(kPinDfB, 20.435579143645651)) + th * K_(kPinDfB, 8.443521135358143)) -
+		                s1 * w2 * K_(kPinDfB, 2.3707272057666411)) + sth * K_(kPinDfB, 0.41077609832706019)) + c1 * t26 * K_(kPinDfB, 0.0975));
 		const double wc = w2 * c2;
 		const double ws = w2 * s2;
-		Df[11] = t23 * ((((c1 * -293.92471275850022 - cth * 2.1065440939849238) + wc * 4.1662750547697547) +
-		                 ws * 1.18292861797764) + s1 * t25) +
-		         e3 * (((((s1 * 293.92471275850022 + th * 20.808641003022259) + wc * 0.59146430898881985) +
-		                 sth * 2.1065440939849238) - ws * 2.0831375273848769) + c1 * t25);
-		Df[13] = t23 * x[3] * (c1 * 0.6600742038144628 - s1 * 4.7414544115332831);
+		Df[11] = t23 * ((((c1 * K_(kPinDfB, -293.92471275850022) - cth * K_(kPinDfB, 2.1065440939849238)) + wc * K_(kPinDfB, 4.1662750547697547)) +
+		                 ws * K_(kPinDfB, 1.18292861797764)) + s1 * t25) +
+		         e3 * (((((s1 * K_(kPinDfB, 293.92471275850022) + th * K_(kPinDfB, 20.808641003022259)) + wc * K_(kPinDfB, 0.59146430898881985)) +
+		                 sth * K_(kPinDfB, 2.1065440939849238)) - ws * K_(kPinDfB, 2.0831375273848769)) + c1 * t25);
+		Df[13] = t23 * x[3] * (c1 * K_(kPinDfC, 0.6600742038144628) - s1 * K_(kPinDfC, 4.7414544115332831));
 		Df[14] = 1.0;
 		Df[15] = -t23 * x[3] * v;
 #pragma unroll
 		for (int i = 0; i < NX * NU * NX; i++) Dg[i] = 0.0;
 		// (c1 s1 = s2 / 2)
-		Dg[9] = -(c1 * 0.1118494602519098 - s1 * 0.80343863413287053) * r26 +
-		        (r26 * r26) * (c2 * 0.59146430898882 - s2 * 2.0831375273848773) *
-		            ((c1 * 0.80343863413287053 + s1 * 0.1118494602519098) + 2.2990706749044238);
-		Dg[11] = (c1 * 1.1471739513016379 - s1 * 8.24039624751662) * t23 -
-		         e3 * ((c1 * 8.24039624751662 + s1 * 1.1471739513016379) + 11.33189235811229);
+		Dg[9] = -(c1 * K_(kPinDfC, 0.1118494602519098) - s1 * K_(kPinDfC, 0.80343863413287053)) * r26 +
+		        (r26 * r26) * (c2 * K_(kPinDfC, 0.59146430898882) - s2 * K_(kPinDfC, 2.0831375273848773)) *
+		            ((c1 * K_(kPinDfC, 0.80343863413287053) + s1 * K_(kPinDfC, 0.1118494602519098)) + K_(kPinDfC, 2.2990706749044238));
+		Dg[11] = (c1 * K_(kPinDfC, 1.1471739513016379) - s1 * K_(kPinDfC, 8.24039624751662)) * t23 -
+		         e3 * ((c1 * K_(kPinDfC, 8.24039624751662) + s1 * K_(kPinDfC, 1.1471739513016379)) + K_(kPinDfC, 11.33189235811229));
 	}
+#undef K_
 };
 
 // ---------------------------------------------------------------------------------------------
