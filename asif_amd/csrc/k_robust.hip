@@ -59,8 +59,6 @@ __device__ __forceinline__ static void pendulum_point_lie(const DevOptions &o, c
 	}
 }
 
-constexpr int kRobustRedRows = 2 * ASIF_HIP_MAX_HALFPLANES; // reduced QP: 2 rows per half-plane
-
 // asif_hip_assemble_batch: the full rows the reference hands to updateA/updateb
 __global__ __launch_bounds__(64) void robust_rows_kernel(DevOptions o, FilterArgs a)
 {
@@ -100,10 +98,64 @@ __global__ __launch_bounds__(64) void robust_rows_kernel(DevOptions o, FilterArg
 	if (a.code) a.code[i] = 1;
 }
 
+// What ASIFrobust::filter reads of its options, and of its arguments: the policy's whole argument block (124 or 188
+// bytes + 72, next to the solver's 112) instead of the 2 KB DevOptions + FilterArgs.  With the big structure the
+// kernel fetched its options piecemeal -- 21 scalar loads in nine dependent groups, each a scalar-cache round trip for
+// a wave that has nothing else to run -- because the scalar file cannot hold what it does not know it will need; this
+// block arrives in three loads issued together.  MAXN: half-planes carried (4 when the set has no more: BASELINE's C5).
+template <int MAXN>
+struct RobustOpts {
+	double halfPlanes[2 * MAXN]; // {a0, a1}: 1 - a.x >= 0
+	double pMin, pMax, relaxCost, relaxLb, lb0, ub0, inf;
+	int nHalfPlanes;
+};
+struct RobustArgs {
+	int64_t ld;
+	const double *x, *udes;
+	double *uact, *relax;
+	int32_t *rc;
+	double *diag;
+	int ndiag;
+};
+
+// examples/InvertedPendulum_Robust.cpp:53-61 (InvertedPendulumRobust::safetySet) and pendulum_point_lie above on the
+// small block, every half-plane slot with a compile-time index (nothing here is addressed at run time: no scratch)
+template <int MAXN>
+__device__ __forceinline__ static void robust_rows_small(const RobustOpts<MAXN> &e, const double (&x)[2], double (&h)[MAXN],
+                                                         double (&fl)[MAXN], double (&gl)[MAXN], double (&gh)[MAXN])
+{
+	double d0[MAXN], d1[MAXN];
+#pragma unroll
+	for (int s = 0; s < MAXN; s++) {
+		h[s] = 1. - e.halfPlanes[2 * s] * x[0] - e.halfPlanes[2 * s + 1] * x[1];
+		d0[s] = -e.halfPlanes[2 * s];
+		d1[s] = -e.halfPlanes[2 * s + 1];
+	}
+	{
+#pragma clang fp contract(off)
+		const double f0 = (x[1] + x[1]) / 2;
+		const double xs = x[0] * 0.5 + x[0] * 0.5;
+		const double t = sin(xs);
+		const double f1 = (t + t) / 2;
+		const double gc = (e.pMax + e.pMin) / 2, gr = (e.pMax - e.pMin) / 2;
+#pragma unroll
+		for (int s = 0; s < MAXN; s++) {
+			const double c0 = (d0[s] + d0[s]) / 2, c1 = (d1[s] + d1[s]) / 2; // centres of AAF(interval(Dh))
+			const double cf = (0.0 + c0 * f0) + c1 * f1;
+			fl[s] = cf - 0.0;
+			const double cg = (0.0 + c0 * 0.0) + c1 * gc;
+			const double r = fabs(c1 * gr);
+			gl[s] = cg - r;
+			gh[s] = cg + r;
+		}
+	}
+}
+
+template <int MAXN>
 struct RobustPolicy {
 	int64_t B;
-	DevOptions o;
-	FilterArgs a;
+	RobustOpts<MAXN> e;
+	RobustArgs a;
 
 	// Fused: every lane of the group assembles the rows of its instance from the state (a dozen flops per
 	// half-plane, cheaper than staging them through HBM) and keeps its share.  Reduced row r = 2s + p is
@@ -111,17 +163,15 @@ struct RobustPolicy {
 	template <int NV, int NC, int G>
 	__device__ __forceinline__ void load(int64_t i, int g, QpLaneData<NV, (NC + G - 1) / G> &qp) const
 	{
-		// NC: kRobustRedRows, or half of it when the set has no more than half the half-planes (the launcher's choice:
-		// BASELINE's C5 has four of eight, and rows that are padding cost what real ones cost)
-		static_assert(NV == 2 && (NC == kRobustRedRows || NC == kRobustRedRows / 2) && (G == 2 || G == 4 || G == 8), "reduced robust QP");
-		using M = InvertedPendulumRobust;
-		constexpr int MAXNP = M::MAXNP, RPL = (NC + G - 1) / G, H = G / 2;
-		const int N = o.nHalfPlanes;
-		double x[2], h[MAXNP], Dh[MAXNP * 2], fl[MAXNP], fh[MAXNP], gl[MAXNP], gh[MAXNP];
+		// NC = 2 MAXN: the whole row budget, or half of it when the set has no more than half the half-planes (the
+		// launcher's choice: BASELINE's C5 has four of eight, and rows that are padding cost what real ones cost)
+		static_assert(NV == 2 && NC == 2 * MAXN && (G == 2 || G == 4 || G == 8), "reduced robust QP");
+		constexpr int RPL = (NC + G - 1) / G, H = G / 2;
+		const int N = e.nHalfPlanes;
+		double x[2], h[MAXN], fl[MAXN], gl[MAXN], gh[MAXN];
 		x[0] = a.x[i];
 		x[1] = a.x[a.ld + i];
-		M::safetySet(o, x, h, Dh);
-		pendulum_point_lie(o, x, Dh, N, fl, fh, gl, gh);
+		robust_rows_small<MAXN>(e, x, h, fl, gl, gh);
 		const bool hiRow = (g & 1) != 0;
 		const int sub = g >> 1;
 #pragma unroll
@@ -130,7 +180,7 @@ struct RobustPolicy {
 #pragma unroll
 			for (int q = 0; q < H; q++) {
 				const int s = H * k + q; // compile-time
-				if (s < MAXNP) {
+				if (s < MAXN) {
 					const bool pick = (q == sub) && (s < N);
 					lg = pick ? (hiRow ? gh[s] : gl[s]) : lg;
 					hs = pick ? h[s] : hs;
@@ -144,19 +194,19 @@ struct RobustPolicy {
 		}
 		// src/asif_robust.cpp:89-101,140-142 restricted to (u, delta)
 		qp.Hd[0] = 1.0;
-		qp.Hd[1] = o.relaxCost;
+		qp.Hd[1] = e.relaxCost;
 		qp.c[0] = -2.0 * a.udes[i];
-		qp.c[1] = -2.0 * o.relaxCost * o.relaxLb;
-		qp.lb[0] = o.lb[0];
-		qp.lb[1] = o.relaxLb;
-		qp.ub[0] = o.ub[0];
-		qp.ub[1] = o.inf;
+		qp.c[1] = -2.0 * e.relaxCost * e.relaxLb;
+		qp.lb[0] = e.lb0;
+		qp.lb[1] = e.relaxLb;
+		qp.ub[0] = e.ub0;
+		qp.ub[1] = e.inf;
 	}
 	template <int NV>
 	__device__ __forceinline__ void store(int64_t i, const double (&sol)[NV], int st, int it) const
 	{
 		if (st == kStatusSolved) {
-			a.uact[i] = fmin(fmax(sol[0], o.lb[0]), o.ub[0]);
+			a.uact[i] = fmin(fmax(sol[0], e.lb0), e.ub0);
 			a.relax[i] = sol[1];
 			a.rc[i] = ASIF_HIP_RC_OK;
 		} else {
@@ -166,6 +216,24 @@ struct RobustPolicy {
 	}
 };
 
+template <int MAXN>
+static RobustPolicy<MAXN> robust_policy(const DevOptions &o, const FilterArgs &a)
+{
+	RobustPolicy<MAXN> p = {};
+	p.B = a.B;
+	for (int k = 0; k < 2 * MAXN; k++) p.e.halfPlanes[k] = o.halfPlanes[k];
+	p.e.pMin = o.pMin;
+	p.e.pMax = o.pMax;
+	p.e.relaxCost = o.relaxCost;
+	p.e.relaxLb = o.relaxLb;
+	p.e.lb0 = o.lb[0];
+	p.e.ub0 = o.ub[0];
+	p.e.inf = o.inf;
+	p.e.nHalfPlanes = o.nHalfPlanes;
+	p.a = {a.ld, a.x, a.udes, a.uact, a.relax, a.rc, a.diag, a.ndiag};
+	return p;
+}
+
 int launch_robust_ip(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                      hipStream_t stream)
 {
@@ -174,15 +242,17 @@ int launch_robust_ip(const DevOptions &o, const asif_hip_solver &S, const Filter
 		hipLaunchKernelGGL(robust_rows_kernel, dim3(grid_for(a.B, 1, 64)), dim3(64), 0, stream, o, a);
 		return (int)hipGetLastError();
 	}
-	const RobustPolicy p = {a.B, o, a};
 	int G = S.lanes_per_qp;
 	if (G == 0) G = a.B >= 32768 ? 2 : (a.B >= 16384 ? 4 : 8); // enough lane groups for one wave on every SIMD
-	const bool half = 2 * o.nHalfPlanes <= kRobustRedRows / 2; // every real row fits half the row budget
+	constexpr int MAXNP = ASIF_HIP_MAX_HALFPLANES;
+	const bool half = o.nHalfPlanes <= MAXNP / 2; // every real row fits half the row budget
+	const RobustPolicy<MAXNP / 2> ph = robust_policy<MAXNP / 2>(o, a);
+	const RobustPolicy<MAXNP> pf = robust_policy<MAXNP>(o, a);
 	switch (G) {
 	// one Ruiz pass by default: these rows are well scaled and a second pass only costs finish rounds
-	case 2: return half ? launch_policy<2, kRobustRedRows / 2, 2>(S, p, stream, 1) : launch_policy<2, kRobustRedRows, 2>(S, p, stream, 1);
-	case 4: return half ? launch_policy<2, kRobustRedRows / 2, 4>(S, p, stream, 1) : launch_policy<2, kRobustRedRows, 4>(S, p, stream, 1);
-	case 8: return half ? launch_policy<2, kRobustRedRows / 2, 8>(S, p, stream, 1) : launch_policy<2, kRobustRedRows, 8>(S, p, stream, 1);
+	case 2: return half ? launch_policy<2, MAXNP, 2>(S, ph, stream, 1) : launch_policy<2, 2 * MAXNP, 2>(S, pf, stream, 1);
+	case 4: return half ? launch_policy<2, MAXNP, 4>(S, ph, stream, 1) : launch_policy<2, 2 * MAXNP, 4>(S, pf, stream, 1);
+	case 8: return half ? launch_policy<2, MAXNP, 8>(S, ph, stream, 1) : launch_policy<2, 2 * MAXNP, 8>(S, pf, stream, 1);
 	default: return ASIF_HIP_EINVAL;
 	}
 }
