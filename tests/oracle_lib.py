@@ -12,6 +12,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+# tests/test_sanitizers.py re-runs host cases with the builds of `make -C tests san` (address + undefined-behaviour
+# sanitizers): ASIF_SAN_DIR names their directory
+SAN_DIR = os.environ.get("ASIF_SAN_DIR")
+if SAN_DIR:
+    LIB_PATH = os.path.join(SAN_DIR, "liboracle_san.so")
 REF_LIB_PATH = os.path.join(ORACLE_DIR, "_ref", "libaffa_ref.so")
 
 MODEL_DI, MODEL_IP, MODEL_SEGWAY, MODEL_IP_ROBUST, MODEL_IP_TB = 0, 1, 2, 3, 4
@@ -91,6 +96,8 @@ OPS = dict(CONST=0, INTERVAL=1, ADD=2, SUB=3, MUL=4, DIV=5, INV=6, NEG=7, SCALE=
 
 def build(force=False):
     """Compile liboracle.so (gcc) and, when /root/reference is present, oracle/_ref."""
+    if SAN_DIR:
+        return  # the sanitizer build is made by tests/Makefile
     if force or not os.path.exists(LIB_PATH) or any(
             os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(LIB_PATH)
             for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))):
@@ -254,9 +261,9 @@ def rb_safety_lo(model, o, x):
 
 
 def rb_last_learning():
-    dh = np.zeros(4)
+    dh = np.zeros(4)  # OR_MAX_NX
     lf = C.c_double()
-    lg = np.zeros(1)
+    lg = np.zeros(2)  # OR_MAX_NU: the oracle copies the whole array (found by tests/test_sanitizers.py: this was one short)
     lib().or_rb_last_learning(_p(dh), C.byref(lf), _p(lg))
     return dh, lf.value, lg
 

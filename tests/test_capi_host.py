@@ -126,8 +126,11 @@ def test_create_multi_releases_everything_exactly_once(tmp_path):
     released once and only once (round 2 destroyed the handles twice when a stream could not be created)."""
     import subprocess
     so = str(tmp_path / "libmulti_own.so")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "asif_amd", "csrc"),
-                           os.path.join(ROOT, "tests", "host_multi_own_driver.cpp"), "-o", so])
+    if os.environ.get("ASIF_SAN_DIR"):  # tests/test_sanitizers.py: the build of `make -C tests san`
+        so = os.path.join(os.environ["ASIF_SAN_DIR"], "libmulti_own_san.so")
+    else:
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "asif_amd", "csrc"),
+                               os.path.join(ROOT, "tests", "host_multi_own_driver.cpp"), "-o", so])
     lib = C.CDLL(so)
     n = 4
     for fail_create, fail_stream in [(-1, -1)] + [(k, -1) for k in range(n)] + [(-1, k) for k in range(n)]:

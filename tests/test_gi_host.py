@@ -17,9 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def gi(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("gi") / "libgi_host.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                           "-I" + os.path.join(ROOT, "asif_amd", "csrc"),
-                           os.path.join(ROOT, "tests", "host_gi_driver.cpp"), "-o", so])
+    if os.environ.get("ASIF_SAN_DIR"):  # tests/test_sanitizers.py: the build of `make -C tests san`
+        so = os.path.join(os.environ["ASIF_SAN_DIR"], "libgi_host_san.so")
+    else:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                               "-I" + os.path.join(ROOT, "asif_amd", "csrc"),
+                               os.path.join(ROOT, "tests", "host_gi_driver.cpp"), "-o", so])
     lib = C.CDLL(so)
 
     def solve(nv, nc, Hd, c, A, b, lb, ub, be, max_steps=28):

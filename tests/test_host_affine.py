@@ -13,6 +13,8 @@ GOLD = os.path.join(ROOT, "tests", "golden", "affa_programs.json")
 
 
 def _build(tmp):
+    if os.environ.get("ASIF_SAN_DIR"):  # tests/test_sanitizers.py: the build of `make -C tests san`
+        return os.path.join(os.environ["ASIF_SAN_DIR"], "host_aaf_san")
     exe = os.path.join(tmp, "host_aaf")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off",
                            "-I" + os.path.join(ROOT, "asif_amd", "host", "include"),
