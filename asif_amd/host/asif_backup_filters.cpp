@@ -157,10 +157,10 @@ static uint32_t trajectoryLength(double T, double &dt, uint32_t npBTSS)
 // ================================================================================= ASIFimplicit
 ASIFimplicit::ASIFimplicit(const uint32_t nx, const uint32_t nu, const uint32_t npSS, const uint32_t npBS,
                            const uint32_t npBTSS, SetFn safetySet, SetFn backupSet, DynFn dynamics,
-                           DynGradFn dynamicsGradients, CtrlFn backupController, const QPSOLVER, const bool diagonalCost)
+                           DynGradFn dynamicsGradients, CtrlFn backupController, const QPSOLVER qpSolverType, const bool diagonalCost)
     : BackupLoopHost(false, nx, nu, npSS, safetySet, dynamics, dynamicsGradients, nullptr, backupController),
       hBackupEnd_(0.), hSafetyNow_(0.), nv_(nu + 2), npBS_(npBS), npBTSS_(npBTSS), npTC_(npBTSS * npSS + npBS),
-      backupSet_(backupSet), options_(), QPsolver_(new QPWrapperHip(nu + 2, npBTSS * npSS + npBS, diagonalCost)),
+      backupSet_(backupSet), options_(), QPsolver_(makeQPWrapper(qpSolverType, nu + 2, npBTSS * npSS + npBS, diagonalCost)),
       npBT_(0), H_(nv_ * nv_, 0.0), c_(nv_, 0.0), A_(npTC_ * nv_, 0.0), b_(npTC_, 0.0), lb_(nv_, 0.0), ub_(nv_, 0.0),
       batch_(nullptr)
 {
@@ -171,10 +171,10 @@ ASIFimplicit::ASIFimplicit(const uint32_t nx, const uint32_t nu, const uint32_t 
 
 ASIFimplicit::ASIFimplicit(const uint32_t nx, const uint32_t nu, const uint32_t npSS, const uint32_t npBS,
                            const uint32_t npBTSS, SetFn safetySet, SetFn backupSet, DynWithGradFn dynamicsWithGradient,
-                           CtrlFn backupController, const QPSOLVER, const bool diagonalCost)
+                           CtrlFn backupController, const QPSOLVER qpSolverType, const bool diagonalCost)
     : BackupLoopHost(true, nx, nu, npSS, safetySet, nullptr, nullptr, dynamicsWithGradient, backupController),
       hBackupEnd_(0.), hSafetyNow_(0.), nv_(nu + 2), npBS_(npBS), npBTSS_(npBTSS), npTC_(npBTSS * npSS + npBS),
-      backupSet_(backupSet), options_(), QPsolver_(new QPWrapperHip(nu + 2, npBTSS * npSS + npBS, diagonalCost)),
+      backupSet_(backupSet), options_(), QPsolver_(makeQPWrapper(qpSolverType, nu + 2, npBTSS * npSS + npBS, diagonalCost)),
       npBT_(0), H_(nv_ * nv_, 0.0), c_(nv_, 0.0), A_(npTC_ * nv_, 0.0), b_(npTC_, 0.0), lb_(nv_, 0.0), ub_(nv_, 0.0),
       batch_(nullptr)
 {
@@ -458,10 +458,10 @@ int32_t ASIFimplicit::filterBatch(int64_t B, const double x[], const double uDes
 // =============================================================================== ASIFimplicitTB
 ASIFimplicitTB::ASIFimplicitTB(const uint32_t nx, const uint32_t nu, const uint32_t npSS, const uint32_t npBTSS,
                                SetFn safetySet, SetHessFn backupSet, DynFn dynamics, DynGradFn dynamicsGradients,
-                               CtrlFn backupController, const QPSOLVER, const bool diagonalCost)
+                               CtrlFn backupController, const QPSOLVER qpSolverType, const bool diagonalCost)
     : BackupLoopHost(false, nx, nu, npSS, safetySet, dynamics, dynamicsGradients, nullptr, backupController), TTS_(0.),
       BTorthoBS_(0.), hBackupEnd_(0.), hSafetyNow_(0.), nv_(nu + 1), npBTSS_(npBTSS), npTC_(npBTSS * npSS + 2),
-      backupSet_(backupSet), options_(), QPsolver_(new QPWrapperHip(nu + 1, npBTSS * npSS + 2, diagonalCost)), npBT_(0),
+      backupSet_(backupSet), options_(), QPsolver_(makeQPWrapper(qpSolverType, nu + 1, npBTSS * npSS + 2, diagonalCost)), npBT_(0),
       afterUpdate_(false), H_(nv_ * nv_, 0.0), c_(nv_, 0.0), A_(npTC_ * nv_, 0.0), b_(npTC_, 0.0), lb_(nv_, 0.0),
       ub_(nv_, 0.0), batch_(nullptr)
 {
@@ -469,10 +469,10 @@ ASIFimplicitTB::ASIFimplicitTB(const uint32_t nx, const uint32_t nu, const uint3
 
 ASIFimplicitTB::ASIFimplicitTB(const uint32_t nx, const uint32_t nu, const uint32_t npSS, const uint32_t npBTSS,
                                SetFn safetySet, SetHessFn backupSet, DynWithGradFn dynamicsWithGradient,
-                               CtrlFn backupController, const QPSOLVER, const bool diagonalCost)
+                               CtrlFn backupController, const QPSOLVER qpSolverType, const bool diagonalCost)
     : BackupLoopHost(true, nx, nu, npSS, safetySet, nullptr, nullptr, dynamicsWithGradient, backupController), TTS_(0.),
       BTorthoBS_(0.), hBackupEnd_(0.), hSafetyNow_(0.), nv_(nu + 1), npBTSS_(npBTSS), npTC_(npBTSS * npSS + 2),
-      backupSet_(backupSet), options_(), QPsolver_(new QPWrapperHip(nu + 1, npBTSS * npSS + 2, diagonalCost)), npBT_(0),
+      backupSet_(backupSet), options_(), QPsolver_(makeQPWrapper(qpSolverType, nu + 1, npBTSS * npSS + 2, diagonalCost)), npBT_(0),
       afterUpdate_(false), H_(nv_ * nv_, 0.0), c_(nv_, 0.0), A_(npTC_ * nv_, 0.0), b_(npTC_, 0.0), lb_(nv_, 0.0),
       ub_(nv_, 0.0), batch_(nullptr)
 {

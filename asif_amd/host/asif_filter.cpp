@@ -17,8 +17,7 @@ ASIF::ASIF(const uint32_t nx, const uint32_t nu, const uint32_t npSS, SafetySetF
       A_(nc_ * nv_, 0.0), b_(nc_, 0.0), lb_(nv_, 0.0), ub_(nv_, 0.0), LfhUser_(nullptr), LghUser_(nullptr),
       batch_(nullptr), boundModel_(-1)
 {
-	(void)qpSolverType; // one solver in this build: the in-kernel ADMM
-	QPsolver_ = new QPWrapperHip(nv_, nc_, diagonalCost);
+	QPsolver_ = makeQPWrapper(qpSolverType, nv_, nc_, diagonalCost); // src/asif.cpp:36-48
 }
 
 ASIF::~ASIF(void)

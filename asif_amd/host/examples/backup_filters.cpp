@@ -87,8 +87,17 @@ struct HostModel {
 	}
 };
 
+static QPSOLVER g_solver = QPSOLVER::HIP; // `--solver host` anywhere on the command line: the single-agent QPs on the CPU
+
 int main(int argc, char **argv)
 {
+	for (int i = 1; i + 1 < argc; i++)
+		if (!std::strcmp(argv[i], "--solver")) {
+			if (!std::strcmp(argv[i + 1], "host")) g_solver = QPSOLVER::HOST;
+			for (int j = i; j + 2 < argc; j++) argv[j] = argv[j + 2];
+			argc -= 2;
+			break;
+		}
 	if (argc < 3) return 2;
 	const bool tb = !std::strncmp(argv[1], "tb", 2) && std::strncmp(argv[1], "tbdi", 4);
 	const long N = std::atol(argv[2]);
@@ -111,7 +120,7 @@ int main(int argc, char **argv)
 			opts.backTrajDt = 0.001;
 			opts.relaxReachLb = 5.0;
 			opts.relaxSafeLb = 10.0;
-			ASIF::ASIFimplicit flt(2, 1, 4, 1, 10, H::safetySet, H::backupSet3, H::dynamics, H::gradients, H::controller);
+			ASIF::ASIFimplicit flt(2, 1, 4, 1, 10, H::safetySet, H::backupSet3, H::dynamics, H::gradients, H::controller, g_solver);
 			if (flt.initialize(lb, ub, opts) != 1) return 3;
 			double x[2] = {0.1 + (double)run * 0.29, 0.0};
 			for (long i = 0; i < N; i++) {
@@ -128,7 +137,7 @@ int main(int argc, char **argv)
 			opts.backTrajDt = 0.01;
 			opts.relaxReachLb = 5.0;
 			opts.relaxSafeLb = 10.0;
-			ASIF::ASIFimplicit flt(2, 1, 4, 1, 4, H::safetySet, H::backupSet3, H::dynamicsWithGradient, H::controller);
+			ASIF::ASIFimplicit flt(2, 1, 4, 1, 4, H::safetySet, H::backupSet3, H::dynamicsWithGradient, H::controller, g_solver);
 			if (flt.initialize(lb, ub, opts) != 1) return 3;
 			opts.backTrajHorizon = 5.0;
 			double x[2] = {0.0, 0.0}, t = 0.0;
@@ -155,7 +164,7 @@ int main(int argc, char **argv)
 			opts.relaxTTS = 30.0;
 			opts.relaxMinOrtho = 60.0;
 			opts.backTrajMinOrtho = 0.001;
-			ASIF::ASIFimplicitTB flt(2, 1, 4, 4, H::safetySet, H::backupSet4, H::dynamics, H::gradients, H::controller);
+			ASIF::ASIFimplicitTB flt(2, 1, 4, 4, H::safetySet, H::backupSet4, H::dynamics, H::gradients, H::controller, g_solver);
 			if (flt.initialize(lb, ub, opts) != 1) return 3;
 			double x[2] = {-0.1 + (double)run * 0.2, 0.0};
 			for (long i = 0; i < N; i++) {
@@ -176,8 +185,10 @@ int main(int argc, char **argv)
 		opts.relaxSafeLb = 10.0;
 		opts.relaxTTS = 5.0;
 		opts.relaxMinOrtho = 5.0;
-		ASIF::ASIFimplicitTB flt(2, 1, 4, 4, H::safetySet, H::backupSet4, H::dynamicsWithGradient, H::controller);
-		if (flt.initialize(lb, ub, opts) != 1 || flt.bindDeviceModel(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_TB) != 0) return 3;
+		ASIF::ASIFimplicitTB flt(2, 1, 4, 4, H::safetySet, H::backupSet4, H::dynamicsWithGradient, H::controller, g_solver);
+		// (under `--solver host` the loops run without a device: nothing is bound and the batched last line is left out)
+		const bool noDevice = g_solver == QPSOLVER::HOST;
+		if (flt.initialize(lb, ub, opts) != 1 || (!noDevice && flt.bindDeviceModel(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_TB) != 0)) return 3;
 		if (!std::strcmp(argv[1], "tbdi-loop")) {
 			std::printf("i,x0,x1,uAct,relax,TTS,rc,updated\n");
 			const double dt = 0.001, tEnd = dt * (double)N; // the example runs N = 5000
@@ -198,6 +209,7 @@ int main(int argc, char **argv)
 				for (int k = 0; k < 2; k++) x[k] += dt * (f[k] + g[k] * ua[0]);
 				t += dt;
 			}
+			if (noDevice) return 0;
 			// the batched path after updateOptions(): the last state, as a batch of one
 			double ua[1] = {0.0}, rl[1] = {0.0};
 			int32_t rc = 0;
@@ -231,7 +243,7 @@ int main(int argc, char **argv)
 		opts.backTrajDt = 0.001;
 		opts.relaxReachLb = 5.0;
 		opts.relaxSafeLb = 10.0;
-		ASIF::ASIFimplicit flt(2, 1, 4, 1, 10, H::safetySet, H::backupSet3, H::dynamics, H::gradients, H::controller);
+		ASIF::ASIFimplicit flt(2, 1, 4, 1, 10, H::safetySet, H::backupSet3, H::dynamics, H::gradients, H::controller, g_solver);
 		if (flt.initialize(lb, ub, opts) != 1 || flt.bindDeviceModel(ASIF_HIP_MODEL_INVERTED_PENDULUM) != 0) return 3;
 		std::vector<double> bx(2 * N), bu(N), ba(N, 0.0), br(2 * N, 0.0);
 		std::vector<int32_t> brc(N, 0);
@@ -272,8 +284,8 @@ int main(int argc, char **argv)
 		opts.relaxTTS = 30.0;
 		opts.relaxMinOrtho = 60.0;
 		opts.backTrajMinOrtho = 0.001;
-		ASIF::ASIFimplicitTB flt(4, 1, 4, 4, H::safetySet, H::backupSet4, H::dynamics, H::gradients, H::controller);
-		if (flt.initialize(lb, ub, opts) != 1 || flt.bindDeviceModel(ASIF_HIP_MODEL_SEGWAY) != 0) return 3;
+		ASIF::ASIFimplicitTB flt(4, 1, 4, 4, H::safetySet, H::backupSet4, H::dynamics, H::gradients, H::controller, g_solver);
+		if (flt.initialize(lb, ub, opts) != 1 || (g_solver != QPSOLVER::HOST && flt.bindDeviceModel(ASIF_HIP_MODEL_SEGWAY) != 0)) return 3;
 		if (!std::strcmp(argv[1], "tb-loop")) {
 			// the closed loop of examples/segway_implicit_tb.cpp:236-275: from rest with uDes = 0, plant Euler at 1 ms,
 			// updateOptions(backTrajHorizon = 6) once t > tEnd / 2.  x0 is given a push (argv[3], pitch rate) so that the

@@ -4,6 +4,8 @@
 //   t,x,v,uDes,uAct,relax,rc
 // for the first `steps` steps (default 2500 = up to the updateOptions call at t > 2.5 s, after which
 // the reference's behaviour depends on OSQP internals: lb_relax = 6 > ub_relax = 5).
+// --solver host: the QP on the calling thread (ASIF::QPWrapperHost, `QPSOLVER::HOST`) -- BASELINE config 1 as written,
+// "CPU path, no GPU"; the default is the GPU plug-in (QPWrapperHip).
 // With --batch B it also runs B copies of the current state through filterBatch() at every 100th step
 // and checks they agree with the single-agent answer.  With --time every filter() call is clocked on the host and a
 // one-line JSON summary (median / mean / p99 microseconds per call) goes to stderr -- bench.py's `c1` entry.
@@ -46,12 +48,17 @@ int main(int argc, char **argv)
 	int steps = 2500;
 	long batch = 0;
 	bool timing = false;
+	QPSOLVER solver = QPSOLVER::HIP;
 	for (int i = 1; i < argc; i++) {
+		if (!std::strcmp(argv[i], "--solver") && i + 1 < argc) {
+			solver = !std::strcmp(argv[++i], "host") ? QPSOLVER::HOST : QPSOLVER::HIP;
+			continue;
+		}
 		if (!std::strcmp(argv[i], "--steps") && i + 1 < argc) steps = std::atoi(argv[++i]);
 		else if (!std::strcmp(argv[i], "--time")) timing = true;
 		else if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) batch = std::atol(argv[++i]);
 	}
-	ASIF::ASIF *asif = new ASIF::ASIF(nx, nu, npSS, safetySet, dynamics);
+	ASIF::ASIF *asif = new ASIF::ASIF(nx, nu, npSS, safetySet, dynamics, npSS, solver);
 	const int32_t ir = asif->initialize(lb, ub);
 	if (ir != 1) {
 		std::fprintf(stderr, "initialize failed: %d (%s)\n", ir, asif_hip_error_string(ir));

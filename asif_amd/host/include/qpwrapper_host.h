@@ -1,0 +1,54 @@
+// qpwrapper_host.h -- ASIF::QPWrapperHost: the solver plug-in slot filled on the HOST, for the single-agent filter()
+// of the two- and three-variable classes (BASELINE config 1 as written: examples/DoubleIntegrator.cpp on the CPU).
+//
+// solve() runs the product's own dual active-set method -- asif_amd/csrc/gi_small.hpp, the source the kernels run
+// with a lane group per QP, compiled here with one lane per QP -- on the calling thread: no launch, no
+// synchronisation (a batch of one through QPWrapperHip is 13-15 us of launch + sync for 0.3 us of arithmetic).
+// It is selected BY NAME (`QPSOLVER::HOST`); nothing falls back to it: QPWrapperHip without a device keeps failing
+// loudly, and the batched path (filterBatch, the C ABI) has no host solver at all.  Never the test oracle.
+//
+// Shapes: diagonal cost with positive curvature on every variable, nv <= 3, nc <= 64 -- class ASIF (nv 2),
+// ASIFimplicit / ASIFimplicitRB (nv 3, nc up to 64), ASIFimplicitTB (nv 2).  Anything else: initialize() returns
+// ASIF_HIP_EUNSUPPORTED (the classes' constructors hand such shapes to QPWrapperHip instead).
+// Statuses as QPWrapperOsqp::solve (src/qpwrapper_osqp.cpp:225-238): 1, or OSQP's raw value -- -3 primal infeasible;
+// -2 (max_iter) for non-finite data, as the device path, and for an instance the method leaves undecided (none on any
+// seeded workload: tests/test_gi_host.py).
+#pragma once
+#if __has_include("qpwrapper_abstract.h")
+#include "qpwrapper_abstract.h"
+#else
+#include "asif_qp_interface.h"
+#endif
+#include <vector>
+
+namespace ASIF {
+
+class QPWrapperHost : public QPWrapperAbstract {
+public:
+	static constexpr uint32_t kMaxNv = 3, kMaxNc = 64;
+	static bool supports(const uint32_t nv, const uint32_t nc, const bool diagonalCost)
+	{
+		return diagonalCost && nv >= 1 && nv <= kMaxNv && nc <= kMaxNc;
+	}
+
+	QPWrapperHost(const uint32_t nv, const uint32_t nc, const bool diagonalCost);
+	virtual ~QPWrapperHost(void);
+
+	virtual int32_t initialize(const double H[], const double c[], const double A[], const double b[],
+	                           const double lb[], const double ub[], const bool be[] = nullptr);
+	virtual int32_t updateCost(const double H[], const double c[]); // nullptr = unchanged; always 1
+	virtual int32_t updateA(const double A[]);
+	virtual int32_t updateb(const double b[]);
+	virtual int32_t updateBounds(const double lb[], const double ub[]);
+	virtual int32_t solve(void);
+	virtual int32_t getSolution(double sol[]);
+
+	int32_t lastSteps(void) const { return steps_; } // working-set changes of the last solve
+
+private:
+	std::vector<double> Hd_, c_, A_, b_, lb_, ub_, sol_;
+	int32_t status_, steps_;
+	bool ready_;
+};
+
+} // namespace ASIF

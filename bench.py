@@ -776,38 +776,56 @@ def compact(rec):
 
 
 def c1_single_agent(steps=2500):
-    """BASELINE.json configs[0]: the closed loop of examples/DoubleIntegrator.cpp:63-116 on the C++ mirror
-    (asif_amd/host/double_integrator: ASIF::ASIF + QPWrapperHip, one QP per control step on the GPU), timed per
-    filter() call by the program itself; beside it the oracle's OSQP-style restatement on one host core for the same
-    closed-loop states (what `CPU OSQP path` stands for here: OSQP itself is not in the image)."""
+    """BASELINE.json configs[0] ("single agent, CPU path, plumbing, no GPU"): the closed loop of
+    examples/DoubleIntegrator.cpp:63-116 on the C++ mirror (asif_amd/host/double_integrator), timed per filter() call by
+    the program itself, twice: with `QPSOLVER::HOST` (ASIF::QPWrapperHost: the product's dual active-set method on the
+    calling thread -- the config as written, and the headline of this entry) and with the default solver (QPWrapperHip:
+    one QP per control step on the GPU, launch + synchronisation).  Beside them the oracle's OSQP-style restatement on
+    one host core for the same closed-loop states (what `CPU OSQP path` stands for here: OSQP itself is not in the
+    image).  Both runs are checked step by step against the exact optimum on the states they were in."""
     import subprocess
     exe = os.path.join(ROOT, "asif_amd", "host", "double_integrator")
     try:
         if not os.path.exists(exe):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "asif_amd", "host"), "-s"])
-        out = subprocess.run([exe, "--steps", str(steps), "--time"], capture_output=True, text=True, timeout=300)
-        if out.returncode != 0:
-            return {"error": out.stderr[-300:]}
-        t = json.loads([l for l in out.stderr.strip().split("\n") if l.startswith("{")][-1])
-        rows = np.array([[float(v) for v in line.split(",")] for line in out.stdout.strip().split("\n")[1:]])
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
         O.build()
         model, variant = O.CONFIGS[2]
         o = O.default_options(model, variant)
-        xprev = np.vstack([[0.0, 0.0], rows[:-1, 1:3]])
         ud = np.ones((steps, 1))
-        ue, _, rce = O.filter_batch(model, variant, o, xprev, ud, O.SOLVER_EXACT)
+
+        def run(solver):
+            out = subprocess.run([exe, "--steps", str(steps), "--time", "--solver", solver], capture_output=True, text=True,
+                                 timeout=300)
+            if out.returncode != 0:
+                return {"error": out.stderr[-300:]}, None
+            t = json.loads([l for l in out.stderr.strip().split("\n") if l.startswith("{")][-1])
+            rows = np.array([[float(v) for v in line.split(",")] for line in out.stdout.strip().split("\n")[1:]])
+            xprev = np.vstack([[0.0, 0.0], rows[:-1, 1:3]])
+            ue, _, rce = O.filter_batch(model, variant, o, xprev, ud, O.SOLVER_EXACT)
+            return {"us_per_filter_median": t["median_us"], "us_per_filter_mean": t["mean_us"], "us_per_filter_p99": t["p99_us"],
+                    "rc_mismatches_vs_exact": int((rows[:, 6].astype(int) != rce).sum()),
+                    "max_abs_u_err_vs_exact": float(np.abs(rows[:, 4] - ue[:, 0]).max())}, (rows, xprev)
+
+        host, hr = run("host")
+        hip, _ = run("hip")
+        if hr is None:
+            return {"error": host.get("error")}
+        rows, xprev = hr
         t0 = time.perf_counter()
         ua, _, rca = O.filter_batch(model, variant, o, xprev, ud, O.SOLVER_ADMM, None, 1)
         cpu_us = (time.perf_counter() - t0) / steps * 1e6
         return {"workload": "C1 examples/DoubleIntegrator.cpp closed loop, single agent, first 2500 steps "
-                            "(asif_amd/host/double_integrator: ASIF::ASIF::filter through QPWrapperHip)",
-                "us_per_filter_single_agent": t["median_us"], "us_per_filter_mean": t["mean_us"],
-                "us_per_filter_p99": t["p99_us"], "steps": steps,
+                            "(asif_amd/host/double_integrator: ASIF::ASIF::filter, QPSOLVER::HOST = ASIF::QPWrapperHost, the "
+                            "product's dual active-set method on the calling thread, no GPU)",
+                "us_per_filter_single_agent": host["us_per_filter_median"], "us_per_filter_mean": host["us_per_filter_mean"],
+                "us_per_filter_p99": host["us_per_filter_p99"], "steps": steps,
+                "rc_mismatches_vs_exact": host["rc_mismatches_vs_exact"],
+                "max_abs_u_err_vs_exact": host["max_abs_u_err_vs_exact"],
+                "through_the_gpu_solver": dict(hip, solver="QPWrapperHip (default QPSOLVER): one launch + synchronisation per "
+                                                          "control step"),
                 "cpu_us": cpu_us, "cpu_kind": "port: oracle's OSQP-style ADMM restatement, one host core, cold start per step",
-                "rc_mismatches_vs_exact": int((rows[:, 6].astype(int) != rce).sum()),
-                "max_abs_u_err_vs_exact": float(np.abs(rows[:, 4] - ue[:, 0]).max()),
                 "osqp_like_envelope": float(np.abs(rows[:, 4] - ua[:, 0])[rca == 1].max())}
     except Exception as e:  # the line must still be printed
         return {"error": repr(e)[:300]}
@@ -830,7 +848,8 @@ def main():
                     help="asif_hip_solver.polish: 0 pure ADMM, 1 active-set finish at the checks, 2 (library default) also "
                          "once before the first iteration")
     ap.add_argument("--presolve", type=int, default=0,
-                    help="asif_hip_solver.presolve (config 2: closed-form clip instead of the in-kernel ADMM; default 0)")
+                    help="asif_hip_solver.presolve (config 2: pinned variables eliminated and a one-variable closed form under polish "
+                         "0 / 1 too -- the default mode, polish 2, takes that light kernel anyway; default 0)")
     ap.add_argument("--graph", type=int, default=-1,
                     help="0: K direct launches; 1: the K timed launches are captured into one HIP graph (before the timed "
                          "region) and replayed once inside it -- same K launches, same arguments, same stream order; "

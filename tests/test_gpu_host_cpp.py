@@ -16,11 +16,19 @@ HOST = os.path.join(ROOT, "asif_amd", "host")
 
 
 def test_double_integrator_closed_loop(hip, oracle):
+    check_double_integrator_closed_loop(oracle, "hip")
+
+
+# The closed-loop checks below take the solver the program is run with: "hip" (QPWrapperHip, the tests of this file) or
+# "host" (QPWrapperHost, `--solver host`: no device anywhere in the program; tests/test_host_solver_cpp.py runs them in
+# the GPU-less container).
+def check_double_integrator_closed_loop(oracle, solver):
     exe = os.path.join(HOST, "double_integrator")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", HOST, "-s"])
     steps = 2500
-    out = subprocess.run([exe, "--steps", str(steps), "--batch", "256"], capture_output=True, text=True, timeout=600)
+    extra = ["--batch", "256"] if solver == "hip" else ["--solver", "host"]
+    out = subprocess.run([exe, "--steps", str(steps)] + extra, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = np.array([[float(v) for v in line.split(",")] for line in out.stdout.strip().split("\n")[1:]])
     assert rows.shape == (steps, 7)
@@ -47,11 +55,12 @@ def test_double_integrator_closed_loop(hip, oracle):
     assert rows[:, 4].min() < 0.0 and rows[:, 1].max() < 1.0 + 1e-6
 
 
-def _run_backup(kind, n, *extra):
+def _run_backup(kind, n, *extra, solver="hip"):
     exe = os.path.join(HOST, "backup_filters")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", HOST, "-s"])
-    out = subprocess.run([exe, kind, str(n)] + [str(e) for e in extra], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([exe, kind, str(n)] + [str(e) for e in extra] + (["--solver", "host"] if solver == "host" else []),
+                         capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     return np.array([[float(v) for v in line.split(",")] for line in out.stdout.strip().split("\n")[1:]])
 
@@ -104,6 +113,10 @@ def test_tb_class_single_agent_and_batch(hip, oracle):
 
 
 def test_segway_tb_closed_loop(hip, oracle):
+    check_segway_tb_closed_loop(oracle, "hip")
+
+
+def check_segway_tb_closed_loop(oracle, solver):
     """BASELINE config 4's example loop (examples/segway_implicit_tb.cpp:236-275) through the C++ class, literally: from
     rest, uDes = 0, plant Euler at 1 ms, updateOptions(backTrajHorizon = 6) at half time (1 600 of the example's 10 990
     steps).  Rest is not an equilibrium of the model (the pitch's is 0.138 rad): the agent drifts out of the backup set
@@ -111,7 +124,7 @@ def test_segway_tb_closed_loop(hip, oracle):
     the state the program was in (or the saturated backup controller where the reference applies it), with the options
     in force: 316 samples before the update, 601 after (no 1 + backTrajExtend, src/asif_implicit_tb.cpp:377)."""
     steps = 1600
-    rows = _run_backup("tb-loop", steps)
+    rows = _run_backup("tb-loop", steps, solver=solver)
     assert rows.shape == (steps, 10)
     upd = rows[:, 9].astype(int)
     first = int(np.argmax(upd))
@@ -136,12 +149,16 @@ def test_segway_tb_closed_loop(hip, oracle):
 
 @pytest.mark.parametrize("kind,cfg,steps,run", [("implicit-loop", 3, 300, 5), ("dii-loop", 9, 1200, 0), ("tbip-loop", 8, 160, 1)])
 def test_remaining_example_loops_step_by_step(hip, oracle, kind, cfg, steps, run):
+    check_example_loop_step_by_step(oracle, kind, cfg, steps, run, "hip")
+
+
+def check_example_loop_step_by_step(oracle, kind, cfg, steps, run, solver):
     """The main() loops of examples/InvertedPendulum_Implicit.cpp (run 5 of its ten start states),
     examples/DoubleIntegrator_implicit.cpp (fused-gradient constructor, updateOptions(backTrajHorizon = 5) at half time)
     and examples/InvertedPendulum_ImplicitTB.cpp (its second start state) through the C++ classes: every step's input is
     the exact optimum of the QP the reference assembles on the state the program was in, rc identical, and the plant
     step is the example's."""
-    rows = _run_backup(kind, steps, run)
+    rows = _run_backup(kind, steps, run, solver=solver)
     assert rows.shape == (steps, 8)
     model, variant = oracle.CONFIGS[cfg]
     x = np.ascontiguousarray(rows[:, 1:3])
@@ -182,17 +199,23 @@ def test_tb_class_double_integrator_single_agent_and_batch(hip, oracle):
 
 
 def test_double_integrator_tb_closed_loop(hip, oracle):
+    check_double_integrator_tb_closed_loop(oracle, "hip")
+
+
+def check_double_integrator_tb_closed_loop(oracle, solver, steps=5000):
     """The example's own loop (examples/DoubleIntegrator_implicit_tb.cpp:105-160): 5 000 control steps from (0.1, 0.1)
     with uDes = 0.9, updateOptions(backTrajHorizon = 7) once t > 2.5 s.  Per step, on the state the program was in, the
     input must be the exact optimum of the QP the reference assembles with the options in force (after the update the
     trajectory has 7 001 samples: the (1 + backTrajExtend) factor is dropped, src/asif_implicit_tb.cpp:377)."""
-    steps = 5000
-    rows = _run_backup("tbdi-loop", steps)
-    assert rows.shape == (steps + 1, 8)
-    batch_row, rows = rows[-1], rows[:-1]
+    rows = _run_backup("tbdi-loop", steps, solver=solver)
+    batch_row = None
+    if solver == "hip":  # the program's last line: filterBatch() on the final state
+        assert rows.shape == (steps + 1, 8)
+        batch_row, rows = rows[-1], rows[:-1]
+    assert rows.shape == (steps, 8)
     upd = rows[:, 7].astype(int)
     first = int(np.argmax(upd))
-    assert 2499 <= first <= 2502 and np.all(upd[first:] == 1) and np.all(upd[:first] == 0)
+    assert steps // 2 - 1 <= first <= steps // 2 + 2 and np.all(upd[first:] == 1) and np.all(upd[:first] == 0)
     model, variant = oracle.CONFIGS[12]
     o1 = oracle.default_options(model, variant)
     o2 = oracle.default_options(model, variant)
@@ -212,9 +235,9 @@ def test_double_integrator_tb_closed_loop(hip, oracle):
     # the plant step of the example, reproduced from its own inputs
     xn = x[:-1] + 0.001 * np.stack([x[:-1, 1], rows[:-1, 3]], axis=1)
     assert np.abs(xn - x[1:]).max() <= 1e-15
-    # filterBatch() on the state after the last step, options as updated
-    a, _, r = oracle.filter_batch(model, variant, o2, batch_row[None, 1:3], np.array([[0.9]]), oracle.SOLVER_EXACT)
-    assert int(batch_row[6]) == r[0] and abs(batch_row[3] - a[0, 0]) <= 1e-6
+    if batch_row is not None:  # filterBatch() on the state after the last step, options as updated
+        a, _, r = oracle.filter_batch(model, variant, o2, batch_row[None, 1:3], np.array([[0.9]]), oracle.SOLVER_EXACT)
+        assert int(batch_row[6]) == r[0] and abs(batch_row[3] - a[0, 0]) <= 1e-6
 
 
 def test_robust_class_single_agent_and_batch(hip, oracle):

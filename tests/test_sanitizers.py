@@ -1,7 +1,8 @@
 """The suite's host-side native code under AddressSanitizer + UndefinedBehaviorSanitizer (SURVEY.md section 5, row
 "host tests under -fsanitize=address,undefined"): `make -C tests san` builds the CPU oracle (oracle/*.c), the product's
 dual active-set solver compiled for the host (asif_amd/csrc/gi_small.hpp behind tests/host_gi_driver.cpp), the
-multi-device ownership rules (multi_own.hpp) and the mirror's host affine arithmetic (asif_affine.h) with
+multi-device ownership rules (multi_own.hpp), the mirror's host affine arithmetic (asif_affine.h) and the mirror's
+classes themselves (asif_amd/host/*.cpp behind the example programs, run with `--solver host`) with
 -fsanitize=address,undefined -fno-sanitize-recover=all, and the existing host cases run on those builds in a child
 python with the sanitizer runtimes preloaded.  CPU build only: never on the GPU box (not a gpu test; GPU
 AddressSanitizer is not available on the pool).
@@ -61,3 +62,17 @@ def test_host_native_code_is_clean_under_asan_and_ubsan(tmp_path):
     assert not reports, "sanitizer report:\n" + text
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+    # the mirror's classes (asif_amd/host/*.cpp: the host Euler loop with its sensitivity, the critical-sample selection,
+    # the TB rows) and QPWrapperHost behind the example programs, `--solver host`: no device anywhere in the run
+    env2 = {k: v for k, v in env.items() if k != "LD_PRELOAD"}  # executables link their runtimes themselves
+    runs = [["double_integrator_san", "--solver", "host", "--steps", "600"],
+            ["backup_filters_san", "implicit-loop", "12", "5", "--solver", "host"],
+            ["backup_filters_san", "dii-loop", "400", "--solver", "host"],
+            ["backup_filters_san", "tbip-loop", "6", "1", "--solver", "host"],
+            ["backup_filters_san", "tb-loop", "300", "0.5", "--solver", "host"],
+            ["backup_filters_san", "tbdi-loop", "60", "--solver", "host"]]
+    for cmd in runs:
+        p = subprocess.run([os.path.join(SAN_DIR, cmd[0])] + cmd[1:], env=env2, capture_output=True, text=True, timeout=900)
+        reports = sorted(f for f in os.listdir(tmp_path) if f.startswith(("asan", "ubsan")))
+        assert not reports, "sanitizer report in " + " ".join(cmd) + ":\n" + open(os.path.join(tmp_path, reports[0])).read()[:4000]
+        assert p.returncode == 0 and len(p.stdout.strip().split("\n")) >= 6, (cmd, p.returncode, p.stderr[-1000:])
