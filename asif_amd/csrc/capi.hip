@@ -196,6 +196,13 @@ extern "C" int asif_hip_default_solver(asif_hip_solver *s)
 	return ASIF_HIP_OK;
 }
 
+// Options::inf stands for "no bound" in the rows and bounds the classes write (relaxation upper bounds, the TB class's
+// inert rows b = -inf, src/asif_implicit_tb.cpp:727).  OSQP reads any magnitude from OSQP_INFTY = 1e30 on as exactly
+// that, so an infinite or huge value (options.inf = INFINITY, 1e300) is the same problem to the reference as 1e30;
+// here it is clamped to it, so that the kernels' domain check on the problem data (qp_lane.hpp: qp_data_nonfinite,
+// |entry| beyond 1.8e148 or not finite = the solver's max_iter verdict) does not take it for broken data.
+static double no_bound_value(double inf) { return inf > 1e30 ? 1e30 : inf; }
+
 static int model_dims(int model, int variant, const asif_hip_options &o, asif_hip_dims &d, DevOptions &dev,
                       bool after_update = false)
 {
@@ -210,7 +217,7 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 	dev.backTrajDt = o.backTrajDt;
 	dev.backTrajMinOrtho = o.backTrajMinOrtho;
 	dev.satSharpness = o.satSharpness;
-	dev.inf = o.inf;
+	dev.inf = no_bound_value(o.inf);
 	for (int i = 0; i < ASIF_HIP_MAX_NU; i++) {
 		dev.lb[i] = o.lb[i];
 		dev.ub[i] = o.ub[i];
@@ -227,7 +234,11 @@ static int model_dims(int model, int variant, const asif_hip_options &o, asif_hi
 		const double lo = std::ldexp(1.0, -100), hi = std::ldexp(1.0, 100);
 		const bool ok = o.satSharpness >= lo && o.satSharpness <= hi && dev.bevelStop >= lo && dev.bevelStop <= hi &&
 		                dev.bevelStart > 0 && dev.bevelStart < dev.bevelStop && std::isfinite(o.lb[0]) &&
-		                std::isfinite(o.ub[0]) && o.lb[0] < o.ub[0];
+		                std::isfinite(o.ub[0]) && o.lb[0] < o.ub[0] &&
+		                // the fast step takes the linear and the clamped region from ONE clamp of u to [lb, ub]: that is
+		                // the reference's select only while the thresholds stay clear of 1 by more than the rounding of
+		                // uc = (u - middle) 2/range (a sharpness of 1e-15 puts bevelStop an ulp above 1)
+		                dev.bevelStop - 1 > 1e-9 && 1 - dev.bevelStart > 1e-9;
 		dev.satFastOk = ok ? 1 : 0;
 		static const int bevel_free = []() { // developer switch: 0 off, 2 predicts with no margin at all (many repeated blocks)
 			const char *v = getenv("ASIF_HIP_BEVEL_FREE");
@@ -511,7 +522,7 @@ static int rz_configure(asif_hip_ctx *c, const asif_hip_realizable_options &o)
 	z.relaxDes = o.relaxDes;
 	z.relaxOffset = o.relaxOffset;
 	z.relaxCost = o.relaxCost;
-	z.inf = o.inf;
+	z.inf = no_bound_value(o.inf);
 	z.lb = o.lb[0];
 	z.ub = o.ub[0];
 	z.mMin = o.mMin;
@@ -682,7 +693,7 @@ static int rb_configure(asif_hip_ctx *c, const asif_hip_robust_data_options &o)
 	z.npSSmax = M;
 	z.relaxCost = o.relaxCost;
 	z.relaxLb = o.relaxLb;
-	z.inf = o.inf;
+	z.inf = no_bound_value(o.inf);
 	z.lb = o.lb[0];
 	z.ub = o.ub[0];
 	z.mMin = o.mMin;
@@ -1221,7 +1232,14 @@ extern "C" asif_hip_ctx *asif_hip_multi_handle(asif_hip_multi *m, int32_t i)
 
 extern "C" int asif_hip_multi_update_options(asif_hip_multi *m, const asif_hip_options *opts)
 {
-	if (!m) return ASIF_HIP_EINVAL;
+	if (!m || !opts) return ASIF_HIP_EINVAL;
+	// all or nothing: the options are checked against every handle before any handle takes them, so that a refusal
+	// leaves the blocks of one batch on ONE set of options (the check is host arithmetic; nothing below it can fail)
+	for (asif_hip_ctx *h : m->h) {
+		asif_hip_dims d;
+		DevOptions dev;
+		if (int r = model_dims(h->model, h->variant, *opts, d, dev, true)) return r;
+	}
 	for (asif_hip_ctx *h : m->h)
 		if (int r = asif_hip_update_options(h, opts)) return r;
 	return ASIF_HIP_OK;

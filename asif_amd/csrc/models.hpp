@@ -653,8 +653,12 @@ struct DoubleIntegratorTB : DoubleIntegratorImplicit {
 	// gains nothing from eight or sixteen copies)
 	static constexpr bool kTbUnrollWholeBlock = true;
 	// :41-57  h = Pv^2 - sum_ij P_ij x_i x_j in the example's loop order, Dh = mPpPt x, DDh = mPpPt
+	// (fp contract(off) in these two: every product and difference separately rounded, as the reference's loop and the
+	// oracle have them, in whatever kernel they are inlined into -- hipcc's default fuses by use counts that differ between
+	// the Euler pass, the dopri5 kernel and the rows; the sign of this value picks the hit sample)
 	__device__ static double backupSetValue(const DevOptions &, const double (&x)[NX])
 	{
+#pragma clang fp contract(off)
 		double v = 0.01 * 0.01;
 		v -= 1.0 * x[0] * x[0];
 		v -= 0.0 * x[0] * x[1];
@@ -666,6 +670,7 @@ struct DoubleIntegratorTB : DoubleIntegratorImplicit {
 	__device__ static void backupSet(const DevOptions &o, const double (&x)[NX], double &h, double (&Dh)[NX],
 	                                 double (&DDh)[NX * NX])
 	{
+#pragma clang fp contract(off)
 		h = backupSetValue(o, x);
 		Dh[0] = (0.0 + -2.0 * x[0]) + 0.0 * x[1];
 		Dh[1] = (0.0 + 0.0 * x[0]) + -2.0 * x[1];

@@ -117,8 +117,10 @@ int32_t ASIF::updateOptions(void)
 	QPsolver_->updateCost(H_.data(), c_.data());
 	if (batch_) {
 		asif_hip_options o;
-		if (int r = deviceOptions(boundModel_, &o)) return r;
-		if (int r = asif_hip_multi_update_options(batch_, &o)) return r;
+		// failures come back as negative library codes; success is the reference's 1, so a positive code (a hipError_t
+		// passed through) must not be handed on as it is
+		if (int r = deviceOptions(boundModel_, &o)) return r > 0 ? ASIF_HIP_EINVAL : r;
+		if (int r = asif_hip_multi_update_options(batch_, &o)) return r > 0 ? ASIF_HIP_EINVAL : r;
 	}
 	return 1;
 }

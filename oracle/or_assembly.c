@@ -698,7 +698,7 @@ static int assemble_implicit(const or_model *m, const or_options *o, const doubl
 static void assemble_tb_trivial(const or_options *o, int nTC, int nv, double *A, double *b, double *diag)
 {
 	for (int i = 0; i < nTC * nv; i++) A[i] = 0.0;
-	for (int i = 0; i < nTC; i++) b[i] = -o->inf;
+	for (int i = 0; i < nTC; i++) b[i] = -or_no_bound(o->inf);
 	if (diag) {
 		diag[0] = 0.0; /* TTS_ */
 		diag[1] = 1.0; /* BTorthoBS_ */
@@ -947,20 +947,20 @@ void or_qp_static(int model, int variant, const or_options *o, const double *uDe
 		c[nu + 1] = -2.0 * o->relaxCost * o->relaxReachLb;
 		lb[nu] = o->relaxLb;
 		lb[nu + 1] = o->relaxReachLb;
-		ub[nu] = ub[nu + 1] = o->inf;
+		ub[nu] = ub[nu + 1] = or_no_bound(o->inf);
 		break;
 	case OR_VARIANT_IMPLICIT_TB:
 		Hd[nu] = o->relaxCost;
 		c[nu] = -2.0 * o->relaxCost * o->relaxLb;
 		lb[nu] = o->relaxLb;
-		ub[nu] = o->inf;
+		ub[nu] = or_no_bound(o->inf);
 		break;
 	case OR_VARIANT_ROBUST:
 		Hd[nu] = o->relaxCost;
 		c[nu] = -2.0 * o->relaxCost * o->relaxLb;
 		lb[nu] = o->relaxLb;
-		ub[nu] = o->inf;
-		for (int i = nu + 1; i < d.nv; i++) { lb[i] = 0.0; ub[i] = o->inf; }
+		ub[nu] = or_no_bound(o->inf);
+		for (int i = nu + 1; i < d.nv; i++) { lb[i] = 0.0; ub[i] = or_no_bound(o->inf); }
 		for (int i = 0; i < d.nc; i++) be[i] = (i % (nu + 2)) != 0;
 		break;
 	}

@@ -27,6 +27,11 @@ typedef struct {
 
 const or_model *or_model_get(int id);
 
+/* Options::inf as the solver reads it: OSQP takes any magnitude from OSQP_INFTY = 1e30 on for "no bound", so an
+ * infinite or huge Options::inf (the TB class's inert rows b = -inf, src/asif_implicit_tb.cpp:727, the relaxation upper
+ * bounds) is the same problem to the reference as 1e30 -- the value the exact solver, which has no such notion, is handed */
+static inline double or_no_bound(double inf) { return inf > 1e30 ? 1e30 : inf; }
+
 void or_matvec(const double *A, int nl, int ncol, const double *b, double *Ab);
 void or_matmul(const double *A, int nlA, int ncA, const double *B, int ncB, double *AB);
 double or_vecnorm(const double *v, int len);

@@ -317,7 +317,7 @@ void or_rz_qp_static(const or_rz *z, const double *uDes, double *Hd, double *c, 
 		Hd[i] = 0.0;
 		c[i] = 0.0;
 		lb[i] = 0.0;
-		ub[i] = z->d.inf;
+		ub[i] = or_no_bound(z->d.inf);
 	}
 	Hd[0] = 1.0;
 	if (z->d.npSSmax > 0) Hd[nv - 1] = z->d.relaxCost;
@@ -350,7 +350,7 @@ static int rz_exact(const or_rz *z, const double *A, const double *b, const doub
 	double x2[2];
 	if (npSSmax > 0) {
 		const double Hd[2] = {1.0, z->d.relaxCost}, c[2] = {-2.0 * uDes[0], 0.0};
-		const double lb[2] = {z->d.lb[0], 0.0}, ub[2] = {z->d.ub[0], z->d.inf};
+		const double lb[2] = {z->d.lb[0], 0.0}, ub[2] = {z->d.ub[0], or_no_bound(z->d.inf)};
 		or_qp q = {2, nr, Hd, c, A2, b2, lb, ub, 0};
 		r = or_qp_exact_small(&q, x2);
 	} else {

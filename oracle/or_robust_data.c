@@ -171,7 +171,7 @@ void or_rb_qp_static(const or_rb *z, const double *uDes, double *Hd, double *c, 
 		Hd[i] = 0.0;
 		c[i] = 0.0;
 		lb[i] = 0.0;
-		ub[i] = z->d.inf;
+		ub[i] = or_no_bound(z->d.inf);
 	}
 	Hd[0] = 1.0;
 	Hd[1] = z->d.relaxCost;
@@ -199,7 +199,7 @@ static int rb_exact(const or_rb *z, const double *A, const double *uDes, double 
 		b2[2 * s + 1] = -lo_f;
 	}
 	const double Hd[2] = {1.0, z->d.relaxCost}, c[2] = {-2.0 * uDes[0], -2.0 * z->d.relaxCost * z->d.relaxLb};
-	const double lb[2] = {z->d.lb[0], z->d.relaxLb}, ub[2] = {z->d.ub[0], z->d.inf};
+	const double lb[2] = {z->d.lb[0], z->d.relaxLb}, ub[2] = {z->d.ub[0], or_no_bound(z->d.inf)};
 	or_qp q = {2, nr, Hd, c, A2, b2, lb, ub, 0};
 	double x2[2];
 	const int r = or_qp_exact_small(&q, x2);

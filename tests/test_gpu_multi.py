@@ -27,7 +27,9 @@ def _host_single(hip, cfg, x, udes, uact0, relax0):
     return uact, relax, rc
 
 
-@pytest.mark.parametrize("cfg,B,ndev", [(2, 65536, 2), (2, 10007, 3), (4, 4099, 4), (3, 130, 2)])
+# (4, 262144, 8): BASELINE configs[3] itself -- 262 144 segway agents in 8 blocks of 32 768, the split an 8-GPU node
+# takes (here: eight handles, host threads and streams on device 0)
+@pytest.mark.parametrize("cfg,B,ndev", [(2, 65536, 2), (2, 10007, 3), (4, 4099, 4), (3, 130, 2), (4, 262144, 8)])
 def test_multi_equals_single_bitwise(hip, cfg, B, ndev):
     x, udes = workloads.make_batch(cfg, B)
     x, udes = np.ascontiguousarray(x), np.ascontiguousarray(udes)
@@ -83,3 +85,35 @@ def test_page_locked_buffers_take_the_zero_copy_path(hip, cfg, B, ndev):
     m.filter_host(tx.numpy(), tu.numpy(), ua.numpy(), rl.numpy(), rc.numpy())
     m.close()
     assert np.array_equal(rc.numpy(), rc1) and np.array_equal(ua.numpy(), ua1) and np.array_equal(rl.numpy(), rl1)
+
+
+def test_multi_update_options_is_all_or_nothing(hip):
+    """asif_hip_multi_update_options checks the options against every handle before any handle takes them:
+    refused options leave all blocks of the batch on the old ones; accepted options reach all of them."""
+    import ctypes as C
+    B = 3000
+    x, udes = workloads.make_batch(2, B)
+    x, udes = np.ascontiguousarray(x), np.ascontiguousarray(udes)
+    m = hip.MultiFilter(hip.MODEL_DOUBLE_INTEGRATOR, hip.EXPLICIT, [0, 0, 0])
+
+    def run():
+        ua, rl, rc = np.full((1, B), 7.0), np.full((1, B), -7.0), np.zeros(B, dtype=np.int32)
+        m.filter_host(x, udes, ua, rl, rc)
+        return ua, rl, rc
+
+    before = run()
+    bad = hip.default_options(hip.MODEL_DOUBLE_INTEGRATOR, hip.EXPLICIT)
+    bad.relaxLb = 2.0
+    bad.integrator = 2  # no such integrator: EINVAL
+    assert m.lib.asif_hip_multi_update_options(m.handle, C.byref(bad)) < 0
+    after_bad = run()
+    assert all(np.array_equal(a, b) for a, b in zip(before, after_bad))
+    good = hip.default_options(hip.MODEL_DOUBLE_INTEGRATOR, hip.EXPLICIT)
+    good.relaxLb = 2.0
+    assert m.lib.asif_hip_multi_update_options(m.handle, C.byref(good)) == 0
+    ua, rl, rc = run()
+    ok = rc == 1
+    assert ok.sum() > 100 and np.all(rl[0, ok] == 2.0)  # the pinned relaxation variable of every block moved
+    single = hip.Filter(hip.MODEL_DOUBLE_INTEGRATOR, hip.EXPLICIT, options=good)
+    single.close()
+    m.close()

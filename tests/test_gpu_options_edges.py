@@ -76,6 +76,17 @@ def _with_options(hip, oracle, cfg, **kw):
     # sin / cos accept (kTrigCarryMaxStep) -- those blocks are repeated on the generic step, the others stay on the fast one
     (3, 192, dict(backTrajHorizon=2.0, backTrajDt=0.04)),
     (8, 96, dict(backTrajHorizon=2.0, backTrajDt=0.04)),
+    # Options::inf beyond OSQP's own infinity (1e30): "no bound" to the reference whatever its size -- the TB class's
+    # inert rows (b = -inf) and the relaxation's upper bounds must not read as broken data: instances
+    # inside the backup set keep rc 2 with u = clamp(uDes)
+    (4, 1024, dict(inf=float("inf"))),
+    (4, 1024, dict(inf=1e300)),
+    (3, 64, dict(inf=float("inf"))),
+    (2, 1024, dict(inf=float("inf"))),
+    (5, 512, dict(inf=1e300)),
+    # a sharpness whose bevelStop sits within rounding of 1: not the fast step's clamp, the generic chain
+    (3, 96, dict(satSharpness=3e-15, backTrajHorizon=0.75, backTrajDt=0.005)),
+    (12, 256, dict(satSharpness=1e-12, backTrajHorizon=1.0)),
 ])
 def test_non_default_options(hip, oracle, cfg, B, kw):
     o, oo = _with_options(hip, oracle, cfg, **kw)
@@ -87,6 +98,11 @@ def test_non_default_options(hip, oracle, cfg, B, kw):
                                      uact_init=np.full((B, d.nu), 2.5))
     assert np.array_equal(out["rc"], rc), f"{(out['rc'] != rc).sum()} rc mismatches"
     assert np.abs(out["uact"].T - ua).max() <= 1e-6
+    if "inf" in kw and cfg == 4:
+        inside = rc == 2
+        assert inside.sum() > 100
+        lb, ub = oo.lb[0], oo.ub[0]
+        assert np.array_equal(out["uact"][0, inside], np.clip(out["udes"][0, inside], lb, ub))
 
 
 def test_update_options_and_tb_horizon_quirk(hip, oracle):
