@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void implicit_rows_kernel(DevOptions o_arg, Fi
 			const int row = k * NP + r;
 			a.A[(int64_t)(row + 0 * NC) * ld + i] = Lg;
 			a.A[(int64_t)(row + 1 * NC) * ld + i] = h[r];
-			a.A[(int64_t)(row + 2 * NC) * ld + i] = 0.0;
+			if (!a.compactRows) a.A[(int64_t)(row + 2 * NC) * ld + i] = 0.0; // (wave-uniform)
 			a.b[(int64_t)row * ld + i] = -Lf;
 		}
 		if (a.diag) a.diag[(int64_t)k * ld + i] = (double)sidx;
@@ -463,8 +463,12 @@ __global__ __launch_bounds__(256) void implicit_rows_kernel(DevOptions o_arg, Fi
 		}
 		const int row = K * NP;
 		a.A[(int64_t)(row + 0 * NC) * ld + i] = Lg;
-		a.A[(int64_t)(row + 1 * NC) * ld + i] = 0.0;
-		a.A[(int64_t)(row + 2 * NC) * ld + i] = hB;
+		if (a.compactRows) {
+			a.A[(int64_t)(row + 1 * NC) * ld + i] = hB; // the row's one margin entry; the loader knows its column
+		} else {
+			a.A[(int64_t)(row + 1 * NC) * ld + i] = 0.0;
+			a.A[(int64_t)(row + 2 * NC) * ld + i] = hB;
+		}
 		a.b[(int64_t)row * ld + i] = -Lf;
 	}
 	if (RB) {
@@ -527,7 +531,24 @@ struct ImplicitPolicy {
 		qp.ub[0] = o.ub[0];
 		qp.ub[1] = o.inf;
 		qp.ub[2] = o.inf;
-		load_rows<NV, NC, G>(a.A, a.b, a.ld, i, g, 0ull, qp);
+		// compact rows (FilterArgs::compactRows): [Lgh_r, h_r | -Lfh_r]; h_r multiplies the safe relaxation on the
+		// safety rows and the reach relaxation on the last row, the backup set's (src/asif_implicit.cpp:591-611)
+		constexpr int RPL = (NC + G - 1) / G;
+#pragma unroll
+		for (int k = 0; k < RPL; k++) {
+			const int r = g + k * G;
+			const bool valid = r < NC;
+			const int rr = valid ? r : 0;
+			const double lg = a.A[(int64_t)rr * a.ld + i], hv = a.A[(int64_t)(rr + NC) * a.ld + i];
+			const double bv = a.b[(int64_t)rr * a.ld + i];
+			const bool last = rr == NC - M::NPBS;
+			static_assert(M::NPBS == 1, "one backup-set row");
+			qp.A[k][0] = valid ? lg : 0.0;
+			qp.A[k][1] = (valid && !last) ? hv : 0.0;
+			qp.A[k][2] = (valid && last) ? hv : 0.0;
+			qp.b[k] = valid ? bv : -1e20; // out-of-range rows are inert: 0.x >= -big
+			qp.eq[k] = false;
+		}
 	}
 	template <int NV>
 	__device__ __forceinline__ void store(int64_t i, const double (&sol)[NV], int st, int it) const
@@ -598,9 +619,11 @@ int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const Filt
 	using M = InvertedPendulum;
 	if (a.B <= 0) return 0;
 	if (o.integrator == 1 && rb) return ASIF_HIP_EUNSUPPORTED; // held input: time-dependent rhs, Euler only
-	int e = launch_rows<M>(o, a, stream, rb);
+	FilterArgs ac = a;
+	ac.compactRows = assemble_only ? 0 : 1; // the filter's own rows: three doubles each (launchers.hpp)
+	int e = launch_rows<M>(o, ac, stream, rb);
 	if (e || assemble_only) return e;
-	const ImplicitPolicy<M> p = {a.B, o, a};
+	const ImplicitPolicy<M> p = {a.B, o, ac};
 	switch (S.lanes_per_qp) {
 	case 0:
 	case 8: return launch_policy<3, 41, 8>(S, p, stream);
@@ -618,9 +641,11 @@ int launch_implicit_di(const DevOptions &o, const asif_hip_solver &S, const Filt
 	static_assert(M::NPBTSS * M::NPSS + M::NPBS == 17, "QP shape 3 x 17");
 	if (a.B <= 0) return 0;
 	if (o.integrator == 1 && rb) return ASIF_HIP_EUNSUPPORTED;
-	int e = launch_rows<M>(o, a, stream, rb);
+	FilterArgs ac = a;
+	ac.compactRows = assemble_only ? 0 : 1; // the filter's own rows: three doubles each (launchers.hpp)
+	int e = launch_rows<M>(o, ac, stream, rb);
 	if (e || assemble_only) return e;
-	const ImplicitPolicy<M> p = {a.B, o, a};
+	const ImplicitPolicy<M> p = {a.B, o, ac};
 	switch (S.lanes_per_qp) {
 	case 0:
 	case 4: return launch_policy<3, 17, 4>(S, p, stream);

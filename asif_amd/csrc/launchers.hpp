@@ -22,6 +22,12 @@ struct FilterArgs {
 	double *ckpt;
 	// class ASIF with caller-supplied Lie derivatives (src/asif.cpp:287-292): lfh[nc][ld], lgh[nc*nu][ld], or nullptr
 	const double *lfh, *lgh;
+	// ASIFimplicit's rows as the filter's own two launches pass them: [Lgh_r, h_r] in columns 0 and 1 of the staging
+	// block and -Lfh_r in b -- three doubles per row.  The third column of the reference's nc x 3 block is zero on the
+	// safety rows and holds h on the backup row, whose second is zero (src/asif_implicit.cpp:591-611): structure the
+	// solver's loader restores instead of 8 nc bytes per instance written and read back.  0: the reference's full block
+	// (asif_hip_assemble_batch hands that out).
+	int compactRows;
 };
 
 // explicit CBF filter (class ASIF), model = DoubleIntegrator / PlanarTwoInput
