@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 	const int max_newton = S_.max_iter > 0 ? S_.max_iter : 4000;
 	// per half: the problem's verdict (0 = still running), its Newton count, the state of its inverse
 	int status = outside ? kStatusMaxIter : 0, newton = 0;
-	bool kvalid = false, pactr = false, pactb = false;
+	bool kvalid = false, pactr = false, pactb = false, stiff = false;
 	double pri_prev = -1.0, best_res = 1e300;
 
 	// section timers of a scratch build (tools/dev_inv_sections.py); compiled out of the library
@@ -491,6 +491,18 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 				const double kd = s.col_dot(actr ? s.mu * ad : 0.0) + (s.Pd + ig + (actb ? s.mub * s.ab * s.ab : 0.0)) * d;
 				const double res = s.isv ? -g - kd : 0.0;
 				d += s.kinv_mul(res);
+				// A second step once this problem's penalties have been raised (the hard 5 %: K_J's condition is then
+				// mu |a|^2 gamma ~ 1e11 and the running inverse carries its 1e-8 into a direction that one step does not
+				// clean: with the penalties raised in one jump -- qp_lds.hpp, penalty_jump -- single instances zigzagged
+				// through 60-75 Newton steps; with it none exceeds 19).  Problems that never leave the first penalty,
+				// 95 % of the seeded ones, do not pay for it.
+				if (__any(stiff && inn)) {
+					const double ad2 = s.row_dot(d);
+					const double kd2 = s.col_dot(actr ? s.mu * ad2 : 0.0) + (s.Pd + ig + (actb ? s.mub * s.ab * s.ab : 0.0)) * d;
+					const double res2 = s.isv ? -g - kd2 : 0.0;
+					const double corr = s.kinv_mul(res2);
+					d += stiff ? corr : 0.0;
+				}
 			}
 			newton += inn ? 1 : 0;
 			INV_T(2)
@@ -670,7 +682,7 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 				f = 10.0; // stalled at the cap: the multipliers have far to go (rows with tiny coefficients)
 				cap = 1e8;
 			} else if (pri_prev >= 0.0 && pri > 0.1 * pri_prev) {
-				f = 10.0; // the multiplier iteration contracts like 1 / (1 + mu c): not fast enough -> stiffer penalties
+				f = penalty_jump(pri, pri_prev); // not fast enough -> stiffer penalties, by what the contraction seen asks for (qp_lds.hpp)
 			}
 			if (f != 1.0) {
 				s.mu = f > 1.0 ? fmin(s.mu * f, fmax(s.mu, cap)) : fmax(s.mu * f, kLdsMu0);
@@ -678,6 +690,7 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 				s.imu = 1.0 / s.mu;
 				s.imub = 1.0 / s.mub;
 				kvalid = false;
+				stiff = stiff || f > 1.0;
 			}
 			pri_prev = pri;
 		}
