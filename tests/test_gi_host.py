@@ -194,3 +194,29 @@ def test_shipped_half_plane_problems_are_all_decided(oracle, gi):
     assert (stex != 1).sum() > 1000
     ok = st == 1
     assert np.abs(sol[ok] - ex[ok]).max() <= 1e-11
+
+
+def test_conflict_threshold_is_relative_1e_9(oracle, gi):
+    """Where "infeasible" starts (the one soak disagreement): a row that the bounds contradict by eps.
+    The dual active-set stage calls a conflict at a vertex infeasible beyond kActiveTol = 1e-9 relative to the row's
+    own terms (gi_small.hpp); the oracle's exact enumeration counts a row violated beyond 1e-12.  Above both thresholds
+    the verdicts agree; between them -- problems infeasible by 1e-12 ... 1e-9, which OSQP at its default tolerance
+    calls solved -- the stage returns the optimum of the problem with that row met to rounding."""
+    nv, nc = 2, 4
+    eps = np.array([1e-3, 1e-6, 1e-8, 3e-10, 1e-11, 0.0, -1e-6])
+    B = len(eps)
+    Hd = np.tile([1.0, 50.0], (B, 1))
+    c = np.tile([-2.0 * 0.3, -500.0], (B, 1))
+    A = np.zeros((B, nv, nc))
+    A[:, 0, 0] = 1.0                      # row 0: u >= 1 + eps against u <= 1
+    b = np.full((B, nc), -1e20)
+    b[:, 0] = 1.0 + eps
+    lb = np.tile([-1.0, 5.0], (B, 1))
+    ub = np.tile([1.0, 5.0], (B, 1))       # the explicit class's pinned relaxation variable
+    sol, st, _ = gi(nv, nc, Hd, c, A.reshape(B, -1), b, lb, ub, None)
+    ex, stex, _ = oracle.qp_solve_batch(nv, nc, Hd, c, A.reshape(B, -1), b, lb, ub, None, oracle.SOLVER_EXACT)
+    assert list(st) == [2, 2, 2, 1, 1, 1, 1]          # infeasible down to 1e-8, solved from 3e-10 on
+    assert list(stex == 1) == [False, False, False, False, False, True, True]  # the oracle: infeasible down to 1e-11
+    agree = (eps > 2e-9) | (eps < 1e-12)
+    assert np.array_equal((st == 1)[agree], (stex == 1)[agree])
+    assert np.abs(sol[3:6, 0] - 1.0).max() <= 1e-9 and abs(sol[6, 0] - (1.0 - 1e-6)) <= 1e-12
