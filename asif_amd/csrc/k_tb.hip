@@ -33,6 +33,13 @@ namespace asif {
 // goes on alone with pass 2 and the rows exactly as the fused kernel (same code below).  A range / NaN alarm from either
 // role sends the x wave through the fused, checking pass instead.  Taken only when the grid is small enough that the
 // second wave has a SIMD to itself (two workgroups of 77 KB per CU); larger batches run the fused kernel.
+// models that declare kTbFuseQp have the rows kernel solve the instance's QP itself (the kernel's last block); worth it
+// where stage 2 is a visible share of the step (segway 7 %, double integrator 5 %) -- on the pendulum's 11 551-step pass
+// it is 0.7 %, and the solver's registers in the kernel cost the pass's loop 3 %
+template <class M, class = void>
+struct tb_fuse_qp : std::false_type {};
+template <class M>
+struct tb_fuse_qp<M, std::enable_if_t<M::kTbFuseQp>> : std::true_type {};
 template <class M, class = void>
 struct tb_split_roles : std::false_type {};
 template <class M>
@@ -139,6 +146,8 @@ __device__ __forceinline__ void tb_q_role(const DevOptions &o, const double *rin
 // Round 2 wrote a checkpoint to HBM whenever a block ENTERED the selection: on the segway, whose margins shrink along
 // the trajectory, nearly every 4-sample block does -- 171 MB of writes per 32 768 instances (PMC), 5.2 KB per instance.
 constexpr int kCkptLds2 = 1, kCkptSpill = 2;
+// a.code of an instance whose QP the rows kernel left to stage 2 (fused mode): code + this (codes are -3, 1, 2)
+constexpr int kTbPendingMark = 8;
 // waves per workgroup of the fused pass that the kernel is compiled for: the two-state models' kernels (200 VGPRs) take
 // up to four; the segway's sits at the 256-VGPR line, and a larger launch bound makes the compiler cross it further
 // (266 with AGPRs against 262)
@@ -681,28 +690,40 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 	if (!live) return;
 
 	const int code = inside ? 2 : (hit ? 1 : -3);
-	if (a.code) a.code[i] = code;
-	double TTS = 0.0, ortho = inside ? 1.0 : 0.0;
-	if (code != 1) {
-		// trivial rows; also what the staging buffer holds for code -3 (the reference leaves A_, b_
-		// untouched there and never solves; an inert QP keeps stage 2 uniform)
-#pragma unroll 1
-		for (int r = 0; r < NC; r++) {
-#pragma unroll
-			for (int j = 0; j < NV; j++) a.A[(int64_t)(r + j * NC) * ld + i] = 0.0;
-			a.b[(int64_t)r * ld + i] = -o.inf;
+	// The rows of this instance, [Lgh_r, h_r | -Lfh_r], held in registers (every index below is a compile-time one) until
+	// the end of the kernel: the filter's own call solves its QP right here (a.fuseQp, below) and nothing is staged;
+	// asif_hip_assemble_batch and the other solver modes write them out as before.
+	constexpr bool kHold = tb_fuse_qp<M>::value; // (models without the fused solve write each row out as it is made)
+	double rA0[kHold ? NC : 1], rA1[kHold ? NC : 1], rB[kHold ? NC : 1];
+	auto put = [&](int row, double a0, double a1, double bb) { // row: a compile-time value at every call
+		if constexpr (kHold) {
+			rA0[row] = a0;
+			rA1[row] = a1;
+			rB[row] = bb;
+		} else {
+			a.A[(int64_t)(row + 0 * NC) * ld + i] = a0;
+			a.A[(int64_t)(row + 1 * NC) * ld + i] = a1;
+			a.b[(int64_t)row * ld + i] = bb;
 		}
-	} else {
+	};
+	if constexpr (!kHold) {
+		if (a.code) a.code[i] = code;
+	}
+	// trivial rows; also what the QP holds for code -3 (the reference leaves A_, b_ untouched there and never solves; an
+	// inert QP keeps stage 2 uniform)
+	if (kHold || code != 1) {
+#pragma unroll
+		for (int r = 0; r < NC; r++) put(r, 0.0, 0.0, -o.inf);
+	}
+	double TTS = 0.0, ortho = inside ? 1.0 : 0.0;
+	if (code == 1) {
 		// safety rows of the critical samples in [0, idxHit]
-#pragma unroll 1
+#pragma unroll
 		for (int k = 0; k < K; k++) {
 			if (k > idxHit) { // fewer samples than rows: inert padding, :556-566
 #pragma unroll
 				for (int r = 0; r < NP; r++) {
-					const int row = k * NP + r;
-					a.A[(int64_t)(row + 0 * NC) * ld + i] = 0.0;
-					a.A[(int64_t)(row + 1 * NC) * ld + i] = 1.0;
-					a.b[(int64_t)row * ld + i] = -0.0;
+					put(k * NP + r, 0.0, 1.0, -0.0);
 				}
 				continue;
 			}
@@ -727,10 +748,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 					Lf += s * f0[j];
 					Lg += s * g0[j];
 				}
-				const int row = k * NP + r;
-				a.A[(int64_t)(row + 0 * NC) * ld + i] = Lg;
-				a.A[(int64_t)(row + 1 * NC) * ld + i] = h[r];
-				a.b[(int64_t)row * ld + i] = -Lf;
+				put(k * NP + r, Lg, h[r], -Lf);
 			}
 		}
 		// quantities at the hitting sample (z is still the state at idxHit)
@@ -766,10 +784,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 				Lf += dj * f0[j];
 				Lg += dj * g0[j];
 			}
-			const int row = K * NP;
-			a.A[(int64_t)(row + 0 * NC) * ld + i] = Lg;
-			a.A[(int64_t)(row + 1 * NC) * ld + i] = 0.0;
-			a.b[(int64_t)row * ld + i] = -Lf - o.relaxTTS * hReach;
+			put(K * NP, Lg, 0.0, -Lf - o.relaxTTS * hReach);
 		}
 		{ // orthogonality row: gradient of cos(angle(grad h_B, f_cl)) at the hit w.r.t. x0, :601-641
 			double DxHit[NX * NX];
@@ -800,10 +815,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 				Lf += dc * f0[c];
 				Lg += dc * g0[c];
 			}
-			const int row = K * NP + 1;
-			a.A[(int64_t)(row + 0 * NC) * ld + i] = Lg;
-			a.A[(int64_t)(row + 1 * NC) * ld + i] = 0.0;
-			a.b[(int64_t)row * ld + i] = -Lf - o.relaxMinOrtho * (ortho - o.backTrajMinOrtho);
+			put(K * NP + 1, Lg, 0.0, -Lf - o.relaxMinOrtho * (ortho - o.backTrajMinOrtho));
 		}
 	}
 	if (a.diag) {
@@ -812,6 +824,76 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 		a.diag[2 * ld + i] = (double)idxHit;
 #pragma unroll
 		for (int k = 0; k < K; k++) a.diag[(int64_t)(3 + k) * ld + i] = (code == 1 && k <= idxHit) ? (double)top.idx[k] : -1.0;
+	}
+	if constexpr (tb_fuse_qp<M>::value) {
+	if (!a.fuseQp) { // rows out: asif_hip_assemble_batch, or a solver mode that asks for its iterations (stage 2 reads them)
+		if (a.code) a.code[i] = code;
+#pragma unroll
+		for (int r = 0; r < NC; r++) {
+			a.A[(int64_t)(r + 0 * NC) * ld + i] = rA0[r];
+			a.A[(int64_t)(r + 1 * NC) * ld + i] = rA1[r];
+			a.b[(int64_t)r * ld + i] = rB[r];
+		}
+		return;
+	}
+	// ---- the filter's own call, default solver mode: this lane solves its instance's QP here, with the stage that
+	// decides it in stage 2 as well -- the dual active-set method, one lane per QP, rows in registers (2 x 18: 54
+	// doubles) -- and stores what TbPolicy::store would store.  No rows are staged (14 + 14 MB per 32 768 segway
+	// instances written and read back, and a 13 us launch, before).  An instance the stage leaves undecided (none on
+	// any seeded workload) hands its rows over after all and is marked pending: stage 2 runs for the marked ones only.
+	{
+		QpLaneData<NV, NC> qp; // TbPolicy::load: src/asif_implicit_tb.cpp:198-210
+		qp.Hd[0] = 1.0;
+		qp.Hd[1] = o.relaxCost;
+		qp.c[0] = -2.0 * a.udes[i];
+		qp.c[1] = -2.0 * o.relaxCost * o.relaxLb;
+		qp.lb[0] = o.lb[0];
+		qp.lb[1] = o.relaxLb;
+		qp.ub[0] = o.ub[0];
+		qp.ub[1] = o.inf;
+#pragma unroll
+		for (int r = 0; r < NC; r++) {
+			qp.A[r][0] = rA0[r];
+			qp.A[r][1] = rA1[r];
+			qp.b[r] = rB[r];
+			qp.eq[r] = false;
+		}
+		// as AdmmSmall::solve with polish == 2 (admm_small.hpp): data outside the domain = the solver's max_iter verdict
+		const bool nonfinite = qp_data_nonfinite<NV, NC, 1>(qp.Hd, qp.c, qp.lb, qp.ub, qp.A, qp.b);
+		double sol[NV];
+		int gsteps;
+		const int v = GiSmall<NV, NC, 1>::solve_unchecked(qp, 0, 8 * NV + 4, sol, gsteps);
+		int st = 0;
+		if (nonfinite || v == kGiFailed) st = kStatusMaxIter;
+		else if (v == kGiOptimal) st = kStatusSolved;
+		else if (v == kGiInfeasible) st = kStatusPrimalInf;
+		const bool pending = st == 0 && code != -3;
+		if (__any(pending)) {
+			if (pending) {
+#pragma unroll
+				for (int r = 0; r < NC; r++) {
+					a.A[(int64_t)(r + 0 * NC) * ld + i] = rA0[r];
+					a.A[(int64_t)(r + 1 * NC) * ld + i] = rA1[r];
+					a.b[(int64_t)r * ld + i] = rB[r];
+				}
+			}
+		}
+		a.code[i] = pending ? code + kTbPendingMark : code;
+		if (!pending) { // TbPolicy::store
+			if (code != -3 && st == kStatusSolved) {
+				a.uact[i] = fmin(fmax(sol[0], o.lb[0]), o.ub[0]);
+				a.relax[i] = sol[1];
+				a.rc[i] = code; // 2 inside the backup set (:307), 1 otherwise (:343)
+			} else {
+				double u[1], Du[NX];
+				M::backupController(o, x0, u, Du);
+				a.uact[i] = fmin(fmax(u[0], o.lb[0]), o.ub[0]);
+				// :315 (-1 on the trivial branch), :351 (the raw solver status leaks), :360 (-3)
+				a.rc[i] = code == -3 ? ASIF_HIP_RC_BACKUP_UNREACHED : (code == 2 ? ASIF_HIP_RC_QP_FAILED : st);
+			}
+			if (a.diag) a.diag[(int64_t)(a.ndiag - 1) * ld + i] = 0.0; // iterations: decided before the first one
+		}
+	}
 	}
 }
 
@@ -837,10 +919,13 @@ struct TbPolicy {
 		qp.ub[1] = o.inf;
 		load_rows<NV, NC, G>(a.A, a.b, a.ld, i, g, 0ull, qp);
 	}
+	// fused mode (FilterArgs::fuseQp): only the instances the rows kernel marked are stage 2's
+	__device__ __forceinline__ bool pending(int64_t i) const { return !a.fuseQp || a.code[i] > 4; }
 	template <int NV>
 	__device__ __forceinline__ void store(int64_t i, const double (&sol)[NV], int st, int it) const
 	{
-		const int code = a.code[i];
+		int code = a.code[i];
+		if (code > 4) code -= kTbPendingMark;
 		if (code != -3 && st == kStatusSolved) {
 			a.uact[i] = fmin(fmax(sol[0], o.lb[0]), o.ub[0]);
 			a.relax[i] = sol[1];
@@ -859,11 +944,15 @@ struct TbPolicy {
 };
 
 template <class M>
-static int launch_tb(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
+static int launch_tb(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a_in, bool assemble_only,
                      hipStream_t stream)
 {
 	static_assert(M::NPBTSS * M::NPSS + 2 == 18 && M::NU == 1, "QP shape 2 x 18");
-	if (a.B <= 0) return 0;
+	if (a_in.B <= 0) return 0;
+	FilterArgs a = a_in;
+	// the default solver mode decides every QP with the dual active-set stage before anything else: the rows kernel runs
+	// that stage itself (see its last block) and stage 2 is left with what it marks
+	a.fuseQp = (tb_fuse_qp<M>::value && !assemble_only && S.polish == 2 && S.lanes_per_qp == 0) ? 1 : 0;
 	{
 		constexpr size_t region = sizeof(double) * M::NPBTSS * (M::NX + M::NX * M::NX) * 64;
 		const int grid = grid_for(a.B, 1, 64);

@@ -28,6 +28,9 @@ struct FilterArgs {
 	// solver's loader restores instead of 8 nc bytes per instance written and read back.  0: the reference's full block
 	// (asif_hip_assemble_batch hands that out).
 	int compactRows;
+	// ASIFimplicitTB, default solver mode: the rows kernel solves each instance's QP itself (k_tb.hip) and stages nothing;
+	// stage 2 runs for the instances it marks pending in `code`
+	int fuseQp;
 };
 
 // explicit CBF filter (class ASIF), model = DoubleIntegrator / PlanarTwoInput

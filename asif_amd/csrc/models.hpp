@@ -646,6 +646,7 @@ struct DoubleIntegratorImplicit {
 // (src/asif_implicit_tb.cpp:494,623): taken as the whole of mPpPt = -2 I here and in the oracle (or_models.c).
 struct DoubleIntegratorTB : DoubleIntegratorImplicit {
 	static constexpr int kTrajBlock = 16; // 2 101-sample trajectory (7 001 after the example's updateOptions)
+	static constexpr bool kTbFuseQp = true; // the rows kernel solves the instance's 2 x 18 QP itself (k_tb.hip): C12 360 -> 344 us
 	// (no kBevelRate: the bevel-free form of the block measured 8 % SLOWER on this small step, C12 350 -> 378 us)
 	__device__ static bool arrivalFar(const DevOptions &, const double (&)[NX], int) { return false; } // (unused: no quiet blocks)
 	static constexpr bool kTbUnrollSteps = true;
@@ -781,6 +782,7 @@ struct Segway {
 	// the gradients (tanh, Df, Dg) and the 4 x 4 sensitivity are the larger half of the Euler step and x does not
 	// depend on them: pass 1 of the TB kernel may deal x and Q to two waves (k_tb.hip: tb_rows_split_kernel)
 	static constexpr bool kTbSplitRoles = true;
+	static constexpr bool kTbFuseQp = true; // the rows kernel solves the instance's 2 x 18 QP itself (k_tb.hip)
 	static constexpr bool kInputOnLastState = false; // g depends on the pitch
 	static constexpr bool kDfFirstRowShift = false;
 

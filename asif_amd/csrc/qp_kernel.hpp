@@ -3,6 +3,7 @@
 // rows staged in HBM by the trajectory kernel) instantiate it with different policies.
 #pragma once
 #include <type_traits>
+#include <utility>
 #include "admm_small.hpp"
 #include "launchers.hpp"
 
@@ -36,6 +37,13 @@ struct reads_staged_rows : std::false_type {};
 template <class P>
 struct reads_staged_rows<P, std::enable_if_t<P::kStagedRows>> : std::true_type {};
 
+// policies that declare pending(i) have stage 2 solve only the instances for which it is true (the rows kernel has
+// answered the others): a wave none of whose instances is pending exits at once
+template <class P, class = void>
+struct has_pending : std::false_type {};
+template <class P>
+struct has_pending<P, std::void_t<decltype(std::declval<const P &>().pending((int64_t)0))>> : std::true_type {};
+
 template <int NV, int NC, int G, class Policy>
 __global__ __launch_bounds__(256) void qp_policy_kernel(asif_hip_solver S, Policy pol)
 {
@@ -53,8 +61,12 @@ __global__ __launch_bounds__(256) void qp_policy_kernel(asif_hip_solver S, Polic
 	const int64_t tid = blk * blockDim.x + threadIdx.x;
 	const int g = (int)(tid % G);
 	int64_t i = tid / G;
-	const bool live = i < pol.B;
+	bool live = i < pol.B;
 	if (!live) i = pol.B - 1;
+	if constexpr (has_pending<Policy>::value) {
+		live = live && pol.pending(i);
+		if (!__any(live)) return; // wave-uniform
+	}
 	QpLaneData<NV, RPL> qp;
 	pol.template load<NV, NC, G>(i, g, qp);
 	AdmmSmall<NV, RPL, G> admm;
