@@ -867,7 +867,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64 * tb_max_wg_waves<M>()) void tb_ro
 		if (nonfinite || v == kGiFailed) st = kStatusMaxIter;
 		else if (v == kGiOptimal) st = kStatusSolved;
 		else if (v == kGiInfeasible) st = kStatusPrimalInf;
-		const bool pending = st == 0 && code != -3;
+		const bool forced = a.fuseQp == 2 || (a.fuseQp == 3 && (i & 1)); // (developer switch, see launch_tb)
+		const bool pending = (st == 0 || forced) && code != -3;
 		if (__any(pending)) {
 			if (pending) {
 #pragma unroll
@@ -953,6 +954,13 @@ static int launch_tb(const DevOptions &o, const asif_hip_solver &S, const Filter
 	// the default solver mode decides every QP with the dual active-set stage before anything else: the rows kernel runs
 	// that stage itself (see its last block) and stage 2 is left with what it marks
 	a.fuseQp = (tb_fuse_qp<M>::value && !assemble_only && S.polish == 2 && S.lanes_per_qp == 0) ? 1 : 0;
+	if (a.fuseQp) {
+		// developer switch (tests/test_gpu_tb.py): 0 = two launches as before; 2 = the rows kernel marks EVERY instance that
+		// has a QP pending, 3 = every second one -- the hand-over to stage 2 that no seeded instance takes by itself
+		const char *v = getenv("ASIF_HIP_TB_FUSE");
+		if (v && v[0] == '0') a.fuseQp = 0;
+		else if (v && (v[0] == '2' || v[0] == '3')) a.fuseQp = v[0] - '0';
+	}
 	{
 		constexpr size_t region = sizeof(double) * M::NPBTSS * (M::NX + M::NX * M::NX) * 64;
 		const int grid = grid_for(a.B, 1, 64);

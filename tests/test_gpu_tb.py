@@ -103,3 +103,24 @@ def test_small_and_ragged_batches_on_the_two_role_pass(hip, oracle, B):
     ua, rl, rc = gpu_util.oracle_filter(oracle, 4, out["x"], out["udes"], uact_init=7.0, relax_init=-7.0)
     assert np.array_equal(out["rc"], rc)
     assert np.abs(out["uact"] - ua).max() <= 1e-6
+
+
+@pytest.mark.parametrize("cfg,B", [(4, 4099), (12, 3001)])
+def test_fused_solve_and_its_hand_over_to_stage_two(hip, monkeypatch, cfg, B):
+    """ASIFimplicitTB, default solver mode: the rows kernel solves each instance's 2 x 18 QP itself and stages nothing
+    (DESIGN 4.2).  An instance its stage leaves undecided is handed to stage 2 with its rows and a mark -- no seeded
+    instance is, so ASIF_HIP_TB_FUSE forces it: 2 marks every instance that has a QP, 3 every second one (waves with
+    marked and unmarked lanes side by side), 0 is the two-launch path of before.  uAct, relax, rc and the iteration
+    diagnostics bitwise identical across all four, untouched slots untouched."""
+    outs = []
+    for v in (None, "0", "2", "3"):
+        if v is None:
+            monkeypatch.delenv("ASIF_HIP_TB_FUSE", raising=False)
+        else:
+            monkeypatch.setenv("ASIF_HIP_TB_FUSE", v)
+        outs.append(gpu_util.run_filter(cfg, B, uact_init=7.0, relax_init=-7.0))
+    ref = outs[0]
+    assert {1, 2, -3} <= set(np.unique(ref["rc"]).tolist())
+    for o in outs[1:]:
+        assert np.array_equal(o["rc"], ref["rc"]) and np.array_equal(o["uact"], ref["uact"])
+        assert np.array_equal(o["relax"], ref["relax"]) and np.array_equal(o["diag"], ref["diag"])
