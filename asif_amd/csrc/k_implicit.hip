@@ -22,6 +22,7 @@
 // is re-dealt G lanes per QP so the second launch fills the whole chip.
 #include <type_traits>
 #include "backup_traj.hpp"
+#include <utility>
 #include "qp_kernel.hpp"
 
 namespace asif {
@@ -78,6 +79,20 @@ struct ImplicitLds {
 		return sizeof(double) * (head + (rb ? 2 * kLearnMaxHidden * 64 : 0));
 	}
 };
+
+// models that declare kImFuseQp have the rows kernel of plain ASIFimplicit solve the instance's QP itself (the kernel's
+// last block): DoubleIntegrator_implicit's 3 x 17 fits registers (51 doubles), the pendulum's 3 x 41 does not
+template <class M, class = void>
+struct im_fuse_qp : std::false_type {};
+template <class M>
+struct im_fuse_qp<M, std::enable_if_t<M::kImFuseQp>> : std::true_type {};
+// a.code of an instance whose QP the rows kernel left to stage 2 (fused mode): 1 + this
+constexpr int kImPendingMark = 8;
+template <int... I, class F>
+__device__ __forceinline__ void unroll_seq(std::integer_sequence<int, I...>, F &&f)
+{
+	(f(std::integral_constant<int, I>()), ...);
+}
 
 template <class M, bool RB, bool DOPRI = false, int CKPT = kImCkptSpill>
 __global__ __launch_bounds__(256) void implicit_rows_kernel(DevOptions o_arg, FilterArgs a)
@@ -399,9 +414,30 @@ __global__ __launch_bounds__(256) void implicit_rows_kernel(DevOptions o_arg, Fi
 	double dhIndex[NX], Lf00 = 0.0, Lg00 = 0.0; // Dh_index_[0..nx), Lfh[0], Lgh[0]
 #pragma unroll
 	for (int c = 0; c < NX; c++) dhIndex[c] = 0.0;
+	// Models that declare kImFuseQp (plain ASIFimplicit only) keep the rows of the instance -- [Lgh_r, h_r | -Lfh_r],
+	// three doubles each -- in registers until the end of the kernel and solve the QP right here (last block); the others
+	// write each row out as it is made.  `row` is a compile-time value at every call of put().
+	constexpr bool kHold = im_fuse_qp<M>::value && !RB;
+	double rLg[kHold ? NC : 1], rH[kHold ? NC : 1], rB[kHold ? NC : 1];
+	auto put = [&](int row, double lg, double hv, double bb, bool last) {
+		if constexpr (kHold) {
+			rLg[row] = lg;
+			rH[row] = hv;
+			rB[row] = bb;
+		} else {
+			a.A[(int64_t)(row + 0 * NC) * ld + i] = lg;
+			if (a.compactRows) { // (wave-uniform) the row's one margin entry; the loader knows its column
+				a.A[(int64_t)(row + 1 * NC) * ld + i] = hv;
+			} else {
+				a.A[(int64_t)(row + 1 * NC) * ld + i] = last ? 0.0 : hv;
+				a.A[(int64_t)(row + 2 * NC) * ld + i] = last ? hv : 0.0;
+			}
+			a.b[(int64_t)row * ld + i] = bb;
+		}
+	};
 	// safe rows from the parked critical samples
-#pragma unroll 1
-	for (int k = 0; k < K; k++) {
+	auto sample_rows = [&](auto kk) {
+		const int k = kk;
 		double zk[NZ], xs[NX], h[NP], Dh[NP * NX];
 		int slot = 0, sidx = 0; // entry k of the selection, picked with selects: a dynamic index would spill the arrays
 #pragma unroll
@@ -438,13 +474,15 @@ __global__ __launch_bounds__(256) void implicit_rows_kernel(DevOptions o_arg, Fi
 					Lg00 = Lg;
 				}
 			}
-			const int row = k * NP + r;
-			a.A[(int64_t)(row + 0 * NC) * ld + i] = Lg;
-			a.A[(int64_t)(row + 1 * NC) * ld + i] = h[r];
-			if (!a.compactRows) a.A[(int64_t)(row + 2 * NC) * ld + i] = 0.0; // (wave-uniform)
-			a.b[(int64_t)row * ld + i] = -Lf;
+			put(k * NP + r, Lg, h[r], -Lf, false);
 		}
 		if (a.diag) a.diag[(int64_t)k * ld + i] = (double)sidx;
+	};
+	if constexpr (kHold) {
+		unroll_seq(std::make_integer_sequence<int, K>(), sample_rows);
+	} else {
+#pragma unroll 1
+		for (int k = 0; k < K; k++) sample_rows(k);
 	}
 	// backup-set row at the end of the trajectory
 	{
@@ -461,15 +499,7 @@ __global__ __launch_bounds__(256) void implicit_rows_kernel(DevOptions o_arg, Fi
 			Lf += s * f0[j];
 			Lg += s * g0[j];
 		}
-		const int row = K * NP;
-		a.A[(int64_t)(row + 0 * NC) * ld + i] = Lg;
-		if (a.compactRows) {
-			a.A[(int64_t)(row + 1 * NC) * ld + i] = hB; // the row's one margin entry; the loader knows its column
-		} else {
-			a.A[(int64_t)(row + 1 * NC) * ld + i] = 0.0;
-			a.A[(int64_t)(row + 2 * NC) * ld + i] = hB;
-		}
-		a.b[(int64_t)row * ld + i] = -Lf;
+		put(K * NP, Lg, hB, -Lf, true);
 	}
 	if (RB) {
 		if (o.nDebug >= 0) { // :590-605: Dh_index_ from sample n_debug instead
@@ -505,7 +535,88 @@ __global__ __launch_bounds__(256) void implicit_rows_kernel(DevOptions o_arg, Fi
 			a.diag[(int64_t)(K + NX + 1) * ld + i] = dLg;
 		}
 	}
-	if (a.code) a.code[i] = 1;
+	if constexpr (!kHold) {
+		if (a.code) a.code[i] = 1;
+	} else {
+		if (!a.fuseQp) { // rows out: asif_hip_assemble_batch (the reference's full block), or a solver mode that asks for its iterations
+			if (a.code) a.code[i] = 1;
+#pragma unroll
+			for (int r = 0; r < NC; r++) {
+				const bool last = r == NC - NB;
+				a.A[(int64_t)(r + 0 * NC) * ld + i] = rLg[r];
+				if (a.compactRows) {
+					a.A[(int64_t)(r + 1 * NC) * ld + i] = rH[r];
+				} else {
+					a.A[(int64_t)(r + 1 * NC) * ld + i] = last ? 0.0 : rH[r];
+					a.A[(int64_t)(r + 2 * NC) * ld + i] = last ? rH[r] : 0.0;
+				}
+				a.b[(int64_t)r * ld + i] = rB[r];
+			}
+			return;
+		}
+		// ---- the filter's own call, default solver mode: this lane solves its instance's QP here with the stage that
+		// decides it in stage 2 as well (dual active-set method, one lane per QP, rows in registers) and stores what
+		// ImplicitPolicy::store would store; nothing is staged.  An instance the stage leaves undecided (none on any
+		// seeded workload) hands its rows over and is marked in `code`: stage 2 runs for the marked ones only.
+		constexpr int NV = 3;
+		QpLaneData<NV, NC> qp; // ImplicitPolicy::load: src/asif_implicit.cpp:237-254
+		qp.Hd[0] = 1.0;
+		qp.Hd[1] = o.relaxCost;
+		qp.Hd[2] = o.relaxCost;
+		qp.c[0] = -2.0 * a.udes[i];
+		qp.c[1] = -2.0 * o.relaxCost * o.relaxLb;
+		qp.c[2] = -2.0 * o.relaxCost * o.relaxReachLb;
+		qp.lb[0] = o.lb[0];
+		qp.lb[1] = o.relaxLb;
+		qp.lb[2] = o.relaxReachLb;
+		qp.ub[0] = o.ub[0];
+		qp.ub[1] = o.inf;
+		qp.ub[2] = o.inf;
+#pragma unroll
+		for (int r = 0; r < NC; r++) {
+			const bool last = r == NC - NB;
+			qp.A[r][0] = rLg[r];
+			qp.A[r][1] = last ? 0.0 : rH[r];
+			qp.A[r][2] = last ? rH[r] : 0.0;
+			qp.b[r] = rB[r];
+			qp.eq[r] = false;
+		}
+		const bool nonfinite = qp_data_nonfinite<NV, NC, 1>(qp.Hd, qp.c, qp.lb, qp.ub, qp.A, qp.b);
+		double sol[NV];
+		int gsteps;
+		const int v = GiSmall<NV, NC, 1>::solve_unchecked(qp, 0, 8 * NV + 4, sol, gsteps);
+		int st = 0; // as AdmmSmall::solve with polish == 2 (admm_small.hpp)
+		if (nonfinite || v == kGiFailed) st = kStatusMaxIter;
+		else if (v == kGiOptimal) st = kStatusSolved;
+		else if (v == kGiInfeasible) st = kStatusPrimalInf;
+		const bool forced = a.fuseQp == 2 || (a.fuseQp == 3 && (i & 1)); // (developer switch, see launch_implicit_di)
+		const bool pending = st == 0 || forced;
+		if (__any(pending)) {
+			if (pending) {
+#pragma unroll
+				for (int r = 0; r < NC; r++) { // compact rows, as stage 2's loader reads them
+					a.A[(int64_t)(r + 0 * NC) * ld + i] = rLg[r];
+					a.A[(int64_t)(r + 1 * NC) * ld + i] = rH[r];
+					a.b[(int64_t)r * ld + i] = rB[r];
+				}
+			}
+		}
+		a.code[i] = pending ? 1 + kImPendingMark : 1;
+		if (!pending) { // ImplicitPolicy::store
+			if (st == kStatusSolved) {
+				a.uact[i] = fmin(fmax(sol[0], o.lb[0]), o.ub[0]);
+				a.relax[i] = sol[1];
+				a.relax[ld + i] = sol[2];
+				a.rc[i] = ASIF_HIP_RC_OK;
+			} else {
+				double u[1], Du[NX];
+				M::backupController(o, x0, u, Du);
+				a.uact[i] = fmin(fmax(u[0], o.lb[0]), o.ub[0]);
+				a.rc[i] = ASIF_HIP_RC_QP_FAILED;
+			}
+			if (a.diag) a.diag[(int64_t)(a.ndiag - 1) * ld + i] = 0.0; // iterations: decided before the first one
+		}
+	}
 }
 
 template <class M>
@@ -550,6 +661,8 @@ struct ImplicitPolicy {
 			qp.eq[k] = false;
 		}
 	}
+	// fused mode (FilterArgs::fuseQp): only the instances the rows kernel marked are stage 2's
+	__device__ __forceinline__ bool pending(int64_t i) const { return !a.fuseQp || a.code[i] > kImPendingMark; }
 	template <int NV>
 	__device__ __forceinline__ void store(int64_t i, const double (&sol)[NV], int st, int it) const
 	{
@@ -643,6 +756,16 @@ int launch_implicit_di(const DevOptions &o, const asif_hip_solver &S, const Filt
 	if (o.integrator == 1 && rb) return ASIF_HIP_EUNSUPPORTED;
 	FilterArgs ac = a;
 	ac.compactRows = assemble_only ? 0 : 1; // the filter's own rows: three doubles each (launchers.hpp)
+	// the default solver mode decides every QP with the dual active-set stage before anything else: the rows kernel of plain
+	// ASIFimplicit runs that stage itself and stage 2 is left with what it marks
+	ac.fuseQp = (im_fuse_qp<M>::value && !rb && !assemble_only && S.polish == 2 && S.lanes_per_qp == 0) ? 1 : 0;
+	if (ac.fuseQp) {
+		// developer switch (tests/test_gpu_implicit_di.py): 0 = two launches as before; 2 = every instance is marked pending,
+		// 3 = every second one -- the hand-over to stage 2 that no seeded instance takes by itself
+		const char *v = getenv("ASIF_HIP_IM_FUSE");
+		if (v && v[0] == '0') ac.fuseQp = 0;
+		else if (v && (v[0] == '2' || v[0] == '3')) ac.fuseQp = v[0] - '0';
+	}
 	int e = launch_rows<M>(o, ac, stream, rb);
 	if (e || assemble_only) return e;
 	const ImplicitPolicy<M> p = {a.B, o, ac};

@@ -570,6 +570,7 @@ struct PlanarTwoInput {
 // plain box |x|,|v| <= 1 (not the braking parabola of examples/DoubleIntegrator.cpp), ellipsoidal backup set.
 // Sums are accumulated from 0.0 like the reference's matrixVectorMultiply (include/asif_utils.h:46-62).
 struct DoubleIntegratorImplicit {
+	static constexpr bool kImFuseQp = true; // plain ASIFimplicit: the rows kernel solves the instance's 3 x 17 QP itself (k_implicit.hip)
 	static constexpr int NX = 2, NU = 1, NPSS = 4, NPBS = 1, NPBTSS = 4;
 	static constexpr int kTrajBlock = 4; // 201-sample trajectory, 4 critical samples (measured: 4 < 8 < 16)
 	// g = e_last and Dg = 0 for every state: lets the backup loop drop the generic formula's products with

@@ -39,3 +39,22 @@ def test_filter_matches_exact_optimum(hip, oracle, lanes):
     fb = ~ok
     uk = np.clip(-10.0 * out["x"][0] - 20.0 * out["x"][1], -1.0, 1.0)
     assert np.allclose(out["uact"][0][fb], uk[fb], atol=1e-12)
+
+
+def test_fused_solve_and_its_hand_over_to_stage_two(hip, monkeypatch):
+    """DoubleIntegrator_implicit, default solver mode: the rows kernel solves each instance's 3 x 17 QP itself and stages
+    nothing.  ASIF_HIP_IM_FUSE forces the hand-over to stage 2 that no seeded instance takes by itself (2: every
+    instance, 3: every second one), 0 is the two-launch path: uAct, relax, rc, diagnostics bitwise identical across all."""
+    import gpu_util
+    outs = []
+    for v in (None, "0", "2", "3"):
+        if v is None:
+            monkeypatch.delenv("ASIF_HIP_IM_FUSE", raising=False)
+        else:
+            monkeypatch.setenv("ASIF_HIP_IM_FUSE", v)
+        outs.append(gpu_util.run_filter(9, 5003, uact_init=7.0, relax_init=-7.0))
+    ref = outs[0]
+    assert {1, -1} <= set(np.unique(ref["rc"]).tolist())
+    for o in outs[1:]:
+        assert np.array_equal(o["rc"], ref["rc"]) and np.array_equal(o["uact"], ref["uact"])
+        assert np.array_equal(o["relax"], ref["relax"]) and np.array_equal(o["diag"], ref["diag"])
