@@ -726,6 +726,20 @@ static int launch_rows(const DevOptions &o, const FilterArgs &a, hipStream_t str
 	return launch_with_lds(implicit_rows_kernel<M, false, false, kImCkptSpill>, b, waves, nw, o, a, stream);
 }
 
+// FilterArgs::fuseQp of a filter call: the default solver mode decides every QP with the dual active-set stage before
+// anything else, so the rows kernel of plain ASIFimplicit runs that stage itself (models with kImFuseQp) and stage 2 is
+// left with what it marks.  ASIF_HIP_IM_FUSE, a developer switch (tests/test_gpu_implicit*.py): 0 = two launches as before;
+// 2 = every instance is marked pending, 3 = every second one -- the hand-over that no seeded instance takes by itself.
+template <class M>
+static int fuse_mode(const asif_hip_solver &S, bool assemble_only, bool rb)
+{
+	if (!(im_fuse_qp<M>::value && !rb && !assemble_only && S.polish == 2 && S.lanes_per_qp == 0)) return 0;
+	const char *v = getenv("ASIF_HIP_IM_FUSE");
+	if (v && v[0] == '0') return 0;
+	if (v && (v[0] == '2' || v[0] == '3')) return v[0] - '0';
+	return 1;
+}
+
 int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const FilterArgs &a, bool assemble_only,
                        hipStream_t stream, bool rb)
 {
@@ -734,6 +748,7 @@ int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const Filt
 	if (o.integrator == 1 && rb) return ASIF_HIP_EUNSUPPORTED; // held input: time-dependent rhs, Euler only
 	FilterArgs ac = a;
 	ac.compactRows = assemble_only ? 0 : 1; // the filter's own rows: three doubles each (launchers.hpp)
+	ac.fuseQp = fuse_mode<M>(S, assemble_only, rb);
 	int e = launch_rows<M>(o, ac, stream, rb);
 	if (e || assemble_only) return e;
 	const ImplicitPolicy<M> p = {a.B, o, ac};
@@ -756,16 +771,7 @@ int launch_implicit_di(const DevOptions &o, const asif_hip_solver &S, const Filt
 	if (o.integrator == 1 && rb) return ASIF_HIP_EUNSUPPORTED;
 	FilterArgs ac = a;
 	ac.compactRows = assemble_only ? 0 : 1; // the filter's own rows: three doubles each (launchers.hpp)
-	// the default solver mode decides every QP with the dual active-set stage before anything else: the rows kernel of plain
-	// ASIFimplicit runs that stage itself and stage 2 is left with what it marks
-	ac.fuseQp = (im_fuse_qp<M>::value && !rb && !assemble_only && S.polish == 2 && S.lanes_per_qp == 0) ? 1 : 0;
-	if (ac.fuseQp) {
-		// developer switch (tests/test_gpu_implicit_di.py): 0 = two launches as before; 2 = every instance is marked pending,
-		// 3 = every second one -- the hand-over to stage 2 that no seeded instance takes by itself
-		const char *v = getenv("ASIF_HIP_IM_FUSE");
-		if (v && v[0] == '0') ac.fuseQp = 0;
-		else if (v && (v[0] == '2' || v[0] == '3')) ac.fuseQp = v[0] - '0';
-	}
+	ac.fuseQp = fuse_mode<M>(S, assemble_only, rb);
 	int e = launch_rows<M>(o, ac, stream, rb);
 	if (e || assemble_only) return e;
 	const ImplicitPolicy<M> p = {a.B, o, ac};

@@ -340,6 +340,10 @@ struct DoubleIntegrator {
 // ---------------------------------------------------------------------------------------------
 // Inverted pendulum with an LQR-like backup controller, examples/InvertedPendulum_Implicit.cpp:13-80.
 struct InvertedPendulum {
+	// plain ASIFimplicit: the rows kernel solves the instance's 3 x 41 QP itself (k_implicit.hip); its 123 doubles of rows
+	// do not fit the 256 vector registers next to the solver's state -- the compiler parks them in AGPRs (the wave has the
+	// SIMD's 512 to itself) and 0.7 KB of scratch: C3 762 -> 753 us, and nothing staged (34 -> 1 MB per step)
+	static constexpr bool kImFuseQp = true;
 	static constexpr int NX = 2, NU = 1, NPSS = 4, NPBS = 1, NPBTSS = 10;
 	// samples per checkpoint block of the two-pass critical-sample search (k_implicit.hip): ~sqrt(npBT / 2 npBTSS)
 	static constexpr int kTrajBlock = 16; // measured: 8 is 1.7 % faster at twice the checkpoint memory, 32 is 2.7 % slower

@@ -76,3 +76,22 @@ def test_full_size_properties(hip):
     h2 = gpu_util.run_filter(3, B // 2, first=B // 2)
     assert np.array_equal(np.concatenate([h1["uact"], h2["uact"]], axis=1), out["uact"])
     assert np.array_equal(np.concatenate([h1["rc"], h2["rc"]]), rc)
+
+
+def test_fused_solve_and_its_hand_over_to_stage_two(hip, monkeypatch):
+    """InvertedPendulum_Implicit, default solver mode: the rows kernel solves each instance's 3 x 41 QP itself and stages
+    nothing.  ASIF_HIP_IM_FUSE forces the hand-over to stage 2 that no seeded instance takes by itself (2: every
+    instance, 3: every second one), 0 is the two-launch path: uAct, relax, rc, diagnostics bitwise identical across all."""
+    import gpu_util
+    outs = []
+    for v in (None, "0", "2", "3"):
+        if v is None:
+            monkeypatch.delenv("ASIF_HIP_IM_FUSE", raising=False)
+        else:
+            monkeypatch.setenv("ASIF_HIP_IM_FUSE", v)
+        outs.append(gpu_util.run_filter(3, 1027, uact_init=7.0, relax_init=-7.0))
+    ref = outs[0]
+    assert {1, -1} <= set(np.unique(ref["rc"]).tolist())
+    for o in outs[1:]:
+        assert np.array_equal(o["rc"], ref["rc"]) and np.array_equal(o["uact"], ref["uact"])
+        assert np.array_equal(o["relax"], ref["relax"]) and np.array_equal(o["diag"], ref["diag"])
