@@ -585,7 +585,9 @@ __global__ __launch_bounds__(256) void implicit_rows_kernel(DevOptions o_arg, Fi
 		const bool nonfinite = qp_data_nonfinite<NV, NC, 1>(qp.Hd, qp.c, qp.lb, qp.ub, qp.A, qp.b);
 		double sol[NV];
 		int gsteps;
-		const int v = GiSmall<NV, NC, 1>::solve_unchecked(qp, 0, 8 * NV + 4, sol, gsteps);
+		// (solve_general: the launcher fuses only when no variable is pinned by its bounds -- fuse_mode -- so the entry's
+		// elimination of pinned variables, which would hold a second copy of the rows, has nothing to do here)
+		const int v = GiSmall<NV, NC, 1>::solve_general(qp, 0, 8 * NV + 4, sol, gsteps);
 		int st = 0; // as AdmmSmall::solve with polish == 2 (admm_small.hpp)
 		if (nonfinite || v == kGiFailed) st = kStatusMaxIter;
 		else if (v == kGiOptimal) st = kStatusSolved;
@@ -732,9 +734,12 @@ static int launch_rows(const DevOptions &o, const FilterArgs &a, hipStream_t str
 // left with what it marks.  ASIF_HIP_IM_FUSE, a developer switch (tests/test_gpu_implicit*.py): 0 = two launches as before;
 // 2 = every instance is marked pending, 3 = every second one -- the hand-over that no seeded instance takes by itself.
 template <class M>
-static int fuse_mode(const asif_hip_solver &S, bool assemble_only, bool rb)
+static int fuse_mode(const DevOptions &o, const asif_hip_solver &S, bool assemble_only, bool rb)
 {
 	if (!(im_fuse_qp<M>::value && !rb && !assemble_only && S.polish == 2 && S.lanes_per_qp == 0)) return 0;
+	// an input pinned by its bounds (lb == ub; the relaxation variables never are: their upper bound is "none") is
+	// eliminated by the solver's entry before the method runs (gi_small.hpp) -- stage 2's business
+	if (o.lb[0] == o.ub[0] || o.relaxLb >= o.inf || o.relaxReachLb >= o.inf) return 0;
 	const char *v = getenv("ASIF_HIP_IM_FUSE");
 	if (v && v[0] == '0') return 0;
 	if (v && (v[0] == '2' || v[0] == '3')) return v[0] - '0';
@@ -749,7 +754,7 @@ int launch_implicit_ip(const DevOptions &o, const asif_hip_solver &S, const Filt
 	if (o.integrator == 1 && rb) return ASIF_HIP_EUNSUPPORTED; // held input: time-dependent rhs, Euler only
 	FilterArgs ac = a;
 	ac.compactRows = assemble_only ? 0 : 1; // the filter's own rows: three doubles each (launchers.hpp)
-	ac.fuseQp = fuse_mode<M>(S, assemble_only, rb);
+	ac.fuseQp = fuse_mode<M>(o, S, assemble_only, rb);
 	int e = launch_rows<M>(o, ac, stream, rb);
 	if (e || assemble_only) return e;
 	const ImplicitPolicy<M> p = {a.B, o, ac};
@@ -772,7 +777,7 @@ int launch_implicit_di(const DevOptions &o, const asif_hip_solver &S, const Filt
 	if (o.integrator == 1 && rb) return ASIF_HIP_EUNSUPPORTED;
 	FilterArgs ac = a;
 	ac.compactRows = assemble_only ? 0 : 1; // the filter's own rows: three doubles each (launchers.hpp)
-	ac.fuseQp = fuse_mode<M>(S, assemble_only, rb);
+	ac.fuseQp = fuse_mode<M>(o, S, assemble_only, rb);
 	int e = launch_rows<M>(o, ac, stream, rb);
 	if (e || assemble_only) return e;
 	const ImplicitPolicy<M> p = {a.B, o, ac};
