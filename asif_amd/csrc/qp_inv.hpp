@@ -395,6 +395,7 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 	// section timers of a scratch build (tools/dev_inv_sections.py); compiled out of the library
 #ifdef ASIF_INV_PROFILE
 	long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmark = __builtin_readcyclecounter();
+	int cnt_rebuild = 0, cnt_rows = 0, cnt_bounds = 0;
 #define INV_T(k) { const long long tn_ = __builtin_readcyclecounter(); tsec[k] += tn_ - tmark; tmark = tn_; }
 #else
 #define INV_T(k)
@@ -442,6 +443,9 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 			{
 				const bool gone = (pactr && !actr) || (pactb && !actb);
 				const bool rebuild = inn && (!kvalid || hballot<HW>(gone, h) != 0);
+#ifdef ASIF_INV_PROFILE
+				cnt_rebuild += rebuild ? 1 : 0;
+#endif
 				if (__any(rebuild)) {
 					const double dg = s.isv ? fast_rcp(s.Pd + ig) : 0.0;
 #pragma unroll
@@ -466,6 +470,9 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 					const double ut = s.va[t], ujj = s.va[j], c = s.vr[j];
 					s.sync();
 					s.rank_one(ut, ujj, c, on);
+#ifdef ASIF_INV_PROFILE
+					cnt_bounds += on ? 1 : 0;
+#endif
 					pendb = pendb && t != j;
 				}
 				// rows entering: K += mu_i a_i a_i'
@@ -480,6 +487,9 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 					const double ut = s.kinv_mul(at);
 					const double vu = hsum<HW>(at * ut);
 					s.rank_one(ut, vu, c, on);
+#ifdef ASIF_INV_PROFILE
+					cnt_rows += on ? 1 : 0;
+#endif
 					pendr = pendr && t != i;
 				}
 			}
@@ -709,6 +719,11 @@ __global__ __launch_bounds__(64, ASIF_INV_MIN_WAVES) void qp_inv_kernel(asif_hip
 #ifdef ASIF_INV_PROFILE
 		if (t == 0)
 			for (int k = 0; k < 7; k++) a.sol[(int64_t)k * ld + qi] = (double)tsec[k]; // scratch build: times instead of x
+		if (t == 0) {
+			a.sol[(int64_t)7 * ld + qi] = cnt_rebuild;
+			a.sol[(int64_t)8 * ld + qi] = cnt_rows;
+			a.sol[(int64_t)9 * ld + qi] = cnt_bounds;
+		}
 #endif
 	}
 #undef INV_T

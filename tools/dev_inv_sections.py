@@ -31,6 +31,10 @@ tot = t.sum(0)
 print("newton mean per QP", n.mean(), "per wave", nw.mean(), "cycles/wave mean", tot.mean(), "max", tot.max())
 for k in range(7):
     print(f"{names[k]:20s} {t[k].mean():12.0f} cycles  {100 * t[k].sum() / tot.sum():5.1f} %   per wave-newton {t[k].sum() / nw.sum():9.0f}")
+c = sol[7:10].cpu().numpy()  # per QP: rebuilds of the inverse, rank-one steps for rows, for bounds
+print("per QP: rebuilds mean %.2f max %d; rank-one steps rows mean %.1f max %d, bounds mean %.1f max %d" % (c[0].mean(), c[0].max(), c[1].mean(), c[1].max(), c[2].mean(), c[2].max()))
+easy = n == 4
+print("  the 4-step problems: rebuilds %.2f, rows %.1f, bounds %.1f" % (c[0][easy].mean(), c[1][easy].mean(), c[2][easy].mean()))
 hard = np.argsort(tot)[-3:]
 for w in hard:
     print("wave", w, "newton", nw[w], "cycles", tot[w], {names[k]: int(t[k][w]) for k in range(7)})
