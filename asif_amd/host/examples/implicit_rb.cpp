@@ -88,6 +88,8 @@ struct Weights {
 	}
 };
 
+static QPSOLVER g_solver = QPSOLVER::HIP; // `--solver host`: single-agent filter() only, the QP on the calling thread, no device
+
 template <class F>
 static int run(F &flt, long N, uint64_t seed)
 {
@@ -98,7 +100,7 @@ static int run(F &flt, long N, uint64_t seed)
 		bx[N + i] = -1.5 + 3.0 * rng(seed, i, 1);
 		bu[i] = -1.5 + 3.0 * rng(seed, i, 2);
 	}
-	if (flt.filterBatch(N, bx.data(), bu.data(), ba.data(), br.data(), brc.data()) != 0) return 4;
+	if (g_solver != QPSOLVER::HOST && flt.filterBatch(N, bx.data(), bu.data(), ba.data(), br.data(), brc.data()) != 0) return 4;
 	for (long i = 0; i < N; i++) {
 		const double x[2] = {bx[i], bx[N + i]}, ud[1] = {bu[i]};
 		double ua[1] = {0.0}, rl[2] = {0.0, 0.0};
@@ -111,6 +113,13 @@ static int run(F &flt, long N, uint64_t seed)
 
 int main(int argc, char **argv)
 {
+	for (int i = 1; i + 1 < argc; i++)
+		if (!std::strcmp(argv[i], "--solver")) {
+			if (!std::strcmp(argv[i + 1], "host")) g_solver = QPSOLVER::HOST;
+			for (int j = i; j + 2 < argc; j++) argv[j] = argv[j + 2];
+			argc -= 2;
+			break;
+		}
 	if (argc < 2) return 2;
 	const long N = std::atol(argv[1]);
 	const bool plain = argc > 2 && !std::strcmp(argv[2], "plain");
@@ -124,9 +133,9 @@ int main(int argc, char **argv)
 		opts.relaxReachLb = 5.0;
 		opts.relaxSafeLb = 10.0;
 		opts.use_learning = true;
-		ASIF::ASIFimplicit flt(2, 1, 4, 1, 10, safetySetT<double>, backupSet, dynamics, gradients, controller);
+		ASIF::ASIFimplicit flt(2, 1, 4, 1, 10, safetySetT<double>, backupSet, dynamics, gradients, controller, g_solver);
 		W.fill(flt.learning_data_);
-		if (flt.initialize(lb, ub, opts) != 1 || flt.bindDeviceModel(ASIF_HIP_MODEL_INVERTED_PENDULUM) != 0) return 3;
+		if (flt.initialize(lb, ub, opts) != 1 || (g_solver != QPSOLVER::HOST && flt.bindDeviceModel(ASIF_HIP_MODEL_INVERTED_PENDULUM) != 0)) return 3;
 		return run(flt, N, 2);
 	}
 	double xUnc[2] = {0.02, 0.01}; // asif_amd.workloads.RB_X_UNC
@@ -138,8 +147,8 @@ int main(int argc, char **argv)
 	opts.x_unc = xUnc;
 	opts.use_learning = true;
 	ASIF::ASIFimplicitRB flt(2, 1, 4, 1, 10, safetySetT<double>, safetySetT<interval_t>, backupSet, unusedInterval,
-	                         dynamics, unusedInterval, gradients, unusedInterval, controller);
+	                         dynamics, unusedInterval, gradients, unusedInterval, controller, g_solver);
 	W.fill(flt.learning_data_);
-	if (flt.initialize(lb, ub, opts) != 1 || flt.bindDeviceModel(ASIF_HIP_MODEL_INVERTED_PENDULUM) != 0) return 3;
+	if (flt.initialize(lb, ub, opts) != 1 || (g_solver != QPSOLVER::HOST && flt.bindDeviceModel(ASIF_HIP_MODEL_INVERTED_PENDULUM) != 0)) return 3;
 	return run(flt, N, 10);
 }

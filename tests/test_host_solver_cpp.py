@@ -43,6 +43,14 @@ def test_double_integrator_tb_closed_loop_on_the_host_solver(oracle):
     gpu_twin.check_double_integrator_tb_closed_loop(oracle, "host", steps=1200)
 
 
+@pytest.mark.parametrize("plain", [False, True])
+def test_implicit_rb_class_and_learned_residual_on_the_host_solver(oracle, plain):
+    """ASIF::ASIFimplicitRB (held backup input, interval margins on host AAF operands, the two residual networks) and
+    ASIF::ASIFimplicit with use_learning, single agent, 3 x 41 QP on QPWrapperHost: exact optimum, rc and the class's
+    public diagnostics (Dh_index_, learning_data_.Lfh_diff / Lgh_diff) against the oracle -- no device."""
+    gpu_twin.check_implicit_rb_class(oracle, plain, "host")
+
+
 def test_host_solver_is_opt_in_and_bounded_by_shape(tmp_path):
     """makeQPWrapper: HOST gives QPWrapperHost for nv <= 3 with a diagonal cost, QPWrapperHip for anything else (the
     robust and realizable classes' lifted problems) and under the default name; QPWrapperHost refuses other shapes."""

@@ -70,7 +70,9 @@ def test_host_native_code_is_clean_under_asan_and_ubsan(tmp_path):
             ["backup_filters_san", "dii-loop", "400", "--solver", "host"],
             ["backup_filters_san", "tbip-loop", "6", "1", "--solver", "host"],
             ["backup_filters_san", "tb-loop", "300", "0.5", "--solver", "host"],
-            ["backup_filters_san", "tbdi-loop", "60", "--solver", "host"]]
+            ["backup_filters_san", "tbdi-loop", "60", "--solver", "host"],
+            ["implicit_rb_san", "6", "--solver", "host"],            # ASIFimplicitRB: host AAF margins, held input, networks
+            ["implicit_rb_san", "6", "plain", "--solver", "host"]]
     for cmd in runs:
         p = subprocess.run([os.path.join(SAN_DIR, cmd[0])] + cmd[1:], env=env2, capture_output=True, text=True, timeout=900)
         reports = sorted(f for f in os.listdir(tmp_path) if f.startswith(("asan", "ubsan")))
