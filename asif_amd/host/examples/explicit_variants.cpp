@@ -60,12 +60,18 @@ static double unit(uint64_t k) // splitmix64 -> [0,1)
 	return (double)(z >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// `--solver host`: the objects are built with QPSOLVER::HOST, nothing is bound to a device, and every line carries the
+// state and the desired input after the single-agent answer (case,phase,i,rc,u...,relax,x...,uDes...) for
+// tests/test_host_solver_cpp.py to put through the oracle
+static QPSOLVER g_solver = QPSOLVER::HIP;
+
 static int run_case(const char *name, ASIF::ASIF &flt, int model, uint32_t nx, uint32_t nu, long n, double scale)
 {
+	const bool host = g_solver == QPSOLVER::HOST;
 	std::vector<double> lb(nu, -1.0), ub(nu, 1.0);
 	int32_t r = flt.initialize(lb.data(), ub.data());
 	if (r != 1) { std::fprintf(stderr, "%s: initialize %d\n", name, r); return 2; }
-	r = flt.bindDeviceModel(model);
+	r = host ? 0 : flt.bindDeviceModel(model);
 	if (r != 0) { std::fprintf(stderr, "%s: bindDeviceModel %d (%s)\n", name, r, asif_hip_error_string(r)); return 2; }
 	std::vector<double> x(nx * n), ud(nu * n);
 	for (long i = 0; i < n; i++) {
@@ -89,13 +95,22 @@ static int run_case(const char *name, ASIF::ASIF &flt, int model, uint32_t nx, u
 		}
 		std::vector<double> ua(nu * n, 7.0), rl(n, -7.0);
 		std::vector<int32_t> rc(n, 0);
-		r = flt.filterBatch(n, x.data(), ud.data(), ua.data(), rl.data(), rc.data());
+		r = host ? 0 : flt.filterBatch(n, x.data(), ud.data(), ua.data(), rl.data(), rc.data());
 		if (r != 0) { std::fprintf(stderr, "%s: filterBatch %d (%s)\n", name, r, asif_hip_error_string(r)); return 2; }
 		for (long i = 0; i < n; i++) {
 			double xs[4], us[2], u1[2] = {7.0, 7.0}, relax = -7.0;
 			for (uint32_t k = 0; k < nx; k++) xs[k] = x[k * n + i];
 			for (uint32_t j = 0; j < nu; j++) us[j] = ud[j * n + i];
 			const int32_t r1 = flt.filter(xs, us, u1, relax);
+			if (host) {
+				std::printf("%s,%d,%ld,%d", name, phase, i, r1);
+				for (uint32_t j = 0; j < nu; j++) std::printf(",%.17g", u1[j]);
+				std::printf(",%.17g", relax);
+				for (uint32_t k = 0; k < nx; k++) std::printf(",%.17g", xs[k]);
+				for (uint32_t j = 0; j < nu; j++) std::printf(",%.17g", us[j]);
+				std::printf("\n");
+				continue;
+			}
 			std::printf("%s,%d,%ld,%d,%d", name, phase, i, r1, rc[i]);
 			for (uint32_t j = 0; j < nu; j++) std::printf(",%.17g", u1[j]);
 			for (uint32_t j = 0; j < nu; j++) std::printf(",%.17g", ua[j * n + i]);
@@ -107,14 +122,21 @@ static int run_case(const char *name, ASIF::ASIF &flt, int model, uint32_t nx, u
 
 int main(int argc, char **argv)
 {
+	for (int i = 1; i + 1 < argc; i++)
+		if (!std::strcmp(argv[i], "--solver")) {
+			if (!std::strcmp(argv[i + 1], "host")) g_solver = QPSOLVER::HOST;
+			for (int j = i; j + 2 < argc; j++) argv[j] = argv[j + 2];
+			argc -= 2;
+			break;
+		}
 	const long n = argc > 1 ? std::atol(argv[1]) : 64;
 	std::printf("case,phase,i,rcSingle,rcBatch,u...\n");
 	{
-		ASIF::ASIF flt(2, 2, 5, p2SafetySet, p2Dynamics);
+		ASIF::ASIF flt(2, 2, 5, p2SafetySet, p2Dynamics, -1, g_solver);
 		if (int r = run_case("planar2", flt, ASIF_HIP_MODEL_PLANAR_TWO_INPUT, 2, 2, n, 1.3)) return r;
 	}
 	{
-		ASIF::ASIF flt(2, 1, 4, diSafetySet, diDynamics, /*npSSmax=*/2);
+		ASIF::ASIF flt(2, 1, 4, diSafetySet, diDynamics, /*npSSmax=*/2, g_solver);
 		if (int r = run_case("di_keep2", flt, ASIF_HIP_MODEL_DOUBLE_INTEGRATOR, 2, 1, n, 1.2)) return r;
 	}
 	return 0;

@@ -51,6 +51,40 @@ def test_implicit_rb_class_and_learned_residual_on_the_host_solver(oracle, plain
     gpu_twin.check_implicit_rb_class(oracle, plain, "host")
 
 
+def test_explicit_class_two_inputs_and_reduced_row_budget_on_the_host_solver(oracle):
+    """class ASIF beyond the shipped example, on QPWrapperHost: a model with two inputs (nv = 3, five rows) and the double
+    integrator with npSSmax = 2 of its 4 rows (src/asif.cpp:250-268), before and after initialize(options) +
+    updateOptions(): rc and uAct of every call against the oracle's exact optimum on the same state; uAct and relax
+    untouched where the QP is infeasible (src/asif.cpp:208-209)."""
+    exe = os.path.join(HOST, "explicit_variants")
+    n = 96
+    out = subprocess.run([exe, str(n), "--solver", "host"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l.split(",") for l in out.stdout.strip().split("\n")[1:]]
+    failed = 0
+    for name, cfg, nu, keep in (("planar2", 11, 2, 0), ("di_keep2", 2, 1, 2)):
+        model, variant = oracle.CONFIGS[cfg]
+        for phase in (0, 1):
+            rows = np.array([[float(v) for v in l[2:]] for l in lines if l[0] == name and int(l[1]) == phase])
+            assert rows.shape == (n, 2 + nu + 1 + 2 + nu), (name, phase, rows.shape)
+            rc1, u1, relax = rows[:, 1].astype(int), rows[:, 2:2 + nu], rows[:, 2 + nu]
+            x, ud = np.ascontiguousarray(rows[:, 3 + nu:5 + nu]), np.ascontiguousarray(rows[:, 5 + nu:])
+            o = oracle.default_options(model, variant)
+            if keep:
+                o.npSSmax = keep
+            if phase == 1:
+                o.relaxCost, o.relaxLb = 20.0, 2.0
+            ua, rl, rc = oracle.filter_batch(model, variant, o, x, ud, oracle.SOLVER_EXACT, uact_init=np.full((n, nu), 7.0))
+            assert np.array_equal(rc1, rc), (name, phase, np.where(rc1 != rc)[0][:8])
+            ok = rc == 1
+            assert ok.sum() >= n // 4
+            failed += int((~ok).sum())
+            assert np.abs(u1[ok] - ua[ok]).max() <= 1e-6, (name, phase)
+            assert np.all(u1[~ok] == 7.0) and np.all(relax[~ok] == -7.0)
+            assert np.abs(relax[ok] - (5.0 if phase == 0 else 2.0)).max() <= 1e-9  # the pinned relaxation variable
+    assert failed >= 1  # the infeasible branch was exercised somewhere
+
+
 def test_host_solver_is_opt_in_and_bounded_by_shape(tmp_path):
     """makeQPWrapper: HOST gives QPWrapperHost for nv <= 3 with a diagonal cost, QPWrapperHip for anything else (the
     robust and realizable classes' lifted problems) and under the default name; QPWrapperHost refuses other shapes."""

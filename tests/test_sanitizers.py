@@ -72,7 +72,8 @@ def test_host_native_code_is_clean_under_asan_and_ubsan(tmp_path):
             ["backup_filters_san", "tb-loop", "300", "0.5", "--solver", "host"],
             ["backup_filters_san", "tbdi-loop", "60", "--solver", "host"],
             ["implicit_rb_san", "6", "--solver", "host"],            # ASIFimplicitRB: host AAF margins, held input, networks
-            ["implicit_rb_san", "6", "plain", "--solver", "host"]]
+            ["implicit_rb_san", "6", "plain", "--solver", "host"],
+            ["explicit_variants_san", "48", "--solver", "host"]]     # class ASIF: two inputs, npSSmax < npSS, updateOptions
     for cmd in runs:
         p = subprocess.run([os.path.join(SAN_DIR, cmd[0])] + cmd[1:], env=env2, capture_output=True, text=True, timeout=900)
         reports = sorted(f for f in os.listdir(tmp_path) if f.startswith(("asan", "ubsan")))
