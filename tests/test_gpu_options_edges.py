@@ -87,6 +87,11 @@ def _with_options(hip, oracle, cfg, **kw):
     # a sharpness whose bevelStop sits within rounding of 1: not the fast step's clamp, the generic chain
     (3, 96, dict(satSharpness=3e-15, backTrajHorizon=0.75, backTrajDt=0.005)),
     (12, 256, dict(satSharpness=1e-12, backTrajHorizon=1.0)),
+    # an input pinned by its bounds (lb == ub): the solver's entry eliminates it before the method runs, so the rows
+    # kernels do not solve in place (k_tb.hip: launch_tb, k_implicit.hip: fuse_mode) -- two launches, same answers
+    (4, 1024, dict(lb=0.3, ub=0.3)),
+    (3, 64, dict(lb=-0.2, ub=-0.2)),
+    (9, 512, dict(lb=0.1, ub=0.1)),
 ])
 def test_non_default_options(hip, oracle, cfg, B, kw):
     o, oo = _with_options(hip, oracle, cfg, **kw)
