@@ -10,25 +10,29 @@ namespace ASIF {
 
 // src/asif_realizable.cpp:5-75
 ASIFrealizable::ASIFrealizable(const uint32_t nx, const uint32_t nu, const double uncertaintyBounds[],
-                               const kernel_t &kernel, DynamicsFn dynamics, const uint32_t npSSmax, const QPSOLVER,
+                               const kernel_t &kernel, DynamicsFn dynamics, const uint32_t npSSmax, const QPSOLVER qpSolverType,
                                const bool diagonalCost)
     : nx_(nx), nu_(nu), uncertaintyBounds_(uncertaintyBounds, uncertaintyBounds + nx), kernel_(kernel),
       nFacets_((uint32_t)kernel.facets.size()), npSS_(kernel.maxCriticalFacets * kernel.maxActiveConstraints),
       npSSmax_((npSSmax > nFacets_) ? nFacets_ : npSSmax),
       nv_((npSSmax_ > 0) ? (nu + npSS_ * 2 * (nu + 1) + 1) : (nu + npSS_ * 2 * (nu + 1))),
       nc_(npSS_ * (nu + 2) + npSSmax_), dynamics_(dynamics), options_(),
-      QPsolver_(new QPWrapperHip(nv_, nc_, diagonalCost)), // the lifted problem itself, src/asif_realizable.cpp:48-53
-      facetSolver_(new QPWrapperHip(nx, 2 * nx + 1, true)), H_(nv_ * nv_, 0.0), c_(nv_, 0.0), A_(nc_ * nv_, 0.0),
+      QPsolver_(makeQPWrapper(qpSolverType, nv_, nc_, diagonalCost)), // the lifted problem itself, src/asif_realizable.cpp:48-53
+      facetSolver_(makeQPWrapper(qpSolverType, nx, 2 * nx + 1, true)), H_(nv_ * nv_, 0.0), c_(nv_, 0.0), A_(nc_ * nv_, 0.0),
       b_(nc_, 0.0), lb_(nv_, 0.0), ub_(nv_, 0.0), A_facet_((2 * nx + 1) * nx, 0.0), b_facet_(2 * nx + 1, 0.0),
       batch_(nullptr), criticalFacets_(kernel.maxCriticalFacets), nCriticalFacets_(0)
 {
 	// facetSolver_ only answers "feasible or not" (:428-429).  When the facet grazes the uncertainty box its two
 	// active rows are nearly parallel and the iterates creep along them; feasibility to 1e-6 is decided long
 	// before the minimiser is resolved to 1e-8 (the reference runs OSQP at 1e-3 here).
-	QPWrapperHip *fs = static_cast<QPWrapperHip *>(facetSolver_);
-	fs->settings.eps_abs = 1e-6;
-	fs->settings.eps_rel = 1e-6;
-	fs->settings.max_iter = 20000;
+	// (QPSOLVER::HOST decides a facet of up to three states exactly, by the active-set method; beyond that at 1e-6 too.)
+	if (QPWrapperHip *fs = dynamic_cast<QPWrapperHip *>(facetSolver_)) {
+		fs->settings.eps_abs = 1e-6;
+		fs->settings.eps_rel = 1e-6;
+		fs->settings.max_iter = 20000;
+	} else if (QPWrapperHost *fh = dynamic_cast<QPWrapperHost *>(facetSolver_)) {
+		fh->epsRel = 1e-6;
+	}
 	if (npSSmax_ > 0) {
 		criticalBarrierFacets_.resize(npSSmax_);
 		hBarrier_.resize(npSSmax_);

@@ -8,10 +8,10 @@
 namespace ASIF {
 
 ASIFrobust::ASIFrobust(const uint32_t nx, const uint32_t nu, const uint32_t npSS, SafetySetFn safetySet,
-                       DynamicsFn dynamics, const uint32_t npSSmax, const QPSOLVER, const bool diagonalCost)
+                       DynamicsFn dynamics, const uint32_t npSSmax, const QPSOLVER qpSolverType, const bool diagonalCost)
     : nx_(nx), nu_(nu), npSS_(npSS), npSSmax_(std::min(npSSmax, npSS)), nv_(nu + 1 + npSSmax_ * 2 * (nu + 1)),
       nc_(npSSmax_ * (1 + (nu + 1))), safetySet_(safetySet), dynamics_(dynamics), options_(),
-      QPsolver_(new QPWrapperHip(nv_, nc_, diagonalCost)), H_(nv_ * nv_, 0.0), c_(nv_, 0.0), A_(nc_ * nv_, 0.0),
+      QPsolver_(makeQPWrapper(qpSolverType, nv_, nc_, diagonalCost)), H_(nv_ * nv_, 0.0), c_(nv_, 0.0), A_(nc_ * nv_, 0.0),
       b_(nc_, 0.0), lb_(nv_, 0.0), ub_(nv_, 0.0), batch_(nullptr)
 {
 }

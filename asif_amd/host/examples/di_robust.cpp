@@ -3,7 +3,7 @@
 // a text file ("N" then N lines "a0 a1"; tests write it from asif_amd/data/robust_halfplanes.json).
 // Single-agent filter() (host affine arithmetic, the full 22-variable QP on the GPU's wave-per-QP kernel) next to
 // filterBatch() on the same states, which are read from stdin as "x0 x1 uDes" lines.
-//   usage: di_robust halfplanes.txt < states.txt      |      di_robust halfplanes.txt --loop STEPS   (the example's main loop)
+//   usage: di_robust [--solver host] halfplanes.txt < states.txt      |      di_robust halfplanes.txt --loop STEPS   (the example's main loop)
 //   prints  i,uAct,relax,rc,uActBatch,relaxBatch,rcBatch  and  "A,<i>,<nc*nv row entries>" lines
 #include <asif++.h>
 #include <cstdio>
@@ -34,6 +34,15 @@ static void dynamics(const interval_t *x, interval_t *f, interval_t *g)
 
 int main(int argc, char **argv)
 {
+	QPSOLVER solver = QPSOLVER::HIP; // `--solver host`: single-agent filter() only, the QP on the calling thread, no device
+	for (int i = 1; i + 1 < argc; i++)
+		if (!std::strcmp(argv[i], "--solver")) {
+			if (!std::strcmp(argv[i + 1], "host")) solver = QPSOLVER::HOST;
+			for (int j = i; j + 2 < argc; j++) argv[j] = argv[j + 2];
+			argc -= 2;
+			break;
+		}
+	const bool host = solver == QPSOLVER::HOST;
 	if (argc < 2) return 2;
 	FILE *fp = std::fopen(argv[1], "r");
 	if (!fp) return 2;
@@ -55,11 +64,11 @@ int main(int argc, char **argv)
 	ASIF::ASIFrobust::Options opts;
 	opts.relaxCost = 50.0;
 	opts.relaxLb = 5.0;
-	ASIF::ASIFrobust flt(2, 1, (uint32_t)N, safetySet, dynamics, 5);
+	ASIF::ASIFrobust flt(2, 1, (uint32_t)N, safetySet, dynamics, 5, solver);
 	if (flt.initialize(lb, ub, opts) != 1) return 3;
 	asif_hip_robust_data_options md;
 	asif_hip_default_robust_data_options(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_ROBUST, &md); // same m, K, F intervals
-	if (flt.bindDeviceData(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_ROBUST, flat.data(), N, md) != 0) return 3;
+	if (!host && flt.bindDeviceData(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_ROBUST, flat.data(), N, md) != 0) return 3;
 
 	if (argc > 3 && !std::strcmp(argv[2], "--loop")) {
 		// the example's own loop (examples/DoubleIntegrator_Robust.cpp:88-131): from rest with uDes = 20, the plant stepped
@@ -92,7 +101,7 @@ int main(int argc, char **argv)
 		bx[i] = xs[2 * i];
 		bx[n + i] = xs[2 * i + 1];
 	}
-	if (flt.filterBatch(n, bx.data(), us.data(), ba.data(), br.data(), brc.data()) != 0) return 4;
+	if (!host && flt.filterBatch(n, bx.data(), us.data(), ba.data(), br.data(), brc.data()) != 0) return 4;
 	std::printf("i,uAct,relax,rc,uActBatch,relaxBatch,rcBatch\n");
 	for (long i = 0; i < n; i++) {
 		const double x[2] = {xs[2 * i], xs[2 * i + 1]}, ud[1] = {us[i]};

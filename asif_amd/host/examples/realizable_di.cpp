@@ -6,7 +6,7 @@
 //     nFacets lines    v0 v1  n0 n1  a_0 .. a_{maxActive-1}
 // Single-agent filter() (facet QPs and the eliminated QP on the GPU through QPWrapperHip, affine arithmetic on
 // the host) next to filterBatch() on the same states, which are read from stdin as "x0 x1 uDes" lines.
-//   usage: realizable_di kernel.txt < states.txt      |      realizable_di kernel.txt --loop STEPS   (the example's main loop)
+//   usage: realizable_di [--solver host] kernel.txt < states.txt      |      realizable_di kernel.txt --loop STEPS   (the example's main loop)
 //   prints  i,uAct,relax0,relax1,rc,nCrit,uActBatch,relax1Batch,rcBatch  and  "A,<i>,<nc*nv row entries>" / "b,<i>,..."
 #include <asif++.h>
 #include <cstdio>
@@ -27,6 +27,15 @@ static void dynamics(const interval_t *x, interval_t *f, interval_t *g)
 
 int main(int argc, char **argv)
 {
+	QPSOLVER solver = QPSOLVER::HIP; // `--solver host`: single-agent filter() only, the QP on the calling thread, no device
+	for (int i = 1; i + 1 < argc; i++)
+		if (!std::strcmp(argv[i], "--solver")) {
+			if (!std::strcmp(argv[i + 1], "host")) solver = QPSOLVER::HOST;
+			for (int j = i; j + 2 < argc; j++) argv[j] = argv[j + 2];
+			argc -= 2;
+			break;
+		}
+	const bool host = solver == QPSOLVER::HOST;
 	if (argc < 2) return 2;
 	FILE *fp = std::fopen(argv[1], "r");
 	if (!fp) return 2;
@@ -59,11 +68,11 @@ int main(int argc, char **argv)
 	opts.relaxCost = 100.0;
 	opts.relaxOffset = 0.0;
 	opts.relaxDes = 10.0;
-	ASIF::ASIFrealizable flt(2, 1, xUncertainty, kernel, dynamics, 2);
+	ASIF::ASIFrealizable flt(2, 1, xUncertainty, kernel, dynamics, 2, solver);
 	if (flt.initialize(lb, ub, opts) != 1) return 3;
 	asif_hip_realizable_options md;
 	asif_hip_default_realizable_options(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_SAMPLED, &md); // same m, K, F intervals
-	if (flt.bindDeviceModel(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_SAMPLED, md) != 0) return 3;
+	if (!host && flt.bindDeviceModel(ASIF_HIP_MODEL_DOUBLE_INTEGRATOR_SAMPLED, md) != 0) return 3;
 
 	if (argc > 3 && !std::strcmp(argv[2], "--loop")) {
 		// the example's own loop (examples/DoubleIntegrator_RealizableSampled.cpp:96-190): the plant stepped at 1 kHz with
@@ -116,7 +125,7 @@ int main(int argc, char **argv)
 		bx[i] = xs[2 * i];
 		bx[N + i] = xs[2 * i + 1];
 	}
-	if (flt.filterBatch(N, bx.data(), us.data(), ba.data(), br.data(), brc.data()) != 0) return 4;
+	if (!host && flt.filterBatch(N, bx.data(), us.data(), ba.data(), br.data(), brc.data()) != 0) return 4;
 	std::printf("i,uAct,relax0,relax1,rc,nCrit,uActBatch,relax1Batch,rcBatch\n");
 	for (long i = 0; i < N; i++) {
 		const double x[2] = {xs[2 * i], xs[2 * i + 1]}, ud[1] = {us[i]};

@@ -2,7 +2,7 @@
 // (ROBUST flavour: g[1] in [0.8, 1.2]) with the box half-planes of SURVEY 8(d): single-agent filter()
 // (affine-arithmetic rows on the host, the full 18-variable QP on the GPU's wave-per-QP kernel) next to
 // filterBatch() on the same seeded states.
-//   usage: robust_pendulum --loop STEPS [P [UDES]]   (the example's main loop)   |   robust_pendulum N    prints  i,uAct,relax,rc,uActBatch,rcBatch, then "A,<i>,<216 row entries>" lines
+//   usage: robust_pendulum [--solver host] --loop STEPS [P [UDES]]   (the example's main loop)   |   robust_pendulum N    prints  i,uAct,relax,rc,uActBatch,rcBatch, then "A,<i>,<216 row entries>" lines
 #include <asif++.h>
 #include <cmath>
 #include <cstdio>
@@ -40,6 +40,15 @@ static double rng(uint64_t seed, uint64_t i, uint64_t j)
 
 int main(int argc, char **argv)
 {
+	QPSOLVER solver = QPSOLVER::HIP; // `--solver host`: single-agent filter() only, the QP on the calling thread, no device
+	for (int i = 1; i + 1 < argc; i++)
+		if (!std::strcmp(argv[i], "--solver")) {
+			if (!std::strcmp(argv[i + 1], "host")) solver = QPSOLVER::HOST;
+			for (int j = i; j + 2 < argc; j++) argv[j] = argv[j + 2];
+			argc -= 2;
+			break;
+		}
+	const bool host = solver == QPSOLVER::HOST;
 	const long N = argc > 1 ? std::atol(argv[1]) : 16;
 	const double a = 1.0 / M_PI;
 	SafetySetData = {{a, 0}, {-a, 0}, {0, a}, {0, -a}};
@@ -47,11 +56,11 @@ int main(int argc, char **argv)
 	ASIF::ASIFrobust::Options opts; // examples/InvertedPendulum_Robust.cpp:120-121
 	opts.relaxCost = 50.0;
 	opts.relaxLb = 5.0;
-	ASIF::ASIFrobust flt(2, 1, (uint32_t)SafetySetData.size(), safetySet, dynamics);
+	ASIF::ASIFrobust flt(2, 1, (uint32_t)SafetySetData.size(), safetySet, dynamics, (uint32_t)-1, solver);
 	if (flt.initialize(lb, ub, opts) != 1) return 3;
 	asif_hip_options md;
 	asif_hip_default_options(ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST, ASIF_HIP_ROBUST, &md); // same half-planes, pMin, pMax
-	if (flt.bindDeviceModel(ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST, md) != 0) return 3;
+	if (!host && flt.bindDeviceModel(ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST, md) != 0) return 3;
 	if (argc > 2 && !std::strcmp(argv[1], "--loop")) {
 		// the example's own loop (examples/InvertedPendulum_Robust.cpp:134-175, ROBUST flavour): from (0.5, 0) with
 		// uDes = 0 by default; UDES = +-1.5 drives the velocity into its half-plane, where the filter takes the input
@@ -79,7 +88,7 @@ int main(int argc, char **argv)
 		bx[N + i] = -3.0 + 6.0 * rng(4, i, 1);
 		bu[i] = -1.5 + 3.0 * rng(4, i, 2);
 	}
-	if (flt.filterBatch(N, bx.data(), bu.data(), ba.data(), br.data(), brc.data()) != 0) return 4;
+	if (!host && flt.filterBatch(N, bx.data(), bu.data(), ba.data(), br.data(), brc.data()) != 0) return 4;
 	std::printf("i,uAct,relax,rc,uActBatch,rcBatch\n");
 	for (long i = 0; i < N; i++) {
 		const double x[2] = {bx[i], bx[N + i]}, ud[1] = {bu[i]};

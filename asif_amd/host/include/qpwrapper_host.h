@@ -8,8 +8,12 @@
 // loudly, and the batched path (filterBatch, the C ABI) has no host solver at all.  Never the test oracle.
 //
 // Shapes: diagonal cost with positive curvature on every variable, nv <= 3, nc <= 64 -- class ASIF (nv 2),
-// ASIFimplicit / ASIFimplicitRB (nv 3, nc up to 64), ASIFimplicitTB (nv 2).  Anything else: initialize() returns
-// ASIF_HIP_EUNSUPPORTED (the classes' constructors hand such shapes to QPWrapperHip instead).
+// ASIFimplicit / ASIFimplicitRB (nv 3, nc up to 64), ASIFimplicitTB (nv 2), ASIFrealizable's facet test (2 x 5) -- on
+// the active-set method.  Every other shape up to 128 x 128, full cost matrices included -- the lifted problems of
+// ASIFrobust (18 x 12, 22 x 15) and ASIFrealizable (38 x 29, 62 x 47, 86 x 65) -- runs the wave kernels' method
+// (proximal method of multipliers + semismooth Newton, qp_alm_host.cpp) with a dense Cholesky factor: 50 us - 2.3 ms
+// per solve on one core.  Beyond that: initialize() returns ASIF_HIP_EUNSUPPORTED (the classes' constructors hand
+// such shapes to QPWrapperHip instead).
 // Statuses as QPWrapperOsqp::solve (src/qpwrapper_osqp.cpp:225-238): 1, or OSQP's raw value -- -3 primal infeasible;
 // -2 (max_iter) for non-finite data, as the device path, and for an instance the method leaves undecided (none on any
 // seeded workload: tests/test_gi_host.py).
@@ -25,10 +29,15 @@ namespace ASIF {
 
 class QPWrapperHost : public QPWrapperAbstract {
 public:
-	static constexpr uint32_t kMaxNv = 3, kMaxNc = 64;
-	static bool supports(const uint32_t nv, const uint32_t nc, const bool diagonalCost)
+	static constexpr uint32_t kMaxNv = 3, kMaxNc = 64;      // active-set stage
+	static constexpr uint32_t kMaxNvAlm = 128, kMaxNcAlm = 128; // Newton stage
+	static bool activeSet(const uint32_t nv, const uint32_t nc, const bool diagonalCost)
 	{
 		return diagonalCost && nv >= 1 && nv <= kMaxNv && nc <= kMaxNc;
+	}
+	static bool supports(const uint32_t nv, const uint32_t nc, const bool diagonalCost)
+	{
+		return activeSet(nv, nc, diagonalCost) || (nv >= 1 && nv <= kMaxNvAlm && nc <= kMaxNcAlm);
 	}
 
 	QPWrapperHost(const uint32_t nv, const uint32_t nc, const bool diagonalCost);
@@ -43,10 +52,12 @@ public:
 	virtual int32_t solve(void);
 	virtual int32_t getSolution(double sol[]);
 
-	int32_t lastSteps(void) const { return steps_; } // working-set changes of the last solve
+	int32_t lastSteps(void) const { return steps_; } // working-set changes (active-set stage) / Newton steps of the last solve
+	double epsRel = 1e-8;                             // Newton stage: scaled residuals to epsRel / 100, as the kernels
+	int32_t maxNewton = 400;
 
 private:
-	std::vector<double> Hd_, c_, A_, b_, lb_, ub_, sol_;
+	std::vector<double> H_, Hd_, c_, A_, b_, lb_, ub_, sol_;
 	int32_t status_, steps_;
 	bool ready_;
 };

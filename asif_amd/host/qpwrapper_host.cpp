@@ -7,6 +7,11 @@
 
 namespace ASIF {
 
+namespace hostqp {
+int solve_alm(int nv, int nc, bool diag, const double *H, const double *c, const double *A, const double *b,
+              const double *lb, const double *ub, const bool *be, double eps_rel, int max_newton, double *sol, int *newton_out);
+}
+
 namespace {
 
 // row capacities the method is instantiated for (rows beyond nc are inert: 0 . x >= -1e20, as on the device)
@@ -48,7 +53,7 @@ int run_nv(const uint32_t nc, const double *Hd, const double *c, const double *A
 } // namespace
 
 QPWrapperHost::QPWrapperHost(const uint32_t nv, const uint32_t nc, const bool diagonalCost)
-    : QPWrapperAbstract(nv, nc, diagonalCost), Hd_(nv, 0.0), c_(nv, 0.0), A_((size_t)nc * nv, 0.0), b_(nc, 0.0),
+    : QPWrapperAbstract(nv, nc, diagonalCost), H_(activeSet(nv, nc, diagonalCost) ? 0 : (size_t)nv * nv, 0.0), Hd_(nv, 0.0), c_(nv, 0.0), A_((size_t)nc * nv, 0.0), b_(nc, 0.0),
       lb_(nv, 0.0), ub_(nv, 0.0), sol_(nv, 0.0), status_(-10), steps_(0), ready_(false)
 {
 }
@@ -72,8 +77,10 @@ int32_t QPWrapperHost::initialize(const double H[], const double c[], const doub
 
 int32_t QPWrapperHost::updateCost(const double H[], const double c[])
 {
-	if (H != nullptr)
+	if (H != nullptr) {
 		for (uint32_t i = 0; i < nv_; i++) Hd_[i] = H[i + (size_t)i * nv_]; // the diagonal, src/qpwrapper_osqp.cpp:267-272
+		if (!H_.empty()) std::memcpy(H_.data(), H, sizeof(double) * nv_ * nv_); // (upper triangle read when !diagonalCost_)
+	}
 	if (c != nullptr) std::memcpy(c_.data(), c, sizeof(double) * nv_);
 	return 1;
 }
@@ -100,6 +107,13 @@ int32_t QPWrapperHost::updateBounds(const double lb[], const double ub[])
 int32_t QPWrapperHost::solve(void)
 {
 	if (!ready_) return (status_ = -10); // OSQP's "unsolved": solve() before initialize()
+	if (!activeSet(nv_, nc_, diagonalCost_)) {
+		int nw = 0;
+		status_ = hostqp::solve_alm((int)nv_, (int)nc_, diagonalCost_, H_.data(), c_.data(), A_.data(), b_.data(), lb_.data(),
+		                            ub_.data(), be_, epsRel, maxNewton, sol_.data(), &nw);
+		steps_ = nw;
+		return status_;
+	}
 	int verdict;
 	switch (nv_) {
 	case 1: verdict = run_nv<1>(nc_, Hd_.data(), c_.data(), A_.data(), b_.data(), lb_.data(), ub_.data(), be_, sol_.data(), steps_); break;

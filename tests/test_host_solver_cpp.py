@@ -51,6 +51,37 @@ def test_implicit_rb_class_and_learned_residual_on_the_host_solver(oracle, plain
     gpu_twin.check_implicit_rb_class(oracle, plain, "host")
 
 
+def test_robust_class_on_the_host_solver(oracle):
+    """ASIF::ASIFrobust, single agent: affine-arithmetic rows bit-identical to the oracle's, the full 18 x 12 problem --
+    multipliers and all, as src/asif_robust.cpp hands it to its solver -- on QPWrapperHost's Newton stage
+    (asif_amd/host/qp_alm_host.cpp): every return code, input and relaxation against the exact optimum."""
+    gpu_twin.check_robust_class(oracle, "host")
+
+
+@pytest.mark.parametrize("p,ud,steps", [(0.8, 0.0, 280), (1.0, 1.5, 155), (1.2, -1.5, 210)])
+def test_robust_pendulum_closed_loop_on_the_host_solver(oracle, p, ud, steps):
+    gpu_twin.check_robust_pendulum_closed_loop(oracle, p, ud, steps, "host")
+
+
+def test_robust_class_on_shipped_data_on_the_host_solver(oracle, tmp_path):
+    """examples/DoubleIntegrator_Robust.cpp's filter (22 x 15, the shipped half-planes): infeasible instances included."""
+    gpu_twin.check_robust_class_on_shipped_data(oracle, tmp_path, "host")
+
+
+def test_double_integrator_robust_closed_loop_on_the_host_solver(oracle, tmp_path):
+    gpu_twin.check_double_integrator_robust_closed_loop(oracle, tmp_path, "host")
+
+
+def test_realizable_class_on_the_host_solver(oracle, tmp_path):
+    """ASIF::ASIFrealizable, single agent: the facet tests (2 x 5) on the active-set stage, the lifted 38 x 29 problem on
+    the Newton stage; critical-facet counts, rows, return codes 1 / -2 and inputs against the oracle."""
+    gpu_twin.check_realizable_class(oracle, tmp_path, "host")
+
+
+def test_realizable_sampled_closed_loop_on_the_host_solver(oracle, tmp_path):
+    gpu_twin.check_realizable_sampled_closed_loop(oracle, tmp_path, "host")
+
+
 def test_explicit_class_two_inputs_and_reduced_row_budget_on_the_host_solver(oracle):
     """class ASIF beyond the shipped example, on QPWrapperHost: a model with two inputs (nv = 3, five rows) and the double
     integrator with npSSmax = 2 of its 4 rows (src/asif.cpp:250-268), before and after initialize(options) +
@@ -86,21 +117,34 @@ def test_explicit_class_two_inputs_and_reduced_row_budget_on_the_host_solver(ora
 
 
 def test_host_solver_is_opt_in_and_bounded_by_shape(tmp_path):
-    """makeQPWrapper: HOST gives QPWrapperHost for nv <= 3 with a diagonal cost, QPWrapperHip for anything else (the
-    robust and realizable classes' lifted problems) and under the default name; QPWrapperHost refuses other shapes."""
+    """makeQPWrapper: HOST gives QPWrapperHost up to 128 x 128 (the robust and realizable classes' lifted problems and
+    full cost matrices on its Newton stage), QPWrapperHip beyond that and under the default name; QPWrapperHost refuses
+    larger shapes."""
     src = tmp_path / "t.cpp"
     src.write_text(r"""
 #include <asif++.h>
 #include <cstdio>
+#include <vector>
 int main() {
 	using namespace ASIF;
 	QPWrapperAbstract *a = makeQPWrapper(QPSOLVER::HOST, 2, 4, true), *b = makeQPWrapper(QPSOLVER::HOST, 18, 12, true),
-	                  *c = makeQPWrapper(QPSOLVER::HOST, 3, 41, false), *d = makeQPWrapper(QPSOLVER::OSQP, 2, 4, true);
-	std::printf("%d %d %d %d\n", dynamic_cast<QPWrapperHost *>(a) != nullptr, dynamic_cast<QPWrapperHip *>(b) != nullptr,
-	            dynamic_cast<QPWrapperHip *>(c) != nullptr, dynamic_cast<QPWrapperHip *>(d) != nullptr);
-	QPWrapperHost big(4, 4, true);
-	const double H[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, z[16] = {0};
-	std::printf("%d\n", big.initialize(H, z, z, z, z, z));
+	                  *c = makeQPWrapper(QPSOLVER::HOST, 3, 41, false), *d = makeQPWrapper(QPSOLVER::OSQP, 2, 4, true),
+	                  *e = makeQPWrapper(QPSOLVER::HOST, 129, 4, true), *f = makeQPWrapper(QPSOLVER::OSQP, 18, 12, true);
+	std::printf("%d %d %d %d %d %d\n", dynamic_cast<QPWrapperHost *>(a) != nullptr, dynamic_cast<QPWrapperHost *>(b) != nullptr,
+	            dynamic_cast<QPWrapperHost *>(c) != nullptr, dynamic_cast<QPWrapperHip *>(d) != nullptr,
+	            dynamic_cast<QPWrapperHip *>(e) != nullptr, dynamic_cast<QPWrapperHip *>(f) != nullptr);
+	QPWrapperHost big(129, 1, true);
+	std::vector<double> H(129 * 129, 0.0), z(129, 0.0);
+	std::printf("%d\n", big.initialize(H.data(), z.data(), z.data(), z.data(), z.data(), z.data()));
+	// full cost matrix on the Newton stage: min x'Hx + c'x, H = [[2,1],[1,3]] (upper triangle read), x1 + x2 >= 1, 0 <= x <= 0.9
+	{
+		QPWrapperHost w(2, 1, false);
+		const double Hf[4] = {2, 99, 1, 3}, cf[2] = {-2, -6}, Af[2] = {1, 1}, bf[1] = {1}, l[2] = {0, 0}, u[2] = {0.9, 0.9};
+		double x[2];
+		const int r = w.initialize(Hf, cf, Af, bf, l, u), st = w.solve();
+		w.getSolution(x);
+		std::printf("%d %d %.15g %.15g\n", r, st, x[0], x[1]);
+	}
 	// a 2 x 4 problem of class ASIF: min (u - 1)^2 + 50 (d - 5)^2, u <= 0.25 by the first row, d pinned at 5
 	const double H2[4] = {1, 0, 0, 50}, c2[2] = {-2, -500}, A2[8] = {-1, 0, 0, 0, 0, 0, 0, 0}, b2[4] = {-0.25, -1e20, -1e20, -1e20},
 	             lb2[2] = {-1, 5}, ub2[2] = {1, 5};
@@ -121,8 +165,10 @@ int main() {
                            "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "asif_amd"),
                            "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60).stdout.split("\n")
-    assert out[0] == "1 1 1 1"
+    assert out[0] == "1 1 1 1 1 1"
     assert int(out[1]) < 0  # ASIF_HIP_EUNSUPPORTED
-    r0, r1, u, d = out[2].split()
+    r, st, x0, x1 = out[2].split()  # unconstrained minimiser (0, 1) clipped: x1 = 0.9, then 4 x0 + 2 x1 - 2 = 0 -> 0.05; row: 0.1
+    assert (int(r), int(st)) == (0, 1) and abs(float(x0) - 0.1) <= 1e-7 and abs(float(x1) - 0.9) <= 1e-7
+    r0, r1, u, d = out[3].split()
     assert (int(r0), int(r1)) == (0, 1) and float(u) == 0.25 and float(d) == 5.0
-    assert int(out[3]) == -3  # OSQP's primal-infeasible value, raw (src/qpwrapper_osqp.cpp:225-238)
+    assert int(out[4]) == -3  # OSQP's primal-infeasible value, raw (src/qpwrapper_osqp.cpp:225-238)

@@ -1,6 +1,7 @@
 """The suite's host-side native code under AddressSanitizer + UndefinedBehaviorSanitizer (SURVEY.md section 5, row
 "host tests under -fsanitize=address,undefined"): `make -C tests san` builds the CPU oracle (oracle/*.c), the product's
-dual active-set solver compiled for the host (asif_amd/csrc/gi_small.hpp behind tests/host_gi_driver.cpp), the
+dual active-set solver compiled for the host (asif_amd/csrc/gi_small.hpp behind tests/host_gi_driver.cpp), QPWrapperHost's
+Newton stage (asif_amd/host/qp_alm_host.cpp), the
 multi-device ownership rules (multi_own.hpp), the mirror's host affine arithmetic (asif_affine.h) and the mirror's
 classes themselves (asif_amd/host/*.cpp behind the example programs, run with `--solver host`) with
 -fsanitize=address,undefined -fno-sanitize-recover=all, and the existing host cases run on those builds in a child
@@ -21,6 +22,7 @@ SAN_DIR = os.path.join(ROOT, "tests", "_san")
 # the host cases: everything that loads native code of this repo without a GPU, sized for minutes under the sanitizers
 CASES = [
     "tests/test_gi_host.py",
+    "tests/test_alm_host.py",
     "tests/test_host_affine.py",
     "tests/test_capi_host.py::test_create_multi_releases_everything_exactly_once",
     "tests/test_oracle_qp.py",
@@ -73,7 +75,20 @@ def test_host_native_code_is_clean_under_asan_and_ubsan(tmp_path):
             ["backup_filters_san", "tbdi-loop", "60", "--solver", "host"],
             ["implicit_rb_san", "6", "--solver", "host"],            # ASIFimplicitRB: host AAF margins, held input, networks
             ["implicit_rb_san", "6", "plain", "--solver", "host"],
-            ["explicit_variants_san", "48", "--solver", "host"]]     # class ASIF: two inputs, npSSmax < npSS, updateOptions
+            ["explicit_variants_san", "48", "--solver", "host"],     # class ASIF: two inputs, npSSmax < npSS, updateOptions
+            ["robust_pendulum_san", "--solver", "host", "24"],       # ASIFrobust: host AAF rows, 18 x 12 on the Newton stage
+            ["robust_pendulum_san", "--solver", "host", "--loop", "60", "1.0", "1.5"]]
+    # the two classes built from data files (the shipped half-planes; the 100 Hz kernel): files written from the fixtures
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    import test_gpu_host_cpp as twin
+    hp = oracle_lib.load_halfplanes()
+    hfile, kfile = str(tmp_path / "hp.txt"), str(tmp_path / "kernel.txt")
+    with open(hfile, "w") as f:
+        f.write(f"{hp.shape[0]}\n" + "".join(f"{float(a[0])!r} {float(a[1])!r}\n" for a in hp))
+    twin._write_kernel(oracle_lib.load_kernel("100Hz"), kfile)
+    runs += [["di_robust_san", "--solver", "host", hfile, "--loop", "120"],      # 22 x 15, infeasible steps included
+             ["realizable_di_san", "--solver", "host", kfile, "--loop", "600"]]  # facet tests (2 x 5) + 38 x 29
     for cmd in runs:
         p = subprocess.run([os.path.join(SAN_DIR, cmd[0])] + cmd[1:], env=env2, capture_output=True, text=True, timeout=900)
         reports = sorted(f for f in os.listdir(tmp_path) if f.startswith(("asan", "ubsan")))
