@@ -8,8 +8,10 @@
 // J = rows outside their interval) with an exact line search on the piecewise-linear derivative; outer update
 // y <- mu (s - proj s), xhat <- x; termination on scaled residuals (1e-10), OSQP's primal-infeasibility certificate on
 // the dual increment; penalties raised by the factor the observed contraction asks for (penalty_jump).  What differs is
-// the linear algebra -- a dense Cholesky factor of K_J here, where the kernels keep an inverse by rank-one steps or a
-// factor in LDS -- and nothing else: selected BY NAME (QPSOLVER::HOST), never a fallback, never the test oracle.
+// the linear algebra -- a dense Cholesky factor of K_J here, rebuilt when J changes, where the kernels keep an inverse
+// by rank-one steps or a factor in LDS -- and the bookkeeping around it (no polish stage, a scalar line search over
+// sorted breakpoints); iterates are therefore not bit-identical to the kernels', the bar is the same (status on every
+// instance, 1e-6 on u: tests/test_alm_host.py).  Selected BY NAME (QPSOLVER::HOST), never a fallback, never the oracle.
 // Form translation as QPWrapperOsqp (src/qpwrapper_osqp.cpp:263-376): P = 2H, rows [A; I], l = [b; lb], u = [inf | b; ub].
 #include <algorithm>
 #include <cmath>
