@@ -169,6 +169,7 @@ static int launch_lds(const asif_hip_solver &S0, const QpArgs &a, hipStream_t st
 
 // nv <= 32, nc <= 32, diagonal cost: two QPs per wave, the inverse of K_J kept by rank-one steps (qp_inv.hpp).
 // Shapes are padded to the next compiled size <NVMAX, NCMAX>.
+constexpr int64_t kInvTwoWavesMin = 16384;
 template <int NVMAX, int NCMAX, int HW = 32>
 static int launch_inv(const asif_hip_solver &S0, const QpArgs &a, hipStream_t stream)
 {
@@ -178,6 +179,9 @@ static int launch_inv(const asif_hip_solver &S0, const QpArgs &a, hipStream_t st
 	constexpr int QPW = 64 / HW;
 	const size_t bytes = QPW * inv_half_doubles(NVMAX, NCMAX, HW) * sizeof(double);
 	auto kern = qp_inv_kernel<NVMAX, NCMAX, HW>;
+	if constexpr (HW == 32) {
+		if (a.B >= kInvTwoWavesMin) kern = qp_inv_kernel<NVMAX, NCMAX, HW, 2>; // eight waves' worth of problems per SIMD: qp_inv.hpp, MINW
+	}
 	if (bytes > 48 * 1024) {
 		hipError_t e = allow_dynamic_lds((const void *)kern, bytes);
 		if (e != hipSuccess) return (int)e;

@@ -73,6 +73,40 @@ __host__ __device__ inline size_t lds_doubles(int nv, int nc, int vpt, int rpt, 
 	return n;
 }
 
+// The two rows of 16 of every group of 32, side by side: a = the even row's value in both rows, b = the odd row's
+// (v_permlane16_swap_b32, new on gfx950: a vector instruction where ds_swizzle went through the LDS path and a
+// wait for it, in every one of the dozen reductions of a Newton step).  rows32 likewise for the two halves of the wave.
+#ifndef ASIF_INV_SWIZZLE
+__device__ __forceinline__ void rows16(double v, double &a, double &b)
+{
+	const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+	const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+	const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+	a = __hiloint2double((int)rh[0], (int)rl[0]);
+	b = __hiloint2double((int)rh[1], (int)rl[1]);
+}
+#else
+__device__ __forceinline__ void rows16(double v, double &a, double &b) // (the ds_swizzle form, for comparison builds)
+{
+	const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F);
+	const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
+	const double o = __hiloint2double(hi, lo);
+	const bool odd = (threadIdx.x & 16) != 0;
+	a = odd ? o : v;
+	b = odd ? v : o;
+}
+#endif
+__device__ __forceinline__ void rows32(double v, double &a, double &b)
+{
+	const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+	const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+	const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+	a = __hiloint2double((int)rh[0], (int)rl[0]);
+	b = __hiloint2double((int)rh[1], (int)rl[1]);
+}
+// whole-wave reductions, the xor butterfly: four DPP steps inside the rows of 16, then the rows of a group of 32, then
+// the two groups (the same pairs in the same order as six __shfl_xor stages, whose two widest went through ds_bpermute)
+#ifdef ASIF_LDS_SHFL // comparison builds: the __shfl_xor form
 __device__ __forceinline__ double wmax(double v)
 {
 #pragma unroll
@@ -91,6 +125,44 @@ __device__ __forceinline__ double wsum(double v)
 	for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
 	return v;
 }
+#else
+__device__ __forceinline__ double wmax(double v)
+{
+	v = fmax(v, dpp_xchg<1>(v));
+	v = fmax(v, dpp_xchg<2>(v));
+	v = fmax(v, dpp_xchg<4>(v));
+	v = fmax(v, dpp_xchg<8>(v));
+	double a, b;
+	rows16(v, a, b);
+	v = fmax(a, b);
+	rows32(v, a, b);
+	return fmax(a, b);
+}
+__device__ __forceinline__ double wmin(double v)
+{
+	v = fmin(v, dpp_xchg<1>(v));
+	v = fmin(v, dpp_xchg<2>(v));
+	v = fmin(v, dpp_xchg<4>(v));
+	v = fmin(v, dpp_xchg<8>(v));
+	double a, b;
+	rows16(v, a, b);
+	v = fmin(a, b);
+	rows32(v, a, b);
+	return fmin(a, b);
+}
+__device__ __forceinline__ double wsum(double v)
+{
+	v += dpp_xchg<1>(v);
+	v += dpp_xchg<2>(v);
+	v += dpp_xchg<4>(v);
+	v += dpp_xchg<8>(v);
+	double a, b;
+	rows16(v, a, b);
+	v = a + b;
+	rows32(v, a, b);
+	return a + b;
+}
+#endif
 __device__ __forceinline__ double lane_get(double v, int src) // src wave-uniform
 {
 	const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
