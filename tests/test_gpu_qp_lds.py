@@ -43,6 +43,21 @@ def test_robust_full_18x12_every_instance(hip, oracle):
     assert it.max() < 400
 
 
+def test_two_waves_per_simd_instantiation_gives_the_same_bits(hip, oracle):
+    """From 16 384 problems on the half-wave kernel is launched with its register allocation held to two waves per
+    SIMD (k_qp.hip: kInvTwoWavesMin) -- other code, with spills: same solution, status and Newton count, bit for
+    bit, as the one-wave build gives the same problems in a batch of 4 096."""
+    d, Hd, c, A, b, lb, ub, be = _config_qps(oracle, 5, 4096)
+    sol1, st1, it1 = _solve(hip, Hd, c, A, b, lb, ub, be)
+    rep = lambda a: np.tile(a, (4, 1))
+    sol4, st4, it4 = _solve(hip, rep(Hd), rep(c), rep(A), rep(b), rep(lb), rep(ub), be)
+    assert len(st4) == 16384 and np.all(st1 == 1)
+    for k in range(4):
+        blk = slice(4096 * k, 4096 * (k + 1))
+        assert np.array_equal(st4[blk], st1) and np.array_equal(it4[blk], it1)
+        assert np.array_equal(sol4[blk], sol1)
+
+
 def test_robust_data_22x15_every_status(hip, oracle):
     hp = oracle.load_halfplanes()
     z = oracle.RobustData(hp)
