@@ -151,13 +151,27 @@ int launch_qp_wave(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream
 }
 
 template <int VPT, int RPT, bool FULLH>
-static int launch_lds(const asif_hip_solver &S0, const QpArgs &a, hipStream_t stream)
+static int launch_lds(const asif_hip_solver &S0, const QpArgs &a_in, hipStream_t stream)
 {
 	asif_hip_solver S = S0;
 	if (S.scaling_iters == 0) S.scaling_iters = 4;
 	else if (S.scaling_iters < 0) S.scaling_iters = 0;
-	const size_t bytes = lds_doubles(a.nv, a.nc, VPT, RPT, FULLH) * sizeof(double);
+	QpArgs a = a_in;
+	size_t bytes = lds_doubles(a.nv, a.nc, VPT, RPT, FULLH) * sizeof(double);
 	if (bytes > 160 * 1024) return ASIF_HIP_EUNSUPPORTED;
+	{
+		// K_J kept between Newton steps where the shape leaves room for it (qp_lds.hpp, build<true>); ASIF_HIP_QP_KEEP_KJ=0:
+		// developer switch, the full sum at every change of the active set
+		static const bool off = []() {
+			const char *v = getenv("ASIF_HIP_QP_KEEP_KJ");
+			return v && v[0] == '0';
+		}();
+		const size_t with = lds_doubles(a.nv, a.nc, VPT, RPT, FULLH, true) * sizeof(double);
+		if (!off && with <= 160 * 1024) {
+			a.keep_kj = 1;
+			bytes = with;
+		}
+	}
 	auto kern = qp_lds_kernel<VPT, RPT, FULLH>;
 	if (bytes > 48 * 1024) {
 		hipError_t e = allow_dynamic_lds((const void *)kern, bytes);

@@ -141,6 +141,7 @@ struct QpArgs {
 	const double *H;   // full cost matrix [nv*nv][ld] (column-major, upper triangle read) or nullptr: Hd is used
 	uint64_t be_mask2; // rows 64..127
 	int only_status = 0; // != 0: a second pass -- only instances whose status[] holds this value are solved (again)
+	int keep_kj = 0;     // qp_lds.hpp: the shape's LDS has room for the unfactored K_J between Newton steps (set by the launcher)
 };
 // pre-assembled QPs; returns ASIF_HIP_EUNSUPPORTED for shapes without a compiled kernel
 int launch_qp_small(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream);

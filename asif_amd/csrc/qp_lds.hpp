@@ -55,16 +55,18 @@ __host__ __device__ inline double penalty_jump(double pri, double pri_prev)
 	const double f = (1.0 / kLdsRhoTarget - 1.0) / (1.0 / rho - 1.0);
 	return f < 10.0 ? 10.0 : (f > 1e6 ? 1e6 : f);
 }
+constexpr int kLdsMaxDeltas = 16; // rank-one updates of the kept K_J between two full sums (LdsQp::build)
 constexpr int kLdsMaxOuter = 80;
 constexpr int kLdsMaxInner = 60;
 
 __host__ __device__ inline int lds_rs(int nc) { return (nc < 1 ? 1 : nc) | 1; }
 __host__ __device__ inline int lds_nvp(int nv) { return nv | 1; }
 // doubles of dynamic LDS for a shape
-__host__ __device__ inline size_t lds_doubles(int nv, int nc, int vpt, int rpt, bool fullh)
+__host__ __device__ inline size_t lds_doubles(int nv, int nc, int vpt, int rpt, bool fullh, bool kp = false)
 {
 	size_t n = (size_t)nv * lds_rs(nc) + (size_t)nv * lds_nvp(nv);
 	if (fullh) n += (size_t)nv * (nv + 1) / 2;
+	if (kp) n += (size_t)nv * (nv + 1) / 2; // the unfactored K_J kept between Newton steps (LdsQp::build<true>)
 	n += 64 * vpt * 2;                 // va, dinv
 	n += 64 * rpt;                     // vr
 	n += 5 * (64 * (size_t)(rpt + vpt)); // line-search view of all rows: s, dl, l, u, mu
@@ -173,7 +175,7 @@ __device__ __forceinline__ double lane_get(double v, int src) // src wave-unifor
 template <int VPT, int RPT, bool FULLH>
 struct LdsQp {
 	// LDS
-	double *At, *S, *Pp, *va, *dinv, *vr, *ls_s, *ls_d, *ls_l, *ls_u, *ls_m, *ls_t;
+	double *At, *S, *Pp, *Kp, *va, *dinv, *vr, *ls_s, *ls_d, *ls_l, *ls_u, *ls_m, *ls_t;
 	int *alist;
 	int lane, nv, nc, RS, NVP, nact;
 	// variables owned by this lane
@@ -351,18 +353,30 @@ struct LdsQp {
 
 	// S <- P + I/gamma + sum_{i active} mu_i a_i a_i' + diag(active bounds), then LDL' in place.
 	// actr / actb: this lane's rows / bounds currently outside their interval.
-	__device__ __forceinline__ void build(const bool (&actr)[RPT], const bool (&actb)[VPT])
+	//
+	// DELTA (shapes whose LDS has room for it: Kp, the unfactored K_J, upper triangle packed by columns -- lane j's column
+	// is contiguous): K_J is kept from one Newton step to the next and only the rows and bounds that ENTERED or LEFT the
+	// active set since (inr / inb: what Kp holds) are added or taken out, each a rank-one term; S is Kp's copy, factored
+	// in place as before.  The full sum is O(|J| nv^2) per Newton step -- half the kernel's time at 86 x 65, where most
+	// of the 65 rows are equalities that never leave -- the update O(changes nv^2).  A term taken out leaves the rounding
+	// of its two additions behind (eps mu |a|^2, against a diagonal that may be 1/gamma): the caller rebuilds in full
+	// whenever the penalties change and after kLdsMaxDeltas updates in a row; the gradient and the line search never
+	// see K_J, so its accuracy can cost Newton steps, not the answer.
+	template <bool DELTA>
+	__device__ __forceinline__ void build(const bool (&actr)[RPT], const bool (&actb)[VPT], bool (&inr)[RPT], bool (&inb)[VPT])
 	{
-		// compact list of the active general rows + their weights
+		// compact list of the general rows to add (DELTA: or to take out) + their weights
 		int base = 0;
 #pragma unroll
 		for (int r = 0; r < RPT; r++) {
-			const bool a = isr[r] && actr[r];
+			const bool act = isr[r] && actr[r];
+			const bool a = DELTA ? (act != inr[r]) : act;
 			const unsigned long long m = __ballot(a);
 			const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
 			if (a) alist[pos] = vj(r);
 			base += __popcll(m);
-			vr[vj(r)] = mu[r];
+			vr[vj(r)] = (DELTA && !act) ? -mu[r] : mu[r];
+			inr[r] = act;
 		}
 		nact = base;
 		sync();
@@ -373,11 +387,20 @@ struct LdsQp {
 		for (int k = 0; k < VPT; k++) {
 			const int j = vj(k);
 			if (isv[k]) {
+				const double bnew = actb[k] ? mub[k] * ab[k] * ab[k] : 0.0, bold = inb[k] ? mub[k] * ab[k] * ab[k] : 0.0;
 				auto finish = [&](int c, double sv) { // entry (c, j) of K_J, c <= j
-					if constexpr (FULLH) sv += Pp[pidx(c, j)];
-					if (c == j) {
-						if constexpr (!FULLH) sv += Pd[k];
-						sv += 1.0 / kLdsGamma + (actb[k] ? mub[k] * ab[k] * ab[k] : 0.0);
+					if constexpr (DELTA) {
+						double *kp = Kp + pidx(c, j);
+						if (c == j) sv += bnew - bold;
+						sv += *kp;
+						*kp = sv;
+					} else {
+						if constexpr (FULLH) sv += Pp[pidx(c, j)];
+						if (c == j) {
+							if constexpr (!FULLH) sv += Pd[k];
+							sv += 1.0 / kLdsGamma + bnew;
+						}
+						if (Kp) Kp[pidx(c, j)] = sv;
 					}
 					S[c * NVP + j] = sv;
 				};
@@ -408,6 +431,7 @@ struct LdsQp {
 					if (c0 <= j) finish(c0, acc);
 				}
 			}
+			inb[k] = actb[k];
 		}
 		sync();
 	}
@@ -535,6 +559,7 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 		s.At = p; p += (size_t)nv * s.RS;
 		s.S = p; p += (size_t)nv * s.NVP;
 		s.Pp = p; if (FULLH) p += (size_t)nv * (nv + 1) / 2;
+		s.Kp = a.keep_kj ? p : nullptr; if (a.keep_kj) p += (size_t)nv * (nv + 1) / 2;
 		s.va = p; p += 64 * VPT;
 		s.dinv = p; p += 64 * VPT;
 		s.vr = p; p += 64 * RPT;
@@ -604,7 +629,8 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 	const double big = kInfty * kMinScaling;
 	const int max_newton = S_.max_iter > 0 ? S_.max_iter : 4000;
 	int status = 0, newton = 0;
-	bool have_factor = false, fact_ok = true;
+	bool have_factor = false, fact_ok = true, kj_valid = false;
+	int deltas = 0;
 	bool pactr[RPT], pactb[VPT];
 #pragma unroll
 	for (int r = 0; r < RPT; r++) pactr[r] = false;
@@ -690,14 +716,18 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 			if (newton >= max_newton) break;
 			// ---- Newton direction on the current active set
 			if (__any(changed)) {
-				s.build(actr, actb);
+				// (pactr / pactb double as "what Kp holds": build() brings them up to date)
+				if (kj_valid && deltas < kLdsMaxDeltas) {
+					s.template build<true>(actr, actb, pactr, pactb);
+					deltas++;
+				} else {
+					s.template build<false>(actr, actb, pactr, pactb);
+					kj_valid = s.Kp != nullptr;
+					deltas = 0;
+				}
 				LDS_T(6)
 				fact_ok = s.factor() && fact_ok;
 				have_factor = true;
-#pragma unroll
-				for (int r = 0; r < RPT; r++) pactr[r] = actr[r];
-#pragma unroll
-				for (int k = 0; k < VPT; k++) pactb[k] = actb[k];
 			}
 			LDS_T(1)
 			double d[VPT];
@@ -896,6 +926,7 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 #pragma unroll
 				for (int k = 0; k < VPT; k++) s.mub[k] = f > 1.0 ? fmin(s.mub[k] * f, fmax(s.mub[k], cap)) : fmax(s.mub[k] * f, kLdsMu0);
 				have_factor = false;
+				kj_valid = false; // the rows' weights in Kp are the old penalties
 			}
 		}
 		pri_prev = pri;
