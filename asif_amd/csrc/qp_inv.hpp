@@ -252,6 +252,20 @@ struct InvQp {
 		sync();
 		return s0 + s1;
 	}
+	// K^-1 a_i for a row of the block: its coefficients are read where they lie (column i of At; the padding is zero),
+	// no broadcast vector to write and wait for
+	__device__ __forceinline__ double kinv_row(int i)
+	{
+		double s0 = 0.0, s1 = 0.0;
+		const double *col = At + i;
+#pragma unroll
+		for (int j = 0; j < NVMAX; j += 2) {
+			s0 += Kr[j] * lds1<HW>(col + j * RS);
+			s1 += Kr[j + 1] * lds1<HW>(col + (j + 1) * RS);
+			if (j % 8 == 6) __builtin_amdgcn_sched_barrier(0);
+		}
+		return s0 + s1;
+	}
 	// K^-1 <- (K + c v v')^-1 given u = K^-1 v in every lane's ut (its own component) and vu = v'u:
 	// K^-1 -= u u' c / (1 + c vu)
 	__device__ __forceinline__ void rank_one(double ut, double vu, double c, bool on)
@@ -517,7 +531,7 @@ __global__ __launch_bounds__(64, MINW) void qp_inv_kernel(asif_hip_solver S_, Qp
 					const int i = on ? __ffsll((long long)m) - 1 : 0;
 					const double at = s.isv ? s.At[t * RS + i] : 0.0;
 					const double c = s.vr[i];
-					const double ut = s.kinv_mul(at);
+					const double ut = s.kinv_row(i);
 					const double vu = hsum<HW>(at * ut);
 					s.rank_one(ut, vu, c, on);
 #ifdef ASIF_INV_PROFILE

@@ -1,4 +1,3 @@
-(tools/dev_inv_ab.sh asif_amd/libasif_hip.so; python tools/dev_rz_time.py 10Hz_50pt 8 2>/dev/null | tail -1
-for K in 100Hz 10Hz_50pt; do ASIF_HIP_LIB=$PWD/asif_amd/csrc/build/ab/invprof.so python tools/dev_inv_sections_rz.py $K 1 2>/dev/null | grep "upkeep\|rebuilds\|newton mean"; done) > gpurun_out/inv_diagb.txt 2>&1
-cat gpurun_out/inv_diagb.txt
+(tools/dev_inv_ab.sh asif_amd/libasif_hip.so; python tools/dev_rz_time.py 10Hz_50pt 8 2>/dev/null | tail -1) > gpurun_out/inv_row.txt 2>&1
+cat gpurun_out/inv_row.txt
 timeout -k 10 900 python -m pytest tests/test_gpu_qp_lds.py tests/test_gpu_qp_generic.py tests/test_gpu_realizable.py -x -q 2>&1 | tail -5
