@@ -183,7 +183,10 @@ static int launch_lds(const asif_hip_solver &S0, const QpArgs &a_in, hipStream_t
 
 // nv <= 32, nc <= 32, diagonal cost: two QPs per wave, the inverse of K_J kept by rank-one steps (qp_inv.hpp).
 // Shapes are padded to the next compiled size <NVMAX, NCMAX>.
-constexpr int64_t kInvTwoWavesMin = 16384;
+#ifndef ASIF_INV_TWO_WAVES_MIN
+#define ASIF_INV_TWO_WAVES_MIN 16384
+#endif
+constexpr int64_t kInvTwoWavesMin = ASIF_INV_TWO_WAVES_MIN;
 template <int NVMAX, int NCMAX, int HW = 32>
 static int launch_inv(const asif_hip_solver &S0, const QpArgs &a, hipStream_t stream)
 {
