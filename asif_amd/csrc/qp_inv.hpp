@@ -119,11 +119,14 @@ __device__ __forceinline__ unsigned long long hballot(bool p, int h)
 // never paired (order is kept, which the LDS does anyway).  18 x 12, 8 192 problems: 305 -> 283 us, bits unchanged.
 // The whole-wave variant (HW = 64: one problem per wave, 38 x 29) is bound by its own instruction count instead and
 // keeps the paired reads (unpaired: 2.51 -> 2.75 ms).
-template <int HW>
+// ... except at 64 padded variables (62 x 47): there the paired form needs far more than the 512 registers a wave has
+// (298 spilled: part of the inverse's row lives in scratch and is reloaded term by term in every product; the single
+// reads 116): 7.09 -> 5.49 ms per 6 456.
+template <int HW, int NVMAX>
 __device__ __forceinline__ double lds1(const double *p)
 {
 #ifndef ASIF_INV_PAIRED_READS
-	if constexpr (HW == 32) return *(const volatile __attribute__((address_space(3))) double *)p; // (p points into LDS: every caller's arrays do)
+	if constexpr (HW == 32 || NVMAX > 40) return *(const volatile __attribute__((address_space(3))) double *)p; // (p points into LDS: every caller's arrays do)
 #endif
 	return *p;
 }
@@ -156,8 +159,8 @@ struct InvQp {
 		const double *col = At + (t < NCMAX ? t : 0); // lanes beyond the padded rows shadow row 0 and are masked
 #pragma unroll
 		for (int j = 0; j < NVMAX; j += 2) {
-			s0 += (ABS ? fabs(lds1<HW>(col + j * RS)) : lds1<HW>(col + j * RS)) * lds1<HW>(va + j);
-			s1 += (ABS ? fabs(lds1<HW>(col + (j + 1) * RS)) : lds1<HW>(col + (j + 1) * RS)) * lds1<HW>(va + j + 1);
+			s0 += (ABS ? fabs(lds1<HW, NVMAX>(col + j * RS)) : lds1<HW, NVMAX>(col + j * RS)) * lds1<HW, NVMAX>(va + j);
+			s1 += (ABS ? fabs(lds1<HW, NVMAX>(col + (j + 1) * RS)) : lds1<HW, NVMAX>(col + (j + 1) * RS)) * lds1<HW, NVMAX>(va + j + 1);
 			if (j % 8 == 6) __builtin_amdgcn_sched_barrier(0); // eight terms' loads in flight, not all of them: registers
 		}
 		sync();
@@ -173,8 +176,8 @@ struct InvQp {
 		const double *row = At + (t < NVMAX ? t : 0) * RS; // lanes beyond the padded variables read row 0 and are masked by the caller
 #pragma unroll
 		for (int i = 0; i < NCMAX; i += 2) {
-			s0 += (ABS ? fabs(lds1<HW>(row + i)) : lds1<HW>(row + i)) * lds1<HW>(vr + i);
-			s1 += (ABS ? fabs(lds1<HW>(row + i + 1)) : lds1<HW>(row + i + 1)) * lds1<HW>(vr + i + 1);
+			s0 += (ABS ? fabs(lds1<HW, NVMAX>(row + i)) : lds1<HW, NVMAX>(row + i)) * lds1<HW, NVMAX>(vr + i);
+			s1 += (ABS ? fabs(lds1<HW, NVMAX>(row + i + 1)) : lds1<HW, NVMAX>(row + i + 1)) * lds1<HW, NVMAX>(vr + i + 1);
 			if (i % 8 == 6) __builtin_amdgcn_sched_barrier(0);
 		}
 		sync();
@@ -189,7 +192,7 @@ struct InvQp {
 		const double *col = At + (t < NCMAX ? t : 0);
 #pragma unroll
 		for (int j = 0; j < NVMAX; j++) {
-			const double a = lds1<HW>(col + j * RS), b = lds1<HW>(va + j);
+			const double a = lds1<HW, NVMAX>(col + j * RS), b = lds1<HW, NVMAX>(va + j);
 			s0 += a * b;
 			s1 += fabs(a) * fabs(b);
 			if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
@@ -207,7 +210,7 @@ struct InvQp {
 		const double *row = At + (t < NVMAX ? t : 0) * RS;
 #pragma unroll
 		for (int i = 0; i < NCMAX; i++) {
-			const double a = lds1<HW>(row + i), b = lds1<HW>(vr + i);
+			const double a = lds1<HW, NVMAX>(row + i), b = lds1<HW, NVMAX>(vr + i);
 			s0 += a * b;
 			s1 += fabs(a) * fabs(b);
 			if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
@@ -226,10 +229,10 @@ struct InvQp {
 		const double *row = At + (t < NVMAX ? t : 0) * RS;
 #pragma unroll
 		for (int i = 0; i < NCMAX; i++) {
-			const double a = lds1<HW>(row + i), b = lds1<HW>(vr + i);
+			const double a = lds1<HW, NVMAX>(row + i), b = lds1<HW, NVMAX>(vr + i);
 			s0 += a * b;
 			s1 += fabs(a) * fabs(b);
-			s2 += a * lds1<HW>(rb + i);
+			s2 += a * lds1<HW, NVMAX>(rb + i);
 			if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
 		}
 		sync();
@@ -245,8 +248,8 @@ struct InvQp {
 		double s0 = 0.0, s1 = 0.0;
 #pragma unroll
 		for (int j = 0; j < NVMAX; j += 2) {
-			s0 += Kr[j] * lds1<HW>(va + j);
-			s1 += Kr[j + 1] * lds1<HW>(va + j + 1);
+			s0 += Kr[j] * lds1<HW, NVMAX>(va + j);
+			s1 += Kr[j + 1] * lds1<HW, NVMAX>(va + j + 1);
 			if (j % 8 == 6) __builtin_amdgcn_sched_barrier(0);
 		}
 		sync();
@@ -260,8 +263,8 @@ struct InvQp {
 		const double *col = At + i;
 #pragma unroll
 		for (int j = 0; j < NVMAX; j += 2) {
-			s0 += Kr[j] * lds1<HW>(col + j * RS);
-			s1 += Kr[j + 1] * lds1<HW>(col + (j + 1) * RS);
+			s0 += Kr[j] * lds1<HW, NVMAX>(col + j * RS);
+			s1 += Kr[j + 1] * lds1<HW, NVMAX>(col + (j + 1) * RS);
 			if (j % 8 == 6) __builtin_amdgcn_sched_barrier(0);
 		}
 		return s0 + s1;
@@ -275,7 +278,7 @@ struct InvQp {
 		const double coef = on ? c * fast_rcp(1.0 + c * vu) * ut : 0.0; // denominator >= 1
 #pragma unroll
 		for (int j = 0; j < NVMAX; j++) {
-			Kr[j] -= coef * lds1<HW>(rb + j);
+			Kr[j] -= coef * lds1<HW, NVMAX>(rb + j);
 			if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
 		}
 		sync();
@@ -616,17 +619,17 @@ __global__ __launch_bounds__(64, MINW) void qp_inv_kernel(asif_hip_solver S_, Qp
 						double f0 = qa + tt * a1, f1c = 0.0;
 #pragma unroll 2
 						for (int i = 0; i < NCMAX; i += 2) { // general rows (padding rows carry mu dl = 0)
-							const double st = lds1<HW>(s.ls_s + i) + tt * lds1<HW>(s.ls_d + i);
-							f0 += lds1<HW>(s.ls_m + i) * (st - fmin(fmax(st, lds1<HW>(s.ls_l + i)), lds1<HW>(s.ls_u + i)));
-							const double su = lds1<HW>(s.ls_s + i + 1) + tt * lds1<HW>(s.ls_d + i + 1);
-							f1c += lds1<HW>(s.ls_m + i + 1) * (su - fmin(fmax(su, lds1<HW>(s.ls_l + i + 1)), lds1<HW>(s.ls_u + i + 1)));
+							const double st = lds1<HW, NVMAX>(s.ls_s + i) + tt * lds1<HW, NVMAX>(s.ls_d + i);
+							f0 += lds1<HW, NVMAX>(s.ls_m + i) * (st - fmin(fmax(st, lds1<HW, NVMAX>(s.ls_l + i)), lds1<HW, NVMAX>(s.ls_u + i)));
+							const double su = lds1<HW, NVMAX>(s.ls_s + i + 1) + tt * lds1<HW, NVMAX>(s.ls_d + i + 1);
+							f1c += lds1<HW, NVMAX>(s.ls_m + i + 1) * (su - fmin(fmax(su, lds1<HW, NVMAX>(s.ls_l + i + 1)), lds1<HW, NVMAX>(s.ls_u + i + 1)));
 						}
 #pragma unroll 2
 						for (int i = HW; i < HW + NVMAX; i += 2) { // bounds
-							const double st = lds1<HW>(s.ls_s + i) + tt * lds1<HW>(s.ls_d + i);
-							f0 += lds1<HW>(s.ls_m + i) * (st - fmin(fmax(st, lds1<HW>(s.ls_l + i)), lds1<HW>(s.ls_u + i)));
-							const double su = lds1<HW>(s.ls_s + i + 1) + tt * lds1<HW>(s.ls_d + i + 1);
-							f1c += lds1<HW>(s.ls_m + i + 1) * (su - fmin(fmax(su, lds1<HW>(s.ls_l + i + 1)), lds1<HW>(s.ls_u + i + 1)));
+							const double st = lds1<HW, NVMAX>(s.ls_s + i) + tt * lds1<HW, NVMAX>(s.ls_d + i);
+							f0 += lds1<HW, NVMAX>(s.ls_m + i) * (st - fmin(fmax(st, lds1<HW, NVMAX>(s.ls_l + i)), lds1<HW, NVMAX>(s.ls_u + i)));
+							const double su = lds1<HW, NVMAX>(s.ls_s + i + 1) + tt * lds1<HW, NVMAX>(s.ls_d + i + 1);
+							f1c += lds1<HW, NVMAX>(s.ls_m + i + 1) * (su - fmin(fmax(su, lds1<HW, NVMAX>(s.ls_l + i + 1)), lds1<HW, NVMAX>(s.ls_u + i + 1)));
 						}
 						return f0 + f1c;
 					};
