@@ -10,7 +10,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from asif_amd import capi  # noqa: E402
-capi.LIB_PATH = os.path.join(ROOT, "asif_amd/csrc/build/variants/libasif_ldsprof.so")
+# (the profiling build is named by ASIF_HIP_LIB: tools/build_variant.sh <name> "k_qp.hip" "-DASIF_..._PROFILE")
 import bench  # noqa: E402
 
 dev = torch.device("cuda:0")
