@@ -58,6 +58,36 @@ def test_two_waves_per_simd_instantiation_gives_the_same_bits(hip, oracle):
         assert np.array_equal(sol4[blk], sol1)
 
 
+@pytest.mark.parametrize("nv,nc", [(12, 20), (19, 30), (23, 12), (23, 28), (30, 14), (31, 32), (36, 50), (50, 60), (64, 64)])
+def test_every_padded_instantiation_of_the_inverse_kernel(hip, oracle, nv, nc):
+    """One random family per compiled size of qp_inv.hpp -- <20,32>, <24,16>, <24,32>, <32,16>, <32,32> on half a wave,
+    <40,64>, <64,64> on a whole one (18 x 12, 22 x 15, 38 x 29 and 62 x 47 above cover the others): a strictly feasible
+    point by construction, one equality row, the first eight problems made infeasible; against the oracle's ADMM run
+    to 1e-10."""
+    rng = np.random.default_rng(1000 * nv + nc)
+    B = 48
+    Hd = rng.uniform(0.5, 3.0, (B, nv))
+    c = rng.normal(0, 2, (B, nv))
+    A = rng.normal(0, 1, (B, nc * nv))
+    x0 = rng.normal(0, 1, (B, nv))
+    Am = A.reshape(B, nv, nc).transpose(0, 2, 1)
+    b = np.einsum("brv,bv->br", Am, x0) - rng.uniform(0, 1, (B, nc))
+    be = np.zeros(nc, dtype=np.uint8)
+    be[0] = 1
+    b[:, 0] = np.einsum("bv,bv->b", Am[:, 0], x0)
+    lb = x0 - rng.uniform(0.1, 2, (B, nv))
+    ub = x0 + rng.uniform(0.1, 2, (B, nv))
+    b[:8, 1] += 1000.0  # row 1 cannot be met inside the box
+    s = oracle.admm_settings(eps_abs=1e-10, eps_rel=1e-10, max_iter=200000)
+    ref, stref, _ = oracle.qp_solve_batch(nv, nc, Hd, c, A, b, lb, ub, be, oracle.SOLVER_ADMM, s)
+    sol, st, it = _solve(hip, Hd, c, A, b, lb, ub, be)
+    assert np.all(stref[:8] != 1) and np.all(st[:8] == -3)
+    assert np.all(st[8:] == 1) and np.all(stref[8:] == 1)
+    assert np.abs(sol[8:] - ref[8:]).max() <= U_TOL
+    res = np.einsum("brv,bv->br", Am, sol) - b
+    assert res[8:, 1:].min() >= -1e-6 and np.abs(res[8:, 0]).max() <= 1e-6
+
+
 def test_robust_data_22x15_every_status(hip, oracle):
     hp = oracle.load_halfplanes()
     z = oracle.RobustData(hp)
