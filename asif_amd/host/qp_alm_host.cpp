@@ -122,8 +122,7 @@ int solve_alm(int nv, int nc, bool diag, const double *H, const double *c, const
 		}
 	}
 	// power-of-two Ruiz equilibration of [P A'; A 0] and cost normalisation (qp_lds.hpp: scale), four passes
-	std::vector<double> D(n, 1.0), E(m, 1.0);
-	double cs = 1.0;
+	std::vector<double> D(n, 1.0), E(m, 1.0); // (the cost's own scale factor is not kept: the minimiser does not depend on it)
 	for (int it = 0; it < 4; it++) {
 		std::vector<double> Dt(n), Et(m);
 		for (int j = 0; j < n; j++) {
@@ -154,7 +153,6 @@ int solve_alm(int nv, int nc, bool diag, const double *H, const double *c, const
 		const double ct = pow2_floor_inv(limit_scaling(std::max(cm / n, limit_scaling(qn))));
 		for (double &v : P) v *= ct;
 		for (double &v : q) v *= ct;
-		cs *= ct;
 	}
 	for (int i = 0; i < m; i++) {
 		l[i] *= E[i];
@@ -336,7 +334,6 @@ int solve_alm(int nv, int nc, bool diag, const double *H, const double *c, const
 	if (status == 0 || status == -2) status = best_res <= 1e3 * tol ? 1 : -2; // OSQP's "solved inaccurate" counts as solved (:225)
 	for (int j = 0; j < n; j++) sol[j] = D[j] * x[j];
 	if (newton_out) *newton_out = newton;
-	(void)cs;
 	return status;
 }
 
