@@ -331,6 +331,7 @@ struct InvQp {
 	}
 };
 
+constexpr int kInvFewBp = 8; // breakpoints of a line search up to which phi' is evaluated at each by a reduction (qp_inv_kernel)
 // status / iters follow asif_hip_qp_solve_batch's contract (QPWrapperOsqp::solve, src/qpwrapper_osqp.cpp:225-238)
 #ifndef ASIF_INV_MIN_WAVES
 #define ASIF_INV_MIN_WAVES 1 // waves per SIMD the register allocation is held to (scratch builds try 2)
@@ -602,6 +603,37 @@ __global__ __launch_bounds__(64, MINW) void qp_inv_kernel(asif_hip_solver S_, Qp
 					double tlo = 0.0, thi = 1.0, fhi = f1;
 					double flo = hsum<HW>(qat + dl * rr + dlb * rbv); // (dl, dlb, rr, rbv are zero on the lanes that own nothing)
 					if (__any(cut && anybp)) {
+					// the breakpoints of this half, side by side in LDS behind the two end points
+					int npt = 2;
+					if (t == 0) s.ls_t[0] = 0.0;
+					if (t == 1) s.ls_t[1] = 1.0;
+#pragma unroll
+					for (int e = 0; e < 4; e++) {
+						const bool v = bp[e] <= 1.0;
+						const unsigned long long m = hballot<HW>(v, h);
+						if (v) s.ls_t[npt + __popcll(m & ((1ull << t) - 1ull))] = bp[e];
+						npt += __popcll(m);
+					}
+					s.sync();
+					double tlo_s = 0.0, flo_s = flo, thi_s = 1.0, fhi_s = f1;
+					const bool few = npt <= 2 + kInvFewBp; // (per half: what a half gets must not depend on its neighbour's count)
+					{
+						// A handful of them (2.5 on average where there is any): phi' at each by ONE reduction, every lane its own
+						// row and bound, instead of every lane a pass over all rows.  The two end values are the ones above.
+						for (int k = 2; __any(cut && few && k < npt); k++) {
+							const bool have = few && k < npt;
+							const double tk = have ? s.ls_t[k] : 1.0;
+							const double sk = sr + tk * dl, skb = sb + tk * dlb;
+							const double fr_k = s.isr ? s.mu * dl * (sk - fmin(fmax(sk, s.l), s.u)) : 0.0;
+							const double fb_k = s.isv ? s.mub * dlb * (skb - fmin(fmax(skb, s.lbs), s.ubs)) : 0.0;
+							const double fk = hsum<HW>(qat + tk * a1t + fr_k + fb_k);
+							// best lower bracket: largest t with f < 0; best upper: smallest t with f >= 0
+							if (have && fk < 0.0 && tk > tlo_s) { tlo_s = tk; flo_s = fk; }
+							if (have && !(fk < 0.0) && tk < thi_s) { thi_s = tk; fhi_s = fk; }
+						}
+					}
+					if (__any(cut && !few)) {
+					double tlo_f = tlo_s, flo_f = flo_s, thi_f = thi_s, fhi_f = fhi_s;
 					const double qa = hsum<HW>(qat), a1 = hsum<HW>(a1t);
 					// all rows (general, then bounds) side by side in LDS
 					s.ls_s[t] = sr;
@@ -614,16 +646,6 @@ __global__ __launch_bounds__(64, MINW) void qp_inv_kernel(asif_hip_solver S_, Qp
 					s.ls_l[HW + t] = s.lbs;
 					s.ls_u[HW + t] = s.ubs;
 					s.ls_m[HW + t] = s.isv ? s.mub * dlb : 0.0;
-					int npt = 2;
-					if (t == 0) s.ls_t[0] = 0.0;
-					if (t == 1) s.ls_t[1] = 1.0;
-#pragma unroll
-					for (int e = 0; e < 4; e++) {
-						const bool v = bp[e] <= 1.0;
-						const unsigned long long m = hballot<HW>(v, h);
-						if (v) s.ls_t[npt + __popcll(m & ((1ull << t) - 1ull))] = bp[e];
-						npt += __popcll(m);
-					}
 					s.sync();
 					auto dphi = [&](double tt) {
 						double f0 = qa + tt * a1, f1c = 0.0;
@@ -644,7 +666,7 @@ __global__ __launch_bounds__(64, MINW) void qp_inv_kernel(asif_hip_solver S_, Qp
 						return f0 + f1c;
 					};
 					// bracket of the zero of phi' among {0} u breakpoints u {1}: every lane evaluates phi' at its own point
-					double tlo_s = 0.0, flo_s = 0.0, thi_s = 2.0, fhi_s = 0.0;
+					tlo_s = 0.0, flo_s = 0.0, thi_s = 2.0, fhi_s = 0.0;
 					for (int base = 0; __any(base < npt); base += HW) {
 						const bool mine = base + t < npt;
 						const double tb = mine ? s.ls_t[base + t] : 1.0;
@@ -669,6 +691,13 @@ __global__ __launch_bounds__(64, MINW) void qp_inv_kernel(asif_hip_solver S_, Qp
 						if (gh < thi_s) { thi_s = gh; fhi_s = fhc; }
 					}
 					s.sync();
+					if (few) { // (a half with few breakpoints keeps what the reductions found)
+						tlo_s = tlo_f;
+						flo_s = flo_f;
+						thi_s = thi_f;
+						fhi_s = fhi_f;
+					}
+					}
 					if (anybp) { // (a half without breakpoints keeps its two end points, whatever its neighbour had to search)
 						tlo = tlo_s;
 						flo = flo_s;
