@@ -49,7 +49,7 @@ EXPORTS = [
     "asif_hip_partition", "asif_hip_create_multi", "asif_hip_multi_destroy", "asif_hip_multi_size",
     "asif_hip_multi_handle", "asif_hip_multi_update_options", "asif_hip_filter_batch_host_multi",
     "asif_hip_filter_batch_lie",
-    "asif_hip_math_probe",
+    "asif_hip_math_probe", "asif_hip_qp_solve_batch_warm",
 ]
 
 MODEL_DOUBLE_INTEGRATOR_SAMPLED = 4
@@ -152,6 +152,8 @@ def load():
         lib.asif_hip_assemble_batch.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp]
         lib.asif_hip_qp_solve_batch.argtypes = [C.c_int, C.POINTER(Solver), i64, i64, C.c_int32, C.c_int32, vp, vp,
                                                 vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.asif_hip_qp_solve_batch_warm.argtypes = [C.c_int, C.POINTER(Solver), i64, i64, C.c_int32, C.c_int32, vp,
+                                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp]
         lib.asif_hip_filter_batch_host.argtypes = [vp, i64, vp, vp, vp, vp, vp]
         lib.asif_hip_default_realizable_options.argtypes = [C.c_int, C.POINTER(RealizableOptions)]
         lib.asif_hip_create_realizable.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(KernelData),
@@ -419,6 +421,23 @@ def qp_solve_batch(Hd, c, A, b, lb, ub, sol, status, iters=None, be=None, solver
     check(load().asif_hip_qp_solve_batch(device, C.byref(s), B, c.stride(0), nv, nc, _ptr(Hd), _ptr(c), _ptr(A),
                                          _ptr(b), _ptr(lb), _ptr(ub), bep, _ptr(sol), _ptr(status), _ptr(iters),
                                          _stream()))
+
+
+def qp_solve_batch_warm(Hd, H, c, A, b, lb, ub, sol, status, warm_x, warm_y, warm_in, iters=None, be=None,
+                        solver=None, device=0):
+    """asif_hip_qp_solve_batch_warm: Hd [nv,B] or H [nv*nv,B] (the other None); warm_x [nv,B], warm_y [nc+nv,B]
+    are written by every call and read first when warm_in is true."""
+    nv, B = c.shape
+    nc = b.shape[0]
+    s = solver if solver is not None else default_solver()
+    bep = None
+    if be is not None:
+        arr = (C.c_uint8 * nc)(*[int(v) for v in be])
+        bep = C.cast(arr, C.c_void_p)
+    check(load().asif_hip_qp_solve_batch_warm(device, C.byref(s), B, c.stride(0), nv, nc, _ptr(Hd), _ptr(H), _ptr(c),
+                                              _ptr(A), _ptr(b), _ptr(lb), _ptr(ub), bep, _ptr(sol), _ptr(status),
+                                              _ptr(iters), _ptr(warm_x), _ptr(warm_y), 1 if warm_in else 0,
+                                              _stream()))
 
 
 def qp_solve_batch_dense(H, c, A, b, lb, ub, sol, status, iters=None, be=None, solver=None, device=0):

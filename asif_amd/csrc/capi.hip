@@ -1044,7 +1044,8 @@ extern "C" int asif_hip_assemble_batch(asif_hip_ctx *ctx, int64_t B, int64_t ldx
 static int qp_solve_common(int device, const asif_hip_solver *solver, int64_t B, int64_t ld, int32_t nv, int32_t nc,
                            const double *Hd, const double *H, const double *c, const double *A, const double *b,
                            const double *lb, const double *ub, const uint8_t *be, double *sol, int32_t *status,
-                           int32_t *iters, void *stream)
+                           int32_t *iters, void *stream, double *warm_x = nullptr, double *warm_y = nullptr,
+                           int warm_in = 0)
 {
 	if (B < 0 || ld < B || nv < 1 || nc < 0) return ASIF_HIP_EINVAL;
 	if (nc > 128 || nv > 128) return ASIF_HIP_EUNSUPPORTED;
@@ -1062,7 +1063,24 @@ static int qp_solve_common(int device, const asif_hip_solver *solver, int64_t B,
 		for (int i = 0; i < nc; i++)
 			if (be[i]) (i < 64 ? mask : mask2) |= (1ull << (i & 63));
 	QpArgs a = {B, ld, nv, nc, Hd, c, A, b, lb, ub, mask, sol, status, iters, H, mask2};
+	if (warm_x && warm_y && S.polish != 0) { // the plain ADMM of polish == 0 has its own two-launch form: cold
+		a.warm_x = warm_x;
+		a.warm_y = warm_y;
+		a.warm_in = warm_in;
+	}
 	return launch_qp_small(S, a, (hipStream_t)stream);
+}
+
+extern "C" int asif_hip_qp_solve_batch_warm(int device, const asif_hip_solver *solver, int64_t B, int64_t ld,
+                                            int32_t nv, int32_t nc, const double *Hd, const double *H, const double *c,
+                                            const double *A, const double *b, const double *lb, const double *ub,
+                                            const uint8_t *be, double *sol, int32_t *status, int32_t *iters,
+                                            double *warm_x, double *warm_y, int32_t warm_in, void *stream)
+{
+	if ((!Hd) == (!H)) return B == 0 && (Hd || H) ? ASIF_HIP_OK : ASIF_HIP_EINVAL; // exactly one form of the cost
+	if (B > 0 && (!warm_x || !warm_y)) return ASIF_HIP_EINVAL;
+	return qp_solve_common(device, solver, B, ld, nv, nc, Hd, H, c, A, b, lb, ub, be, sol, status, iters, stream, warm_x,
+	                       warm_y, warm_in != 0);
 }
 
 extern "C" int asif_hip_qp_solve_batch(int device, const asif_hip_solver *solver, int64_t B, int64_t ld, int32_t nv,

@@ -173,6 +173,7 @@ static int launch_lds(const asif_hip_solver &S0, const QpArgs &a_in, hipStream_t
 		}
 	}
 	auto kern = qp_lds_kernel<VPT, RPT, FULLH>;
+	if (a.warm_x) kern = qp_lds_kernel<VPT, RPT, FULLH, true>;
 	if (bytes > 48 * 1024) {
 		hipError_t e = allow_dynamic_lds((const void *)kern, bytes);
 		if (e != hipSuccess) return (int)e;
@@ -199,6 +200,7 @@ static int launch_inv(const asif_hip_solver &S0, const QpArgs &a, hipStream_t st
 	if constexpr (HW == 32) {
 		if (a.B >= kInvTwoWavesMin) kern = qp_inv_kernel<NVMAX, NCMAX, HW, 2>; // eight waves' worth of problems per SIMD: qp_inv.hpp, MINW
 	}
+	if (a.warm_x) kern = qp_inv_kernel<NVMAX, NCMAX, HW, 1, true>; // closed loops: batches of one to a few thousand
 	if (bytes > 48 * 1024) {
 		hipError_t e = allow_dynamic_lds((const void *)kern, bytes);
 		if (e != hipSuccess) return (int)e;

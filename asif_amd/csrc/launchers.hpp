@@ -142,6 +142,11 @@ struct QpArgs {
 	uint64_t be_mask2; // rows 64..127
 	int only_status = 0; // != 0: a second pass -- only instances whose status[] holds this value are solved (again)
 	int keep_kj = 0;     // qp_lds.hpp: the shape's LDS has room for the unfactored K_J between Newton steps (set by the launcher)
+	// asif_hip_qp_solve_batch_warm (wave-level kernels only): the iterate and the multipliers of [A; I] in the caller's
+	// units, x [nv][ld] and y [nc + nv][ld] -- written at the end of every solve (zeros unless the verdict is "solved"),
+	// read as the starting point when warm_in != 0: OSQP's warm_start = 1 between two solve() calls of one workspace
+	double *warm_x = nullptr, *warm_y = nullptr;
+	int warm_in = 0;
 };
 // pre-assembled QPs; returns ASIF_HIP_EUNSUPPORTED for shapes without a compiled kernel
 int launch_qp_small(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream);

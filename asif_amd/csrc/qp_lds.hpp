@@ -537,7 +537,8 @@ struct LdsQp {
 };
 
 // status / iters follow asif_hip_qp_solve_batch's contract (QPWrapperOsqp::solve, src/qpwrapper_osqp.cpp:225-238)
-template <int VPT, int RPT, bool FULLH>
+// WARM: the instantiation behind asif_hip_qp_solve_batch_warm (qp_inv.hpp: same contract, same units)
+template <int VPT, int RPT, bool FULLH, bool WARM = false>
 __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a)
 {
 	extern __shared__ double lds[];
@@ -625,6 +626,21 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 		s.yb[k] = 0.0;
 		s.mub[k] = (s.ubs[k] - s.lbs[k] < kRhoTol) ? 100.0 * kLdsMu0 : kLdsMu0;
 	}
+	if constexpr (WARM) {
+		if (a.warm_in != 0) {
+			auto sane = [](double v) { return fabs(v) < 1e100 ? v : 0.0; }; // NaN, inf, nonsense: no start
+#pragma unroll
+			for (int k = 0; k < VPT; k++)
+				if (s.isv[k]) {
+					s.x[k] = sane(a.warm_x[(int64_t)s.vj(k) * ld + qi]) / s.D[k];
+					s.xh[k] = s.x[k];
+					s.yb[k] = sane(a.warm_y[(int64_t)(nc + s.vj(k)) * ld + qi]) * s.cs / s.Eb[k];
+				}
+#pragma unroll
+			for (int r = 0; r < RPT; r++)
+				if (s.isr[r]) s.y[r] = sane(a.warm_y[(int64_t)s.vj(r) * ld + qi]) * s.cs / s.E[r];
+		}
+	}
 	const double tol = fmax(S_.eps_rel, 1e-10) * 1e-2; // default eps 1e-8 -> 1e-10 on the scaled residuals
 	const double big = kInfty * kMinScaling;
 	const int max_newton = S_.max_iter > 0 ? S_.max_iter : 4000;
@@ -637,6 +653,7 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 #pragma unroll
 	for (int k = 0; k < VPT; k++) pactb[k] = false;
 	double pri_prev = -1.0, best_res = 1e300;
+	[[maybe_unused]] int met = 0; // WARM: consecutive multiplier updates that met the termination test
 	// section timers of a scratch build (tools/dev_lds_sections.py); compiled out of the library
 #ifdef ASIF_LDS_PROFILE
 	long long tsec[7] = {0, 0, 0, 0, 0, 0, 0}, tmark = __builtin_readcyclecounter();
@@ -897,7 +914,13 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 		ndy = wmax(ndy); lhs = wsum(lhs); natv = wmax(natv);
 		const double rp = pri / (1.0 + nax), rd = dua / (1.0 + nd);
 		best_res = fmin(best_res, fmax(rp, rd));
-		if (rp <= tol && rd <= tol) status = kStatusSolved;
+		bool done = rp <= tol && rd <= tol;
+		if constexpr (WARM) {
+			// a warm solve is done when three multiplier updates in a row meet the test (qp_inv.hpp: why)
+			met = done ? met + 1 : 0;
+			done = done && met >= (a.warm_in != 0 ? 3 : 1);
+		}
+		if (done) status = kStatusSolved;
 		else if (ndy > 1e-4 && lhs < -1e-6 * ndy && natv < 1e-6 * ndy) status = kStatusPrimalInf;
 		else if (newton >= max_newton || !fact_ok) status = kStatusMaxIter;
 		else {
@@ -942,6 +965,18 @@ __global__ __launch_bounds__(64) void qp_lds_kernel(asif_hip_solver S_, QpArgs a
 	if (lane == 0) {
 		a.status[qi] = status;
 		if (a.iters) a.iters[qi] = newton;
+	}
+	if constexpr (WARM) {
+		const bool ok = status == kStatusSolved; // a problem without a solution leaves a cold start behind
+#pragma unroll
+		for (int k = 0; k < VPT; k++)
+			if (s.isv[k]) {
+				a.warm_x[(int64_t)s.vj(k) * ld + qi] = ok ? s.D[k] * s.x[k] : 0.0;
+				a.warm_y[(int64_t)(nc + s.vj(k)) * ld + qi] = ok ? s.Eb[k] * s.yb[k] / s.cs : 0.0;
+			}
+#pragma unroll
+		for (int r = 0; r < RPT; r++)
+			if (s.isr[r]) a.warm_y[(int64_t)s.vj(r) * ld + qi] = ok ? s.E[r] * s.y[r] / s.cs : 0.0;
 	}
 #ifdef ASIF_LDS_PROFILE
 	if (lane == 0)

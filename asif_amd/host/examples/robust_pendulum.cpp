@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -38,6 +40,12 @@ static double rng(uint64_t seed, uint64_t i, uint64_t j)
 	return (double)(z >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// reaches the solver the class made for itself (timing mode below: Newton steps of the last solve)
+struct RobustProbe : ASIF::ASIFrobust {
+	using ASIF::ASIFrobust::ASIFrobust;
+	ASIF::QPWrapperAbstract *solver() { return QPsolver_; }
+};
+
 int main(int argc, char **argv)
 {
 	QPSOLVER solver = QPSOLVER::HIP; // `--solver host`: single-agent filter() only, the QP on the calling thread, no device
@@ -56,7 +64,7 @@ int main(int argc, char **argv)
 	ASIF::ASIFrobust::Options opts; // examples/InvertedPendulum_Robust.cpp:120-121
 	opts.relaxCost = 50.0;
 	opts.relaxLb = 5.0;
-	ASIF::ASIFrobust flt(2, 1, (uint32_t)SafetySetData.size(), safetySet, dynamics, (uint32_t)-1, solver);
+	RobustProbe flt(2, 1, (uint32_t)SafetySetData.size(), safetySet, dynamics, (uint32_t)-1, solver);
 	if (flt.initialize(lb, ub, opts) != 1) return 3;
 	asif_hip_options md;
 	asif_hip_default_options(ASIF_HIP_MODEL_INVERTED_PENDULUM_ROBUST, ASIF_HIP_ROBUST, &md); // same half-planes, pMin, pMax
@@ -79,6 +87,45 @@ int main(int argc, char **argv)
 			const double f[2] = {x[1], std::sin(x[0])}, g[2] = {0., p};
 			for (int k = 0; k < 2; k++) x[k] += dt * (f[k] + g[k] * ua[0]);
 		}
+		return 0;
+	}
+	if (argc > 2 && !std::strcmp(argv[1], "--loop-time")) {
+		// the same loop, timed: one line with the cost of a filter() call (the lifted 18 x 12 problem through the class's
+		// solver: QPWrapperHip, warm-started from the previous control step with ASIF_HIP_QP_WARM=1, or QPWrapperHost)
+		const long steps = std::atol(argv[2]);
+		const double p = argc > 3 ? std::atof(argv[3]) : 1.0, dt = 0.01;
+		double x[2] = {0.5, 0.0};
+		const double ud[1] = {argc > 4 ? std::atof(argv[4]) : 0.0};
+		ASIF::QPWrapperHip *hipSolver = dynamic_cast<ASIF::QPWrapperHip *>(flt.solver());
+		std::vector<double> us(steps), usOk;
+		long newton = 0, maxNewton = 0, ok = 0, newtonOk = 0;
+		for (long i = 0; i < steps; i++) {
+			double ua[1] = {0.0}, rl = 0.0;
+			const auto t0 = std::chrono::steady_clock::now();
+			const int32_t rc = flt.filter(x, ud, ua, rl);
+			us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+			ok += rc == 1;
+			if (rc == 1) usOk.push_back(us[i]);
+			if (hipSolver && rc == 1) newtonOk += hipSolver->lastIterations();
+			if (hipSolver) {
+				newton += hipSolver->lastIterations();
+				maxNewton = std::max<long>(maxNewton, hipSolver->lastIterations());
+			}
+			const double f[2] = {x[1], std::sin(x[0])}, g[2] = {0., p};
+			for (int k = 0; k < 2; k++) x[k] += dt * (f[k] + g[k] * ua[0]);
+		}
+		double mean = 0.0;
+		for (double v : us) mean += v / (double)steps;
+		std::sort(us.begin(), us.end());
+		std::sort(usOk.begin(), usOk.end());
+		// the steps whose problem had a solution are the ones a warm start can speak for (after any other verdict the
+		// next start is cold, in OSQP too)
+		std::printf("{\"steps\": %ld, \"rc_ok\": %ld, \"us_median_rc_ok\": %.3f, \"newton_mean_rc_ok\": %.3f, "
+		            "\"us_median\": %.3f, \"us_mean\": %.3f, \"us_p99\": %.3f, "
+		            "\"newton_mean\": %.3f, \"newton_max\": %ld, \"warm_start\": %d, \"final_x\": [%.17g, %.17g]}\n",
+		            steps, ok, usOk.empty() ? 0.0 : usOk[usOk.size() / 2], ok ? (double)newtonOk / (double)ok : 0.0,
+		            us[steps / 2], mean, us[(size_t)(0.99 * (double)(steps - 1))], (double)newton / (double)steps,
+		            maxNewton, hipSolver ? (int)hipSolver->warmStart : -1, x[0], x[1]);
 		return 0;
 	}
 	std::vector<double> bx(2 * N), bu(N), ba(N, 0.0), br(N, 0.0);

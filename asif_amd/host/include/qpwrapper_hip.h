@@ -1,6 +1,13 @@
 // qpwrapper_hip.h -- ASIF::QPWrapperHip: the reference's solver plug-in slot filled by the MI355X kernels
 // (replaces ASIF::QPWrapperOsqp, include/qpwrapper_osqp.h:9-61 / src/qpwrapper_osqp.cpp).
-// One solve() = asif_hip_qp_solve_batch(_dense) with a batch of one; cold start every call.  Any shape the
+// One solve() = asif_hip_qp_solve_batch_warm with a batch of one.  `warmStart = true` (or ASIF_HIP_QP_WARM=1 in the
+// environment) makes the second and later solve() calls start from the previous call's iterate and multipliers, as an
+// OSQP workspace does (warm_start = 1 by default, which the reference's wrapper leaves on), where the problem runs on
+// a wave-level kernel (nv > 3: the lifted problems of ASIFrobust / ASIFrealizable, full cost matrices).  It is OFF by
+// default: the method's cold start ends in 4 Newton steps on the lifted robust problem and 9 on the realizable ones
+// with |u - u_ref| at 4e-9 ... 1e-7, and a warm one gains where the cost is strictly convex (full H 20 x 30: 18 -> 7
+// steps) or the loop moves little (ASIFrobust's example loop: 3.7 -> 0.9 steps, 42 -> 38 us per filter()), not on a
+// state that moved at random (18 x 12: 4.3 -> 7.0; 86 x 65: 9.5 -> 14) -- DESIGN 4.4, tests/test_gpu_qp_warm.py.  Any shape the
 // reference's classes construct a solver with is accepted (up to 128 variables / 128 rows within 160 KB of LDS:
 // ASIFrealizable's 86 x 65 included), diagonalCost = true or false.
 #pragma once
@@ -39,12 +46,14 @@ public:
 	virtual int32_t getSolution(double sol[]);
 
 	asif_hip_solver settings; // kernel settings (defaults from asif_hip_default_solver)
+	bool warmStart;           // OSQPSettings::warm_start; false by default here (see above)
 	int32_t lastIterations(void) const { return iters_; }
 	int lastError(void) const { return error_; } // 0, a negative ASIF_HIP_E* code or a positive hipError_t
 
 private:
 	int device_;
-	double *host_; // pinned: [H (nv or nv*nv) | c | A | b | lb | ub | sol | status, iterations]
+	double *host_; // pinned: [H (nv or nv*nv) | c | A | b | lb | ub | sol | status, iterations | warm x | warm y]
+	bool haveWarm_; // the warm block holds what a solve() of this problem's shape left there
 	std::vector<uint8_t> be8_;
 	double *dev_;  // the device-side address of that same block (zero copy: the kernel reads and writes it in place)
 	void *stream_;
@@ -59,7 +68,9 @@ private:
 	size_t offUb() const { return offLb() + nv_; }
 	size_t offSol() const { return offUb() + nv_; }
 	size_t offStatus() const { return offSol() + nv_; } // two int32 in one double slot
-	size_t total() const { return offStatus() + 1; }
+	size_t offWarmX() const { return offStatus() + 1; }
+	size_t offWarmY() const { return offWarmX() + nv_; }
+	size_t total() const { return offWarmY() + nc_ + nv_; }
 	int setup(void);
 };
 

@@ -55,11 +55,16 @@ public:
 	int32_t lastSteps(void) const { return steps_; } // working-set changes (active-set stage) / Newton steps of the last solve
 	double epsRel = 1e-8;                             // Newton stage: scaled residuals to epsRel / 100, as the kernels
 	int32_t maxNewton = 400;
+	// Newton stage (nv > 3): true = the second and later solve() calls start from the previous call's iterate and
+	// multipliers, as an OSQP workspace does with its default warm_start = 1.  Off by default for the reasons
+	// qpwrapper_hip.h gives (same method, same measurements).  The active-set stage of the small shapes is exact and
+	// takes no start.
+	bool warmStart = false;
 
 private:
-	std::vector<double> H_, Hd_, c_, A_, b_, lb_, ub_, sol_;
+	std::vector<double> H_, Hd_, c_, A_, b_, lb_, ub_, sol_, warmX_, warmY_;
 	int32_t status_, steps_;
-	bool ready_;
+	bool ready_, haveWarm_ = false;
 };
 
 } // namespace ASIF

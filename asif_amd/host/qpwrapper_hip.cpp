@@ -2,6 +2,7 @@
 // C-ABI call, one download per solve().
 #include "qpwrapper_hip.h"
 #include <hip/hip_runtime_api.h>
+#include <cstdlib>
 #include <cstring>
 
 namespace ASIF {
@@ -10,6 +11,10 @@ QPWrapperHip::QPWrapperHip(const uint32_t nv, const uint32_t nc, const bool diag
     : QPWrapperAbstract(nv, nc, diagonalCost), device_(device), host_(nullptr), dev_(nullptr), stream_(nullptr),
       status_(0), iters_(0), error_(0)
 {
+	// off unless asked for (include/qpwrapper_hip.h: why); ASIF_HIP_QP_WARM=1 switches it on without a rebuild
+	const char *w = std::getenv("ASIF_HIP_QP_WARM");
+	warmStart = w && w[0] == '1';
+	haveWarm_ = false;
 	asif_hip_default_solver(&settings);
 	be8_.assign(nc_ > 0 ? nc_ : 1, 0);
 }
@@ -43,6 +48,7 @@ int32_t QPWrapperHip::initialize(const double H[], const double c[], const doubl
                                  const double lb[], const double ub[], const bool be[])
 {
 	if ((error_ = setup()) != 0) return error_;
+	haveWarm_ = false; // osqp_setup: a fresh workspace, its first solve is cold
 	if (be != nullptr)
 		for (uint32_t i = 0; i < nc_; i++) be_[i] = be[i];
 	for (uint32_t i = 0; i < nc_; i++) be8_[i] = be_[i] ? 1 : 0;
@@ -105,15 +111,13 @@ int32_t QPWrapperHip::solve(void)
 	}
 	// batch of one: component k of the single instance sits at base[k] (ld = 1)
 	int32_t *dst = (int32_t *)(dev_ + offStatus());
-	int r;
-	if (diagonalCost_)
-		r = asif_hip_qp_solve_batch(device_, &settings, 1, 1, (int32_t)nv_, (int32_t)nc_, dev_ + offH(), dev_ + offC(),
-		                            dev_ + offA(), dev_ + offB(), dev_ + offLb(), dev_ + offUb(), be8_.data(),
-		                            dev_ + offSol(), dst, dst + 1, stream_);
-	else
-		r = asif_hip_qp_solve_batch_dense(device_, &settings, 1, 1, (int32_t)nv_, (int32_t)nc_, dev_ + offH(),
-		                                  dev_ + offC(), dev_ + offA(), dev_ + offB(), dev_ + offLb(), dev_ + offUb(),
-		                                  be8_.data(), dev_ + offSol(), dst, dst + 1, stream_);
+	const bool diag = diagonalCost_;
+	const int r = asif_hip_qp_solve_batch_warm(device_, &settings, 1, 1, (int32_t)nv_, (int32_t)nc_,
+	                                           diag ? dev_ + offH() : nullptr, diag ? nullptr : dev_ + offH(),
+	                                           dev_ + offC(), dev_ + offA(), dev_ + offB(), dev_ + offLb(),
+	                                           dev_ + offUb(), be8_.data(), dev_ + offSol(), dst, dst + 1,
+	                                           dev_ + offWarmX(), dev_ + offWarmY(), warmStart && haveWarm_ ? 1 : 0,
+	                                           stream_);
 	if (r != 0) {
 		error_ = r;
 		return STATUS_UNSOLVED;
@@ -128,6 +132,7 @@ int32_t QPWrapperHip::solve(void)
 	status_ = st[0];
 	iters_ = st[1];
 	error_ = 0;
+	haveWarm_ = true; // (zeros after a verdict other than "solved": the next start is cold then, as OSQP's is)
 	return status_;
 }
 

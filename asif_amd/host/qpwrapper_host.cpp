@@ -9,7 +9,8 @@ namespace ASIF {
 
 namespace hostqp {
 int solve_alm(int nv, int nc, bool diag, const double *H, const double *c, const double *A, const double *b,
-              const double *lb, const double *ub, const bool *be, double eps_rel, int max_newton, double *sol, int *newton_out);
+              const double *lb, const double *ub, const bool *be, double eps_rel, int max_newton, double *sol, int *newton_out,
+              double *warm_x, double *warm_y, bool warm_in);
 }
 
 namespace {
@@ -54,7 +55,7 @@ int run_nv(const uint32_t nc, const double *Hd, const double *c, const double *A
 
 QPWrapperHost::QPWrapperHost(const uint32_t nv, const uint32_t nc, const bool diagonalCost)
     : QPWrapperAbstract(nv, nc, diagonalCost), H_(activeSet(nv, nc, diagonalCost) ? 0 : (size_t)nv * nv, 0.0), Hd_(nv, 0.0), c_(nv, 0.0), A_((size_t)nc * nv, 0.0), b_(nc, 0.0),
-      lb_(nv, 0.0), ub_(nv, 0.0), sol_(nv, 0.0), status_(-10), steps_(0), ready_(false)
+      lb_(nv, 0.0), ub_(nv, 0.0), sol_(nv, 0.0), warmX_(nv, 0.0), warmY_((size_t)nc + nv, 0.0), status_(-10), steps_(0), ready_(false)
 {
 }
 
@@ -67,6 +68,7 @@ int32_t QPWrapperHost::initialize(const double H[], const double c[], const doub
 	if (be != nullptr)
 		for (uint32_t i = 0; i < nc_; i++) be_[i] = be[i];
 	ready_ = true;
+	haveWarm_ = false; // osqp_setup: a fresh workspace, its first solve is cold
 	updateCost(H, c);
 	updateA(A);
 	updateb(b);
@@ -110,7 +112,9 @@ int32_t QPWrapperHost::solve(void)
 	if (!activeSet(nv_, nc_, diagonalCost_)) {
 		int nw = 0;
 		status_ = hostqp::solve_alm((int)nv_, (int)nc_, diagonalCost_, H_.data(), c_.data(), A_.data(), b_.data(), lb_.data(),
-		                            ub_.data(), be_, epsRel, maxNewton, sol_.data(), &nw);
+		                            ub_.data(), be_, epsRel, maxNewton, sol_.data(), &nw, warmX_.data(), warmY_.data(),
+		                            warmStart && haveWarm_);
+		haveWarm_ = true;
 		steps_ = nw;
 		return status_;
 	}

@@ -24,6 +24,9 @@
  *   asif_hip_qp_solve_batch    replaces  the QPWrapperAbstract solve path for pre-assembled problems
  *                                        (include/qpwrapper_abstract.h:16-51; src/qpwrapper_osqp.cpp:55-261:
  *                                         initialize + solve + getSolution, cold start).
+ *   asif_hip_qp_solve_batch_warm  replaces  the second and later solve() calls of one OSQP workspace
+ *                                        (src/qpwrapper_osqp.cpp:217-245 on OSQP's default warm_start = 1, which
+ *                                         the wrapper leaves on, :68-69): start from the previous x and y.
  *
  * Conventions
  *   - plain C, no C++/torch/HIP types in any signature; `stream` is a hipStream_t passed as void* (NULL = default).
@@ -362,6 +365,23 @@ int asif_hip_qp_solve_batch_dense(int device, const asif_hip_solver *solver, int
                                   int32_t nc, const double *H, const double *c, const double *A, const double *b,
                                   const double *lb, const double *ub, const uint8_t *be, double *sol,
                                   int32_t *status, int32_t *iters, void *stream);
+
+/* The same solve as the two entries above (pass Hd OR H, the other NULL) with the start OSQP's warm_start = 1 gives
+ * the reference's closed loops: between two solve() calls of one workspace OSQP keeps its iterate and multipliers
+ * (the wrapper never switches that off, src/qpwrapper_osqp.cpp:68-69 sets max_iter only).
+ * warm_x[nv][ld], warm_y[(nc + nv)][ld]: the iterate and the multipliers of the rows [A; I] in the caller's units
+ * (OSQP's x and y).  Every call WRITES them -- the final x and y of a problem whose verdict is "solved", zeros
+ * (= a cold start) otherwise; warm_in != 0 makes the call READ them first as its starting point (non-finite entries
+ * count as zero).  The optimum does not depend on the start: same verdicts, solutions equal within the solver's
+ * tolerance, fewer Newton steps (a problem that has not changed since the buffers were written takes none).
+ * Applies to the wave-level kernels (qp_inv.hpp / qp_lds.hpp: every shape with nv > 3, full cost matrices), default
+ * solver modes; the in-register kernels of the nv <= 3 shapes decide in their exact dual active-set stage and the
+ * plain ADMM of solver.polish == 0 keeps its cold two-launch form -- both leave the buffers untouched. */
+int asif_hip_qp_solve_batch_warm(int device, const asif_hip_solver *solver, int64_t B, int64_t ld, int32_t nv,
+                                 int32_t nc, const double *Hd, const double *H, const double *c, const double *A,
+                                 const double *b, const double *lb, const double *ub, const uint8_t *be, double *sol,
+                                 int32_t *status, int32_t *iters, double *warm_x, double *warm_y, int32_t warm_in,
+                                 void *stream);
 
 /* Host-buffer convenience (pinned or pageable host memory, blocking): H2D, filter, D2H.  AoS->SoA is the
  * caller's business: same [component][ld] layout.  Used by the C++ class mirror for single agents. */

@@ -8,14 +8,16 @@
 namespace ASIF {
 namespace hostqp {
 int solve_alm(int nv, int nc, bool diag, const double *H, const double *c, const double *A, const double *b,
-              const double *lb, const double *ub, const bool *be, double eps_rel, int max_newton, double *sol, int *newton_out);
+              const double *lb, const double *ub, const bool *be, double eps_rel, int max_newton, double *sol, int *newton_out,
+              double *warm_x, double *warm_y, bool warm_in);
 }
 } // namespace ASIF
 
 // AoS per instance like or_qp_solve_batch.  diag != 0: Hd[nv] per instance; else H[nv*nv] column-major per instance.
 extern "C" int alm_host_solve_batch(int nv, int nc, int64_t B, int diag, const double *H, const double *c, const double *A,
                                     const double *b, const double *lb, const double *ub, const uint8_t *be, double eps_rel,
-                                    int max_newton, double *sol, int32_t *status, int32_t *newton)
+                                    int max_newton, double *sol, int32_t *status, int32_t *newton, double *warm_x,
+                                    double *warm_y, int warm_in)
 {
 	std::vector<double> Hf((size_t)nv * nv, 0.0);
 	std::vector<uint8_t> beb(nc > 0 ? nc : 1, 0);
@@ -31,7 +33,8 @@ extern "C" int alm_host_solve_batch(int nv, int nc, int64_t B, int diag, const d
 		int nw = 0;
 		status[i] = ASIF::hostqp::solve_alm(nv, nc, diag != 0, Hi, c + i * nv, A + i * (size_t)nc * nv, b + i * nc, lb + i * nv,
 		                                    ub + i * nv, reinterpret_cast<const bool *>(beb.data()), eps_rel, max_newton,
-		                                    sol + i * nv, &nw);
+		                                    sol + i * nv, &nw, warm_x ? warm_x + i * nv : nullptr,
+		                                    warm_y ? warm_y + i * (size_t)(nc + nv) : nullptr, warm_in != 0);
 		newton[i] = nw;
 	}
 	return 0;

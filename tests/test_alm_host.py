@@ -25,7 +25,8 @@ def alm(tmp_path_factory):
                                os.path.join(ROOT, "asif_amd", "host", "qp_alm_host.cpp"), "-o", so])
     lib = C.CDLL(so)
 
-    def solve(nv, nc, H, c, A, b, lb, ub, be=None, diag=True, eps=1e-8, max_newton=400):
+    def solve(nv, nc, H, c, A, b, lb, ub, be=None, diag=True, eps=1e-8, max_newton=400, warm=None, warm_in=False):
+        # warm = (x [B, nv], y [B, nc + nv]) float64 C-contiguous arrays, written by the call, read first with warm_in
         B = c.shape[0]
         arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (H, c, A, b, lb, ub)]
         sol = np.zeros((B, nv))
@@ -33,8 +34,10 @@ def alm(tmp_path_factory):
         nw = np.zeros(B, dtype=np.int32)
         P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
         bep = np.ascontiguousarray(be, dtype=np.uint8).ctypes.data_as(C.POINTER(C.c_uint8)) if be is not None else None
+        wx, wy = (P(warm[0]), P(warm[1])) if warm is not None else (None, None)
         r = lib.alm_host_solve_batch(nv, nc, C.c_int64(B), int(diag), *[P(a) for a in arrs], bep, C.c_double(eps), max_newton,
-                                     P(sol), st.ctypes.data_as(C.POINTER(C.c_int32)), nw.ctypes.data_as(C.POINTER(C.c_int32)))
+                                     P(sol), st.ctypes.data_as(C.POINTER(C.c_int32)), nw.ctypes.data_as(C.POINTER(C.c_int32)),
+                                     wx, wy, int(warm_in))
         assert r == 0
         return sol, st, nw
     return solve
@@ -155,3 +158,69 @@ def test_data_outside_the_domain_and_budget(alm, oracle):
     assert np.array_equal(st[good], stref[good]) and np.array_equal(sol[good], ref[good])
     sol1, st1, nw1 = alm(d.nv, d.nc, Hd, c, A, b, lb, ub, be, max_newton=1)
     assert np.all(nw1 <= 1) and np.any(st1 == -2)
+
+
+def test_warm_start_realizable_two_control_steps(alm, oracle):
+    """OSQP's warm_start = 1 between two solve() calls of one workspace (the reference's wrapper leaves it on,
+    src/qpwrapper_osqp.cpp:68-69): the 38 x 29 problem of ASIFrealizable at a state and at the state a plant step later,
+    the second solve started from the first one's iterate and multipliers.  Same verdicts, |u - u_ref| <= 1e-6, less
+    than half the Newton steps of a cold solve."""
+    k = oracle.load_kernel("100Hz")
+    z = oracle.Realizable(k)
+    B = 256
+    x, u = oracle.make_batch_realizable(k, B)
+    rng = np.random.default_rng(38)
+    x2 = x + 0.002 * rng.normal(size=x.shape)
+    keep = (z.assemble(x)[2] == 1) & (z.assemble(x2)[2] == 1)
+    x, x2, u = x[keep], x2[keep], u[keep]
+    n = len(x)
+
+    def qps(x):
+        A, b, code, info = z.assemble(x)
+        Hd, c, lb, ub = (np.zeros((n, z.nv)) for _ in range(4))
+        for i in range(n):
+            Hd[i], c[i], lb[i], ub[i], be = z.qp_static(u[i])
+        H = np.zeros((n, z.nv * z.nv))
+        H[:, :: z.nv + 1] = Hd
+        return H, c, A, b, lb, ub, be
+
+    ua, rl, rc = z.filter(x2, u)
+    warm = (np.full((n, z.nv), np.nan), np.full((n, z.nv + z.nc), np.nan))
+    s1, st1, n1 = alm(z.nv, z.nc, *qps(x), diag=False, warm=warm)
+    assert np.all(np.isfinite(warm[0])) and np.all(np.isfinite(warm[1]))
+    assert np.array_equal(warm[0][st1 == 1], s1[st1 == 1]) and np.all(warm[0][st1 != 1] == 0.0)
+    q2 = qps(x2)
+    sw, stw, nw = alm(z.nv, z.nc, *q2, diag=False, warm=warm, warm_in=True)
+    sc, stc, nc_ = alm(z.nv, z.nc, *q2, diag=False)
+    assert np.array_equal(stw == 1, rc == 1) and np.array_equal(stc == 1, rc == 1)
+    ok = rc == 1
+    assert ok.sum() > 100
+    assert np.abs(sw[ok, 0].clip(-20, 20) - ua[ok, 0]).max() <= U_TOL
+    assert nw[ok].sum() < 0.5 * nc_[ok].sum()
+
+
+def test_warm_start_robust_18x12(alm, oracle):
+    """The lifted robust problem needs four Newton steps from a cold start; a warm one is no shorter on a randomly moved
+    state (it is in the closed loops, where the active set stays) -- what must hold is the answer."""
+    B = 1024
+    d, Hd, c, A, b, lb, ub, be = _config_qps(oracle, 5, B)
+    model, variant = oracle.CONFIGS[5]
+    o = oracle.default_options(model, variant)
+    x, u = oracle.make_batch(5, B)
+    rng = np.random.default_rng(5)
+    x2 = x + 0.005 * rng.normal(size=x.shape)
+    A2, b2, code, _ = oracle.assemble_batch(model, variant, o, x2)
+    ua, rl, rc = oracle.filter_batch(model, variant, o, x2, u, oracle.SOLVER_EXACT)
+    H = np.zeros((B, d.nv * d.nv))
+    H[:, :: d.nv + 1] = Hd
+    warm = (np.zeros((B, d.nv)), np.zeros((B, d.nv + d.nc)))
+    s1, st1, n1 = alm(d.nv, d.nc, H, c, A, b, lb, ub, be, diag=False, warm=warm)
+    s0, st0, n0 = alm(d.nv, d.nc, H, c, A, b, lb, ub, be, diag=False)
+    assert np.array_equal(s1, s0) and np.array_equal(n1, n0)  # writing the block changes nothing
+    sw, stw, nw = alm(d.nv, d.nc, H, c, A2, b2, lb, ub, be, diag=False, warm=warm, warm_in=True)
+    assert np.array_equal(stw, rc)
+    assert np.abs(sw[:, 0].clip(o.lb[0], o.ub[0]) - ua[:, 0]).max() <= U_TOL
+    assert np.abs(sw[:, 1] - rl[:, 0]).max() <= U_TOL
+    # the unchanged problem: two multiplier updates, next to no Newton steps
+    su, stu, nu = alm(d.nv, d.nc, H, c, A2, b2, lb, ub, be, diag=False, warm=warm, warm_in=True)
+    assert np.array_equal(stu, rc) and nu.mean() <= 3 and np.abs(su[:, :2] - sw[:, :2]).max() <= U_TOL

@@ -280,6 +280,14 @@ def test_robust_pendulum_closed_loop(hip, oracle, p, ud, steps):
     check_robust_pendulum_closed_loop(oracle, p, ud, steps, "hip")
 
 
+@pytest.mark.parametrize("p,ud,steps", [(0.8, 0.0, 280), (1.0, 1.5, 155)])
+def test_robust_pendulum_closed_loop_warm_started(hip, oracle, p, ud, steps, monkeypatch):
+    """The same loops with QPWrapperHip::warmStart on (ASIF_HIP_QP_WARM=1): every solve() after the first starts from
+    the previous control step's iterate and multipliers, as the reference's OSQP workspace does.  Same bar."""
+    monkeypatch.setenv("ASIF_HIP_QP_WARM", "1")
+    check_robust_pendulum_closed_loop(oracle, p, ud, steps, "hip")
+
+
 def check_robust_pendulum_closed_loop(oracle, p, ud, steps, solver):
     """The main() loop of examples/InvertedPendulum_Robust.cpp:134-175 (ROBUST flavour: steps of 10 ms from (0.5, 0), plant
     gain p in {pMin, 1, pMax}) through ASIF::ASIFrobust: each step's affine-arithmetic rows on the host and its
