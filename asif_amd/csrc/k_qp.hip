@@ -224,6 +224,15 @@ int launch_qp_lds(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
 		return v && v[0] == '0';
 	}();
 	if (!a.H && a.nv <= 32 && a.nc <= 32 && !inv_off) {
+		// ASIFrobust with four safety functions, 18 x 12 (BASELINE's C5 lifted), at its own size: the padded <20, 16>
+		// walks two zero columns and four zero rows in every product -- a tenth / a quarter of each loop, and the loops
+		// are the kernel.  Zeros added to the same two chains: the same bits (tests/test_gpu_qp_lds.py).
+		// ASIF_HIP_QP_INV_EXACT=0: developer switch, the padded size.
+		static const bool exact_off = []() {
+			const char *v = getenv("ASIF_HIP_QP_INV_EXACT");
+			return v && v[0] == '0';
+		}();
+		if (a.nv == 18 && a.nc == 12 && !exact_off) return launch_inv<18, 12>(S, a, stream);
 		if (a.nv <= 8) return launch_inv_nc<8>(S, a, stream);
 		if (a.nv <= 20) return launch_inv_nc<20>(S, a, stream); // ASIFrobust with four safety functions: 18 x 12
 		if (a.nv <= 24) return launch_inv_nc<24>(S, a, stream); // five: 22 x 15

@@ -262,3 +262,32 @@ def test_two_problems_per_wave_do_not_see_each_other(hip, oracle, B):
     sh = _solve(hip, Hd[1:B + 1], c[1:B + 1], A[1:B + 1], b[1:B + 1], lb[1:B + 1], ub[1:B + 1], be)
     for x, y in zip(full, sh):
         assert np.array_equal(x[1:B + 1], y)
+
+
+def test_exact_size_18x12_instantiation_gives_the_padded_one_s_bits(oracle, tmp_path):
+    """18 x 12 runs on qp_inv_kernel<18, 12> instead of the padded <20, 16> (k_qp.hip): the padding only ever added zeros
+    to the same summation chains, so solution, status and Newton count are the same bits.  The developer switch
+    ASIF_HIP_QP_INV_EXACT=0 is read once per process: two child processes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})\n"
+        "import oracle_lib as O; O.build()\n"
+        "from asif_amd import capi\n"
+        "from test_gpu_qp_generic import _config_qps, _solve\n"
+        "d, Hd, c, A, b, lb, ub, be = _config_qps(O, 5, 4096)\n"
+        "sol, st, it = _solve(capi, Hd, c, A, b, lb, ub, be)\n"
+        "np.savez(sys.argv[1], sol=sol, st=st, it=it)\n")
+    outs = []
+    for exact in ("1", "0"):
+        f = str(tmp_path / f"exact{exact}.npz")
+        env = dict(os.environ, ASIF_HIP_QP_INV_EXACT=exact)
+        r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(f))
+    a, b = outs
+    assert np.all(a["st"] == 1) and np.array_equal(a["st"], b["st"]) and np.array_equal(a["it"], b["it"])
+    assert np.array_equal(a["sol"], b["sol"])
