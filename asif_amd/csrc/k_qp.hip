@@ -197,7 +197,10 @@ static int launch_inv(const asif_hip_solver &S0, const QpArgs &a, hipStream_t st
 	constexpr int QPW = 64 / HW;
 	const size_t bytes = QPW * inv_half_doubles(NVMAX, NCMAX, HW) * sizeof(double);
 	auto kern = qp_inv_kernel<NVMAX, NCMAX, HW>;
-	if constexpr (HW == 32) {
+	// <18, 12> and <8, 16> need 253 / 251 registers as they are: two waves fit a SIMD without the tighter allocation,
+	// whose code is slower at every batch size (18 x 12: 250 against 295 us per 16 384, 753 against 897 per 65 536)
+	constexpr bool fits_two = (NVMAX == 18 && NCMAX == 12) || (NVMAX == 8 && NCMAX == 16);
+	if constexpr (HW == 32 && !fits_two) {
 		if (a.B >= kInvTwoWavesMin) kern = qp_inv_kernel<NVMAX, NCMAX, HW, 2>; // eight waves' worth of problems per SIMD: qp_inv.hpp, MINW
 	}
 	if (a.warm_x) kern = qp_inv_kernel<NVMAX, NCMAX, HW, 1, true>; // closed loops: batches of one to a few thousand
@@ -233,6 +236,7 @@ int launch_qp_lds(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
 			return v && v[0] == '0';
 		}();
 		if (a.nv == 18 && a.nc == 12 && !exact_off) return launch_inv<18, 12>(S, a, stream);
+		if (a.nv == 22 && a.nc <= 16 && !exact_off) return launch_inv<22, 16>(S, a, stream); // five safety functions: 22 x 15
 		if (a.nv <= 8) return launch_inv_nc<8>(S, a, stream);
 		if (a.nv <= 20) return launch_inv_nc<20>(S, a, stream); // ASIFrobust with four safety functions: 18 x 12
 		if (a.nv <= 24) return launch_inv_nc<24>(S, a, stream); // five: 22 x 15

@@ -46,7 +46,27 @@ def test_robust_full_18x12_every_instance(hip, oracle):
 def test_two_waves_per_simd_instantiation_gives_the_same_bits(hip, oracle):
     """From 16 384 problems on the half-wave kernel is launched with its register allocation held to two waves per
     SIMD (k_qp.hip: kInvTwoWavesMin) -- other code, with spills: same solution, status and Newton count, bit for
-    bit, as the one-wave build gives the same problems in a batch of 4 096."""
+    bit, as the one-wave build gives the same problems in a batch of 2 048.  On the 22 x 15 problems of the shipped
+    half-planes (the 18 x 12 instantiation fits two waves as it is and has no second build)."""
+    hp = oracle.load_halfplanes()
+    z = oracle.RobustData(hp)
+    B = 2048
+    x, u = oracle.make_batch_robust_data(hp, B)
+    A, b, code, sel = z.assemble(x)
+    Hd, c, lb, ub = (np.zeros((B, z.nv)) for _ in range(4))
+    for i in range(B):
+        Hd[i], c[i], lb[i], ub[i], be = z.qp_static(u[i])
+    sol1, st1, it1 = _solve(hip, Hd, c, A, b, lb, ub, be)
+    rep = lambda a: np.tile(a, (8, 1))
+    sol8, st8, it8 = _solve(hip, rep(Hd), rep(c), rep(A), rep(b), rep(lb), rep(ub), be)
+    assert len(st8) == 16384 and (st1 == 1).sum() > 1000 and (st1 != 1).sum() > 100
+    for k in range(8):
+        blk = slice(B * k, B * (k + 1))
+        assert np.array_equal(st8[blk], st1) and np.array_equal(it8[blk], it1)
+        assert np.array_equal(sol8[blk], sol1)
+
+
+def test_large_batch_of_18x12_equals_small_batches(hip, oracle):
     d, Hd, c, A, b, lb, ub, be = _config_qps(oracle, 5, 4096)
     sol1, st1, it1 = _solve(hip, Hd, c, A, b, lb, ub, be)
     rep = lambda a: np.tile(a, (4, 1))
@@ -265,7 +285,8 @@ def test_two_problems_per_wave_do_not_see_each_other(hip, oracle, B):
 
 
 def test_exact_size_18x12_instantiation_gives_the_padded_one_s_bits(oracle, tmp_path):
-    """18 x 12 runs on qp_inv_kernel<18, 12> instead of the padded <20, 16> (k_qp.hip): the padding only ever added zeros
+    """18 x 12 runs on qp_inv_kernel<18, 12> instead of the padded <20, 16>, 22 x 15 on <22, 16> instead of <24, 16>
+    (k_qp.hip): the padding only ever added zeros
     to the same summation chains, so solution, status and Newton count are the same bits.  The developer switch
     ASIF_HIP_QP_INV_EXACT=0 is read once per process: two child processes."""
     import os
@@ -280,7 +301,12 @@ def test_exact_size_18x12_instantiation_gives_the_padded_one_s_bits(oracle, tmp_
         "from test_gpu_qp_generic import _config_qps, _solve\n"
         "d, Hd, c, A, b, lb, ub, be = _config_qps(O, 5, 4096)\n"
         "sol, st, it = _solve(capi, Hd, c, A, b, lb, ub, be)\n"
-        "np.savez(sys.argv[1], sol=sol, st=st, it=it)\n")
+        "hp = O.load_halfplanes(); z = O.RobustData(hp); B = 1024\n"
+        "x, u = O.make_batch_robust_data(hp, B); A, b, code, sel = z.assemble(x)\n"
+        "Hd, c, lb, ub = (np.zeros((B, z.nv)) for _ in range(4))\n"
+        "for i in range(B): Hd[i], c[i], lb[i], ub[i], be = z.qp_static(u[i])\n"
+        "sol2, st2, it2 = _solve(capi, Hd, c, A, b, lb, ub, be)\n"
+        "np.savez(sys.argv[1], sol=sol, st=st, it=it, sol2=sol2, st2=st2, it2=it2)\n")
     outs = []
     for exact in ("1", "0"):
         f = str(tmp_path / f"exact{exact}.npz")
@@ -291,3 +317,6 @@ def test_exact_size_18x12_instantiation_gives_the_padded_one_s_bits(oracle, tmp_
     a, b = outs
     assert np.all(a["st"] == 1) and np.array_equal(a["st"], b["st"]) and np.array_equal(a["it"], b["it"])
     assert np.array_equal(a["sol"], b["sol"])
+    # 22 x 15 on <22, 16> against <24, 16>, infeasible problems included
+    assert (a["st2"] != 1).sum() > 50 and np.array_equal(a["st2"], b["st2"]) and np.array_equal(a["it2"], b["it2"])
+    assert np.array_equal(a["sol2"], b["sol2"])
