@@ -245,6 +245,11 @@ int launch_qp_lds(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
 	// 32 < nv or nc <= 64, diagonal cost: the same kernel with the whole wave on one problem (ASIFrealizable's lifted
 	// problems: 38 x 29 on the 100 Hz kernel, 62 x 47 on the 50-point one)
 	if (!a.H && a.nv <= 64 && a.nc <= 64 && !inv_off) {
+		static const bool exact_off = []() { // (ASIF_HIP_QP_INV_EXACT=0: the padded sizes, as above)
+			const char *v = getenv("ASIF_HIP_QP_INV_EXACT");
+			return v && v[0] == '0';
+		}();
+		if (a.nv == 38 && a.nc <= 30 && a.nc > 16 && !exact_off) return launch_inv<38, 30, 64>(S, a, stream); // ASIFrealizable, 100 Hz kernels: 38 x 29
 		if (a.nv <= 40) return a.nc <= 32 ? launch_inv<40, 32, 64>(S, a, stream) : launch_inv<40, 64, 64>(S, a, stream);
 		return a.nc <= 48 ? launch_inv<64, 48, 64>(S, a, stream) : launch_inv<64, 64, 64>(S, a, stream);
 	}

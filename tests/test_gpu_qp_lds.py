@@ -286,7 +286,7 @@ def test_two_problems_per_wave_do_not_see_each_other(hip, oracle, B):
 
 def test_exact_size_18x12_instantiation_gives_the_padded_one_s_bits(oracle, tmp_path):
     """18 x 12 runs on qp_inv_kernel<18, 12> instead of the padded <20, 16>, 22 x 15 on <22, 16> instead of <24, 16>
-    (k_qp.hip): the padding only ever added zeros
+    (k_qp.hip), 38 x 29 on the whole-wave <38, 30, 64> instead of <40, 32, 64>: the padding only ever added zeros
     to the same summation chains, so solution, status and Newton count are the same bits.  The developer switch
     ASIF_HIP_QP_INV_EXACT=0 is read once per process: two child processes."""
     import os
@@ -306,7 +306,12 @@ def test_exact_size_18x12_instantiation_gives_the_padded_one_s_bits(oracle, tmp_
         "Hd, c, lb, ub = (np.zeros((B, z.nv)) for _ in range(4))\n"
         "for i in range(B): Hd[i], c[i], lb[i], ub[i], be = z.qp_static(u[i])\n"
         "sol2, st2, it2 = _solve(capi, Hd, c, A, b, lb, ub, be)\n"
-        "np.savez(sys.argv[1], sol=sol, st=st, it=it, sol2=sol2, st2=st2, it2=it2)\n")
+        "k = O.load_kernel('100Hz'); r = O.Realizable(k); x, u = O.make_batch_realizable(k, 256)\n"
+        "A, b, code, info = r.assemble(x); keep = code == 1; x, u, A, b = x[keep], u[keep], A[keep], b[keep]\n"
+        "Hd, c, lb, ub = (np.zeros((len(x), r.nv)) for _ in range(4))\n"
+        "for i in range(len(x)): Hd[i], c[i], lb[i], ub[i], be = r.qp_static(u[i])\n"
+        "sol3, st3, it3 = _solve(capi, Hd, c, A, b, lb, ub, be)\n"
+        "np.savez(sys.argv[1], sol=sol, st=st, it=it, sol2=sol2, st2=st2, it2=it2, sol3=sol3, st3=st3, it3=it3)\n")
     outs = []
     for exact in ("1", "0"):
         f = str(tmp_path / f"exact{exact}.npz")
@@ -320,3 +325,6 @@ def test_exact_size_18x12_instantiation_gives_the_padded_one_s_bits(oracle, tmp_
     # 22 x 15 on <22, 16> against <24, 16>, infeasible problems included
     assert (a["st2"] != 1).sum() > 50 and np.array_equal(a["st2"], b["st2"]) and np.array_equal(a["it2"], b["it2"])
     assert np.array_equal(a["sol2"], b["sol2"])
+    # 38 x 29 on the whole-wave <38, 30, 64> against <40, 32, 64>
+    assert len(a["st3"]) > 100 and np.array_equal(a["st3"], b["st3"]) and np.array_equal(a["it3"], b["it3"])
+    assert np.array_equal(a["sol3"], b["sol3"])
