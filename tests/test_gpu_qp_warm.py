@@ -228,3 +228,39 @@ def test_argument_errors(hip):
         hip.qp_solve_batch_warm(z(5) + 1, z(25), z(5), z(10), z(2), z(5) - 1, z(5) + 1, z(5), st, z(5), z(7), False)
     with pytest.raises(hip.AsifHipError):  # no warm block
         hip.qp_solve_batch_warm(z(5) + 1, None, z(5), z(10), z(2), z(5) - 1, z(5) + 1, z(5), st, None, None, False)
+
+
+def test_ragged_batch_with_a_leading_dimension(hip, oracle):
+    """B = 37 (an odd batch: the last wave's second half has no problem) inside arrays of leading dimension 48: the same
+    bits as the dense call, the 11 columns beyond the batch untouched in every output."""
+    d, Hd, c, A, b, lb, ub, be = _config_qps(oracle, 5, 37)
+    B, ld = 37, 48
+    dev = torch.device("cuda:0")
+
+    def wide(a):  # [B, k] -> view [k, B] of a [k, ld] tensor whose other columns hold a marker
+        w = torch.full((a.shape[1], ld), 7.25, dtype=torch.float64, device=dev)
+        w[:, :B] = torch.from_numpy(np.ascontiguousarray(a.T)).to(dev)
+        return w
+    ins = [wide(a) for a in (Hd, c, A, b, lb, ub)]
+    outs = {k: torch.full((r, ld), -3.5, dtype=torch.float64, device=dev) for k, r in (("sol", 18), ("wx", 18), ("wy", 30))}
+    st = torch.full((ld,), -77, dtype=torch.int32, device=dev)
+    it = torch.full((ld,), -77, dtype=torch.int32, device=dev)
+    v = lambda t: t[:, :B]
+    hip.qp_solve_batch_warm(v(ins[0]), None, *[v(t) for t in ins[1:]], v(outs["sol"]), st[:B], v(outs["wx"]), v(outs["wy"]),
+                            False, iters=it[:B], be=be)
+    torch.cuda.synchronize()
+    ws = _Workspace(hip, B, 18, 12)
+    s0, st0, it0 = ws.solve(Hd, c, A, b, lb, ub, be, warm=False)
+    assert np.array_equal(outs["sol"][:, :B].cpu().numpy().T, s0) and np.array_equal(st[:B].cpu().numpy(), st0)
+    assert np.array_equal(outs["wx"][:, :B].cpu().numpy(), ws.wx.cpu().numpy())
+    assert np.array_equal(outs["wy"][:, :B].cpu().numpy(), ws.wy.cpu().numpy())
+    for t in outs.values():
+        assert np.all(t[:, B:].cpu().numpy() == -3.5)
+    assert np.all(st[B:].cpu().numpy() == -77) and np.all(it[B:].cpu().numpy() == -77)
+    # and a warm second call over the same strided block
+    hip.qp_solve_batch_warm(v(ins[0]), None, *[v(t) for t in ins[1:]], v(outs["sol"]), st[:B], v(outs["wx"]), v(outs["wy"]),
+                            True, iters=it[:B], be=be)
+    torch.cuda.synchronize()
+    assert np.array_equal(st[:B].cpu().numpy(), st0) and np.abs(outs["sol"][:2, :B].cpu().numpy().T - s0[:, :2]).max() <= U_TOL
+    for t in outs.values():
+        assert np.all(t[:, B:].cpu().numpy() == -3.5)
