@@ -3,7 +3,8 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2..12|qp] [--batch B] [--kernel 100Hz]
                     [--presolve 1] [--polish 0|1|2] [--no-cpu-baseline] [--no-pcie]
-                    [--shape c2|c3|c4|c5full|rz38|rz62|rz86] [--lanes 64]       (with --config qp)
+                    [--shape c2|c3|c4|c5full] [--lanes 64]       (with --config qp; the realizable filter's 38 x 29 ...
+                    86 x 65 and the shipped half-planes' 22 x 15: tools/dev_rz_time.py, tools/scratch/bench_rd22.py)
 
 One "step" = one pass of the filter (constraint assembly + in-kernel solve + saturation + return
 code) over one batch of synthetic states that is already resident in HBM when the timed region starts.
