@@ -197,9 +197,11 @@ static int launch_inv(const asif_hip_solver &S0, const QpArgs &a, hipStream_t st
 	constexpr int QPW = 64 / HW;
 	const size_t bytes = QPW * inv_half_doubles(NVMAX, NCMAX, HW) * sizeof(double);
 	auto kern = qp_inv_kernel<NVMAX, NCMAX, HW>;
-	// <18, 12> and <8, 16> need 253 / 251 registers as they are: two waves fit a SIMD without the tighter allocation,
-	// whose code is slower at every batch size (18 x 12: 250 against 295 us per 16 384, 753 against 897 per 65 536)
-	constexpr bool fits_two = (NVMAX == 18 && NCMAX == 12) || (NVMAX == 8 && NCMAX == 16);
+	// <18, 12>, <14, 10>, <10, 6> and <8, 16> need 253 / 229 / 187 / 251 registers as they are: two waves fit a SIMD
+	// without the tighter allocation, whose code is slower at every batch size (18 x 12: 250 against 295 us per 16 384,
+	// 753 against 897 per 65 536)
+	constexpr bool fits_two = (NVMAX == 18 && NCMAX == 12) || (NVMAX == 8 && NCMAX == 16) || (NVMAX == 14 && NCMAX == 10) ||
+	                          (NVMAX == 10 && NCMAX == 6);
 	if constexpr (HW == 32 && !fits_two) {
 		if (a.B >= kInvTwoWavesMin) kern = qp_inv_kernel<NVMAX, NCMAX, HW, 2>; // eight waves' worth of problems per SIMD: qp_inv.hpp, MINW
 	}
@@ -227,16 +229,24 @@ int launch_qp_lds(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
 		return v && v[0] == '0';
 	}();
 	if (!a.H && a.nv <= 32 && a.nc <= 32 && !inv_off) {
-		// ASIFrobust with four safety functions, 18 x 12 (BASELINE's C5 lifted), at its own size: the padded <20, 16>
-		// walks two zero columns and four zero rows in every product -- a tenth / a quarter of each loop, and the loops
-		// are the kernel.  Zeros added to the same two chains: the same bits (tests/test_gpu_qp_lds.py).
-		// ASIF_HIP_QP_INV_EXACT=0: developer switch, the padded size.
+		// The lifted problem of ASIFrobust is (2 + 4 N) x 3 N for N safety functions (src/asif_robust.cpp:21-22): each N the
+		// library carries (up to ASIF_HIP_MAX_HALFPLANES = 8; N = 1 sits on <8, 16>, N = 8 on the whole-wave kernel below)
+		// has the kernel at its own size, rounded to even.  The padded grid below made 18 x 12 (BASELINE's C5 lifted) walk
+		// two zero columns and four zero rows in every product -- a tenth / a quarter of each loop, and the loops are the
+		// kernel -- and sent 26 x 18 to <32, 32>.  Zeros added to the same two chains: the same bits
+		// (tests/test_gpu_qp_lds.py).  ASIF_HIP_QP_INV_EXACT=0: developer switch, the padded sizes.
 		static const bool exact_off = []() {
 			const char *v = getenv("ASIF_HIP_QP_INV_EXACT");
 			return v && v[0] == '0';
 		}();
-		if (a.nv == 18 && a.nc == 12 && !exact_off) return launch_inv<18, 12>(S, a, stream);
-		if (a.nv == 22 && a.nc <= 16 && !exact_off) return launch_inv<22, 16>(S, a, stream); // five safety functions: 22 x 15
+		if (!exact_off) {
+			if (a.nv == 10 && a.nc <= 6) return launch_inv<10, 6>(S, a, stream);   // N = 2
+			if (a.nv == 14 && a.nc <= 10) return launch_inv<14, 10>(S, a, stream); // N = 3: 14 x 9
+			if (a.nv == 18 && a.nc == 12) return launch_inv<18, 12>(S, a, stream); // N = 4
+			if (a.nv == 22 && a.nc <= 16) return launch_inv<22, 16>(S, a, stream); // N = 5: 22 x 15 (DoubleIntegrator_Robust)
+			if (a.nv == 26 && a.nc <= 18) return launch_inv<26, 18>(S, a, stream); // N = 6
+			if (a.nv == 30 && a.nc <= 22) return launch_inv<30, 22>(S, a, stream); // N = 7: 30 x 21
+		}
 		if (a.nv <= 8) return launch_inv_nc<8>(S, a, stream);
 		if (a.nv <= 20) return launch_inv_nc<20>(S, a, stream); // ASIFrobust with four safety functions: 18 x 12
 		if (a.nv <= 24) return launch_inv_nc<24>(S, a, stream); // five: 22 x 15
@@ -249,6 +259,7 @@ int launch_qp_lds(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
 			const char *v = getenv("ASIF_HIP_QP_INV_EXACT");
 			return v && v[0] == '0';
 		}();
+		if (a.nv == 34 && a.nc <= 24 && !exact_off) return launch_inv<34, 24, 64>(S, a, stream); // ASIFrobust, N = 8
 		if (a.nv == 38 && a.nc <= 30 && a.nc > 16 && !exact_off) return launch_inv<38, 30, 64>(S, a, stream); // ASIFrealizable, 100 Hz kernels: 38 x 29
 		if (a.nv <= 40) return a.nc <= 32 ? launch_inv<40, 32, 64>(S, a, stream) : launch_inv<40, 64, 64>(S, a, stream);
 		return a.nc <= 48 ? launch_inv<64, 48, 64>(S, a, stream) : launch_inv<64, 64, 64>(S, a, stream);

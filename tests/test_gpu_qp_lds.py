@@ -311,7 +311,13 @@ def test_exact_size_18x12_instantiation_gives_the_padded_one_s_bits(oracle, tmp_
         "Hd, c, lb, ub = (np.zeros((len(x), r.nv)) for _ in range(4))\n"
         "for i in range(len(x)): Hd[i], c[i], lb[i], ub[i], be = r.qp_static(u[i])\n"
         "sol3, st3, it3 = _solve(capi, Hd, c, A, b, lb, ub, be)\n"
-        "np.savez(sys.argv[1], sol=sol, st=st, it=it, sol2=sol2, st2=st2, it2=it2, sol3=sol3, st3=st3, it3=it3)\n")
+        "from test_gpu_qp_lds import _robust_qps_with_n_halfplanes\n"
+        "extra = {}\n"
+        "for N in (2, 3, 6, 7, 8):\n"
+        "    d, q, _ = _robust_qps_with_n_halfplanes(O, N, 256)\n"
+        "    s_, st_, it_ = _solve(capi, *q)\n"
+        "    extra[f'solN{N}'], extra[f'stN{N}'], extra[f'itN{N}'] = s_, st_, it_\n"
+        "np.savez(sys.argv[1], sol=sol, st=st, it=it, sol2=sol2, st2=st2, it2=it2, sol3=sol3, st3=st3, it3=it3, **extra)\n")
     outs = []
     for exact in ("1", "0"):
         f = str(tmp_path / f"exact{exact}.npz")
@@ -328,3 +334,46 @@ def test_exact_size_18x12_instantiation_gives_the_padded_one_s_bits(oracle, tmp_
     # 38 x 29 on the whole-wave <38, 30, 64> against <40, 32, 64>
     assert len(a["st3"]) > 100 and np.array_equal(a["st3"], b["st3"]) and np.array_equal(a["it3"], b["it3"])
     assert np.array_equal(a["sol3"], b["sol3"])
+    # ASIFrobust's other sizes: 10 x 6, 14 x 9, 26 x 18, 30 x 21 (half-wave), 34 x 24 (whole-wave)
+    for N in (2, 3, 6, 7, 8):
+        for k in ("sol", "st", "it"):
+            assert np.array_equal(a[f"{k}N{N}"], b[f"{k}N{N}"]), (N, k)
+
+
+def _robust_qps_with_n_halfplanes(oracle, N, B):
+    """The lifted (2 + 4 N) x 3 N problem of ASIFrobust for a safe set of N half-planes 1 - a_k . x >= 0, a_k spread
+    round the circle at the radius of BASELINE's C5 box (1 / pi), on C5's seeded states."""
+    model, variant = oracle.CONFIGS[5]
+    o = oracle.default_options(model, variant)
+    o.nHalfPlanes = N
+    for k in range(N):
+        th = 2 * np.pi * (k + 0.25) / N
+        o.halfPlanes[2 * k] = np.cos(th) / np.pi
+        o.halfPlanes[2 * k + 1] = np.sin(th) / np.pi
+    d = oracle.dims(model, variant, o)
+    assert (d.nv, d.nc) == (2 + 4 * N, 3 * N)
+    x, u = oracle.make_batch(5, B)
+    A, b, code, _ = oracle.assemble_batch(model, variant, o, x)
+    assert np.all(code == 1)
+    Hd, c, lb, ub = (np.zeros((B, d.nv)) for _ in range(4))
+    for i in range(B):
+        Hd[i], c[i], lb[i], ub[i], be = oracle.qp_static(model, variant, o, u[i])
+    ua, rl, rc = oracle.filter_batch(model, variant, o, x, u, oracle.SOLVER_EXACT)
+    return d, (Hd, c, A, b, lb, ub, be), (o, ua, rl, rc)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 5, 6, 7, 8])
+def test_robust_lifted_problem_for_every_number_of_safety_functions(hip, oracle, N):
+    """ASIFrobust hands its solver a (2 + 4 N) x 3 N problem (src/asif_robust.cpp:21-22): 6 x 3 ... 34 x 24 for the
+    N = 1 ... 8 the library carries -- each on a kernel of its own size (k_qp.hip; N = 4 is the 18 x 12 above).  Status
+    equal to the oracle's exact filter on every instance, |u - u_ref| <= 1e-6; the relaxation, which reaches the
+    hundreds on the states far outside these sets, to 1e-5 of its size (the closed-loop tests' bar)."""
+    B = 1024
+    d, q, (o, ua, rl, rc) = _robust_qps_with_n_halfplanes(oracle, N, B)
+    sol, st, it = _solve(hip, *q)
+    assert np.array_equal(st == 1, rc == 1), f"{((st == 1) != (rc == 1)).sum()} status mismatches"
+    ok = rc == 1
+    assert ok.sum() > B // 2
+    assert np.abs(sol[ok, 0].clip(o.lb[0], o.ub[0]) - ua[ok, 0]).max() <= U_TOL
+    assert (np.abs(sol[ok, 1] - rl[ok, 0]) / np.maximum(1.0, np.abs(rl[ok, 0]))).max() <= 1e-5
+    print(f"N={N}: max|delta| {np.abs(rl[ok, 0]).max():.1f}, max|delta - delta_ref| {np.abs(sol[ok, 1] - rl[ok, 0]).max():.1e}")
