@@ -201,7 +201,7 @@ static int launch_inv(const asif_hip_solver &S0, const QpArgs &a, hipStream_t st
 	// without the tighter allocation, whose code is slower at every batch size (18 x 12: 250 against 295 us per 16 384,
 	// 753 against 897 per 65 536)
 	constexpr bool fits_two = (NVMAX == 18 && NCMAX == 12) || (NVMAX == 8 && NCMAX == 16) || (NVMAX == 14 && NCMAX == 10) ||
-	                          (NVMAX == 10 && NCMAX == 6);
+	                          (NVMAX == 10 && NCMAX == 6) || (NVMAX == 6 && NCMAX == 4);
 	if constexpr (HW == 32 && !fits_two) {
 		if (a.B >= kInvTwoWavesMin) kern = qp_inv_kernel<NVMAX, NCMAX, HW, 2>; // eight waves' worth of problems per SIMD: qp_inv.hpp, MINW
 	}
@@ -230,7 +230,7 @@ int launch_qp_lds(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
 	}();
 	if (!a.H && a.nv <= 32 && a.nc <= 32 && !inv_off) {
 		// The lifted problem of ASIFrobust is (2 + 4 N) x 3 N for N safety functions (src/asif_robust.cpp:21-22): each N the
-		// library carries (up to ASIF_HIP_MAX_HALFPLANES = 8; N = 1 sits on <8, 16>, N = 8 on the whole-wave kernel below)
+		// library carries (up to ASIF_HIP_MAX_HALFPLANES = 8; N = 8 on the whole-wave kernel below)
 		// has the kernel at its own size, rounded to even.  The padded grid below made 18 x 12 (BASELINE's C5 lifted) walk
 		// two zero columns and four zero rows in every product -- a tenth / a quarter of each loop, and the loops are the
 		// kernel -- and sent 26 x 18 to <32, 32>.  Zeros added to the same two chains: the same bits
@@ -240,6 +240,7 @@ int launch_qp_lds(const asif_hip_solver &S, const QpArgs &a, hipStream_t stream)
 			return v && v[0] == '0';
 		}();
 		if (!exact_off) {
+			if (a.nv == 6 && a.nc <= 4) return launch_inv<6, 4>(S, a, stream);     // N = 1: 6 x 3
 			if (a.nv == 10 && a.nc <= 6) return launch_inv<10, 6>(S, a, stream);   // N = 2
 			if (a.nv == 14 && a.nc <= 10) return launch_inv<14, 10>(S, a, stream); // N = 3: 14 x 9
 			if (a.nv == 18 && a.nc == 12) return launch_inv<18, 12>(S, a, stream); // N = 4

@@ -313,7 +313,7 @@ def test_exact_size_18x12_instantiation_gives_the_padded_one_s_bits(oracle, tmp_
         "sol3, st3, it3 = _solve(capi, Hd, c, A, b, lb, ub, be)\n"
         "from test_gpu_qp_lds import _robust_qps_with_n_halfplanes\n"
         "extra = {}\n"
-        "for N in (2, 3, 6, 7, 8):\n"
+        "for N in (1, 2, 3, 6, 7, 8):\n"
         "    d, q, _ = _robust_qps_with_n_halfplanes(O, N, 256)\n"
         "    s_, st_, it_ = _solve(capi, *q)\n"
         "    extra[f'solN{N}'], extra[f'stN{N}'], extra[f'itN{N}'] = s_, st_, it_\n"
@@ -334,8 +334,8 @@ def test_exact_size_18x12_instantiation_gives_the_padded_one_s_bits(oracle, tmp_
     # 38 x 29 on the whole-wave <38, 30, 64> against <40, 32, 64>
     assert len(a["st3"]) > 100 and np.array_equal(a["st3"], b["st3"]) and np.array_equal(a["it3"], b["it3"])
     assert np.array_equal(a["sol3"], b["sol3"])
-    # ASIFrobust's other sizes: 10 x 6, 14 x 9, 26 x 18, 30 x 21 (half-wave), 34 x 24 (whole-wave)
-    for N in (2, 3, 6, 7, 8):
+    # ASIFrobust's other sizes: 6 x 3, 10 x 6, 14 x 9, 26 x 18, 30 x 21 (half-wave), 34 x 24 (whole-wave)
+    for N in (1, 2, 3, 6, 7, 8):
         for k in ("sol", "st", "it"):
             assert np.array_equal(a[f"{k}N{N}"], b[f"{k}N{N}"]), (N, k)
 
